@@ -1,0 +1,848 @@
+// Acquisition: host orchestration of the PRN x Doppler parallel code-phase search.
+//
+// Replaces BDS-3_B2a/acquisition.m:126-336 and BDS-3_B1C/acquisition.m:125-307 (and
+// B1C/GPU_acquisition.m, which is the same algorithm on gpuArray built-ins).
+//
+// How the search is organised here (DESIGN.md has the full derivation):
+//  * The reference's circular correlation of length N (2 code periods, code zero beyond
+//    X samples) is evaluated as a linear correlation of the code with the periodic
+//    extension of the wiped-off block, zero padded to a 5-smooth length
+//    L >= N + X - 1 -- identical lag for lag, and L has no factor 53 (N = 2^2 3 5^5 53 at
+//    99.375 MS/s).
+//  * Forward transforms run once per Doppler bin (the reference redoes them per PRN),
+//    code spectra once per PRN and are cached in the context.
+//  * Per (PRN, bin) cell: one row-pass kernel (spectrum product + inverse rows) and one
+//    column-pass kernel (inverse columns + |.| combine + max/argmax).  The D x N
+//    results matrix is never materialised.
+//  * fp32 is only a sieve: every cell within 2e-5 of a PRN's fp32 maximum (plus its
+//    +-1 bin / +-1 lag neighbours) is re-evaluated in f64 by direct time-domain
+//    correlation; peakSize, secondPeakSize, the fine-Doppler sums, sigPower and the
+//    DC mean are all f64 / exact-integer.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <map>
+#include <set>
+#include <tuple>
+
+#include "bds_acq_kernels.h"
+#include "bds_internal.h"
+
+namespace bds {
+
+static const double kPi = 3.14159265358979323846;
+
+// ---------------------------------------------------------------------------------------
+struct Plan2D {
+    long L = 0;
+    int L1 = 0, L2 = 0;
+    Plan1D p1{}, p2{};  // p1: columns (length L1), p2: rows (length L2)
+    TwiddleL twl{};
+    int logT = 0, Spad = 0, nt_cols = 0, nt_rows = 0, ntiles = 0;
+    size_t lds_cols = 0, lds_rows = 0;
+    float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_hi = nullptr, *d_lo = nullptr;
+};
+
+static bool is_5smooth(long v) {
+    for (int p : {2, 3, 5})
+        while (v % p == 0) v /= p;
+    return v == 1;
+}
+
+static void factor_radices(int S, Plan1D &p) {
+    // radix order: 4s first (cheapest per bit), then a 2, then 3s and 5s
+    int v = S, n = 0;
+    int rad[kMaxStages];
+    while (v % 4 == 0) rad[n++] = 4, v /= 4;
+    while (v % 2 == 0) rad[n++] = 2, v /= 2;
+    while (v % 3 == 0) rad[n++] = 3, v /= 3;
+    while (v % 5 == 0) rad[n++] = 5, v /= 5;
+    // larger radices late (their twiddle tables index stays small early): sort descending cost last
+    std::sort(rad, rad + n, [](int a, int b) { return a > b; });
+    p.S = S;
+    p.nstage = n;
+    int ns = 1;
+    for (int i = 0; i < n; ++i) {
+        p.radix[i] = rad[i];
+        p.nb[i] = FastDiv((uint32_t)(S / rad[i]));
+        p.ns[i] = FastDiv((uint32_t)ns);
+        p.tws[i] = S / (ns * rad[i]);
+        ns *= rad[i];
+    }
+}
+
+static constexpr int kMaxColLen = 1280;   // column-pass transform length limit (LDS: T*L1*8 B)
+static constexpr int kMaxRowLen = 8192;   // row-pass transform length limit
+static constexpr int kColPoints = 10240;  // T*L1 budget (80 KiB of LDS)
+
+static int stage_count(int S) {
+    Plan1D p{};
+    factor_radices(S, p);
+    return p.nstage;
+}
+
+// smallest 5-smooth L >= need that splits as L1*L2 within the kernel limits
+static bool choose_lengths(long need, long &L, int &L1, int &L2) {
+    for (long cand = std::max<long>(need, 16);; ++cand) {
+        if (cand > (long)kMaxColLen * kMaxRowLen) return false;
+        if (!is_5smooth(cand)) continue;
+        int best = 0;
+        for (int a = 2; a <= kMaxColLen && (long)a * a <= cand; ++a)
+            if (cand % a == 0 && cand / a <= kMaxRowLen && stage_count(a) <= kMaxStages &&
+                stage_count((int)(cand / a)) <= kMaxStages)
+                best = a;
+        if (best) {
+            L = cand;
+            L1 = best;
+            L2 = (int)(cand / best);
+            return true;
+        }
+    }
+}
+
+static int threads_for(long points) {
+    // (S/R)*T <= floor(16/R)*nthr for R in {2,3,4,5}  <=>  points <= 15*nthr
+    long nt = (points + 14) / 15;
+    nt = ((nt + 63) / 64) * 64;
+    return (int)std::min<long>(1024, std::max<long>(256, nt));
+}
+
+static void plan_free(Plan2D &pl) {
+    for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo})
+        if (*p) (void)hipFree(*p), *p = nullptr;
+}
+
+static int upload_twiddles(bds_ctx *ctx, int n, long denom, long step, float2 **dptr) {
+    // table[i] = exp(-2 pi j * (i*step) / denom), computed in f64
+    std::vector<float2> h((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const long m = ((long)i * step) % denom;
+        const double a = -2.0 * kPi * (double)m / (double)denom;
+        h[i] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * (size_t)n));
+    BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    return BDS_OK;
+}
+
+static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
+    plan_free(pl);
+    if (!choose_lengths(need, pl.L, pl.L1, pl.L2))
+        return fail(ctx, BDS_ERR_UNSUPPORTED, "no two-pass transform plan for length >= %ld", need);
+    factor_radices(pl.L1, pl.p1);
+    factor_radices(pl.L2, pl.p2);
+    int logT = 5;
+    while (logT > 0 && ((long)pl.L1 << logT) > kColPoints) --logT;
+    while (logT > 0 && (1 << logT) > pl.L2) --logT;
+    pl.logT = logT;
+    pl.Spad = pl.L1 | 1;
+    pl.ntiles = (pl.L2 + (1 << logT) - 1) >> logT;
+    pl.nt_cols = threads_for((long)pl.L1 << logT);
+    pl.nt_rows = threads_for(pl.L2);
+    if (((long)pl.L1 << logT) > 15L * pl.nt_cols || pl.L2 > 15L * pl.nt_rows)
+        return fail(ctx, BDS_ERR_UNSUPPORTED, "transform %d x %d exceeds the per-workgroup budget", pl.L1, pl.L2);
+    pl.lds_cols = sizeof(float2) * (size_t)pl.Spad * (size_t)(1 << logT);
+    pl.lds_rows = sizeof(float2) * (size_t)pl.L2;
+    int rc;
+    if ((rc = upload_twiddles(ctx, pl.L1, pl.L1, 1, &pl.d_tw1))) return rc;
+    if ((rc = upload_twiddles(ctx, pl.L2, pl.L2, 1, &pl.d_tw2))) return rc;
+    const int nhi = (int)((pl.L + (1L << kTwLoBits) - 1) >> kTwLoBits);
+    if ((rc = upload_twiddles(ctx, nhi, pl.L, 1L << kTwLoBits, &pl.d_hi))) return rc;
+    if ((rc = upload_twiddles(ctx, 1 << kTwLoBits, pl.L, 1, &pl.d_lo))) return rc;
+    pl.p1.tw = pl.d_tw1;
+    pl.p2.tw = pl.d_tw2;
+    pl.twl.hi = pl.d_hi;
+    pl.twl.lo = pl.d_lo;
+    return BDS_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+struct PrnResult {
+    double peak = 0, denom = 0;
+    int fbin = 0;  // 1-based
+    long codePhase = 0;
+    bool detected = false;
+};
+
+struct AcqState {
+    // key of everything cached below
+    int signal = 0, pilotACQ = 0, code_len = 0;
+    double fs = 0, cfb = 0, cohT = 0;
+    long spc = 0, X = 0, N = 0, n_ext = 0;
+    int ncomp = 0;
+    Plan2D plan;
+    CodeTable tab{};   // xlen = X (coarse)
+    // device buffers
+    int8_t *d_sig = nullptr;
+    size_t sig_cap = 0;
+    long n_samples = 0;
+    std::vector<int8_t> h_sig;
+    std::vector<int64_t> h_prefix;  // prefix sums of the samples (exact DC means)
+    int8_t *d_prim = nullptr;       // [63][2][code_len]
+    float2 *d_Cs = nullptr;         // [slots][ncomp][L]
+    size_t cs_cap_slots = 0;
+    std::map<int, int> cs_slot;     // PRN -> slot
+    float2 *d_Xs = nullptr;
+    size_t xs_cap = 0;  // elements
+    float2 *d_Bw = nullptr;
+    size_t bw_cap = 0;  // elements
+    Rec *d_recs = nullptr;
+    size_t recs_cap = 0;
+    float *d_rowmax = nullptr;
+    int *d_rowarg = nullptr;
+    size_t rows_cap = 0;
+    CorrJob *d_jobs = nullptr;
+    double2 *d_jobout = nullptr;
+    size_t jobs_cap = 0;
+    // last run (diagnostics)
+    int D = 0;
+    std::vector<int> run_prns;
+    std::vector<float> h_rowmax;
+    std::vector<int> h_rowarg;
+    std::map<int, PrnResult> last;
+    int group = 4;
+};
+
+void acq_state_free(AcqState *a) {
+    if (!a) return;
+    plan_free(a->plan);
+    for (void *p : {(void *)a->d_sig, (void *)a->d_prim, (void *)a->d_Cs, (void *)a->d_Xs, (void *)a->d_Bw,
+                    (void *)a->d_recs, (void *)a->d_rowmax, (void *)a->d_rowarg, (void *)a->d_jobs,
+                    (void *)a->d_jobout})
+        if (p) (void)hipFree(p);
+    delete a;
+}
+
+static int check_settings(bds_ctx *ctx, const bds_settings &s) {
+    if (s.signal != BDS_SIGNAL_B1C && s.signal != BDS_SIGNAL_B2A)
+        return fail(ctx, BDS_ERR_ARG, "settings.signal must be BDS_SIGNAL_B1C or BDS_SIGNAL_B2A");
+    if (!(s.samplingFreq > 0) || !(s.codeFreqBasis > 0) || s.codeLength != 10230)
+        return fail(ctx, BDS_ERR_ARG, "settings.samplingFreq/codeFreqBasis must be positive and codeLength 10230");
+    if (!(s.acqStep > 0) || !(s.acqSearchBand >= 0))
+        return fail(ctx, BDS_ERR_ARG, "settings.acqStep must be > 0 and acqSearchBand >= 0");
+    if (s.resamplingflag == 1 && s.samplingFreq > s.resamplingThreshold)
+        return fail(ctx, BDS_ERR_UNSUPPORTED,
+                    "acquisition resampling branch (acquisition.m:56-124) is not built; set resamplingflag = 0");
+    if (s.n_acq < 1 || s.n_acq > BDS_MAX_PRN) return fail(ctx, BDS_ERR_ARG, "settings.acqSatelliteList is empty or too long");
+    for (int i = 0; i < s.n_acq; ++i)
+        if (s.acqSatelliteList[i] < 1 || s.acqSatelliteList[i] > BDS_MAX_PRN)
+            return fail(ctx, BDS_ERR_ARG, "settings.acqSatelliteList[%d] = %d out of 1..63", i, s.acqSatelliteList[i]);
+    if (s.signal == BDS_SIGNAL_B1C && !(s.acqCohT > 0 && s.acqCohT <= 10))
+        return fail(ctx, BDS_ERR_ARG, "settings.acqCohT must be in (0, 10] ms");
+    if (s.signal == BDS_SIGNAL_B2A && s.fineNoncoh < 1)
+        return fail(ctx, BDS_ERR_ARG, "settings.fineNoncoh must be >= 1");
+    return BDS_OK;
+}
+
+template <class T>
+static int ensure(bds_ctx *ctx, T **p, size_t *cap, size_t need) {
+    if (*cap >= need && *p) return BDS_OK;
+    if (*p) (void)hipFree(*p), *p = nullptr, *cap = 0;
+    hipError_t e = hipMalloc((void **)p, sizeof(T) * need);
+    if (e != hipSuccess)
+        return fail(ctx, BDS_ERR_NOMEM, "hipMalloc of %zu bytes failed: %s", sizeof(T) * need, hipGetErrorString(e));
+    *cap = need;
+    return BDS_OK;
+}
+
+// (Re)derive sizes, plan and code tables when the settings that define them change.
+static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
+    int rc = check_settings(ctx, s);
+    if (rc) return rc;
+    if (!ctx->acq) ctx->acq = new AcqState();
+    AcqState &a = *ctx->acq;
+    const long spc = samples_per_code(s);
+    long X, N;
+    int ncomp;
+    if (s.signal == BDS_SIGNAL_B1C) {
+        X = (long)m_round((double)spc / 10 * s.acqCohT);         // samplesXmsLen  B1C/acquisition.m:132
+        N = (long)m_round((double)spc / 10 * (10 + s.acqCohT));  // len10PlusXms   :135
+        ncomp = s.pilotACQflag == 1 ? 2 : 1;
+    } else {
+        X = spc;      // B2a/acquisition.m:179-180
+        N = 2 * spc;  // len2ms :134
+        ncomp = 2;
+    }
+    if (X < 1 || X > spc || N <= X) return fail(ctx, BDS_ERR_ARG, "degenerate acquisition sizes (spc=%ld X=%ld N=%ld)", spc, X, N);
+    const bool same = a.signal == s.signal && a.fs == s.samplingFreq && a.cfb == s.codeFreqBasis &&
+                      a.cohT == s.acqCohT && a.pilotACQ == s.pilotACQflag && a.code_len == s.codeLength &&
+                      a.plan.L > 0;
+    if (same) return BDS_OK;
+    a.cs_slot.clear();
+    a.signal = s.signal;
+    a.fs = s.samplingFreq;
+    a.cfb = s.codeFreqBasis;
+    a.cohT = s.acqCohT;
+    a.pilotACQ = s.pilotACQflag;
+    a.code_len = s.codeLength;
+    a.spc = spc;
+    a.X = X;
+    a.N = N;
+    a.n_ext = N + X - 1;
+    a.ncomp = ncomp;
+    if ((rc = plan_build(ctx, a.plan, a.n_ext))) return rc;
+    if (const char *g = std::getenv("BDS_ACQ_GROUP")) a.group = std::max(1, std::min(64, atoi(g)));
+    // primary codes of every PRN, both components
+    if (!a.d_prim) BDS_HIP(ctx, hipMalloc((void **)&a.d_prim, (size_t)BDS_MAX_PRN * 2 * 10230));
+    std::vector<int8_t> prim((size_t)BDS_MAX_PRN * 2 * 10230);
+    for (int prn = 1; prn <= BDS_MAX_PRN; ++prn)
+        for (int c = 0; c < 2; ++c) gen_primary(s.signal, c == 1, prn, &prim[((size_t)(prn - 1) * 2 + c) * 10230]);
+    BDS_HIP(ctx, hipMemcpy(a.d_prim, prim.data(), prim.size(), hipMemcpyHostToDevice));
+    a.tab.prim = a.d_prim;
+    a.tab.ts = 1.0 / s.samplingFreq;                                                     // makeDataTable.m:49
+    a.tab.tc = s.signal == BDS_SIGNAL_B1C ? 1.0 / s.codeFreqBasis / 2 : 1.0 / s.codeFreqBasis;  // :50 / makeB2aDataTable.m:47
+    a.tab.spc = spc;
+    a.tab.xlen = X;
+    a.tab.code_len = 10230;
+    a.tab.boc = s.signal == BDS_SIGNAL_B1C ? 1 : 0;
+    return BDS_OK;
+}
+
+static hipStream_t st(bds_ctx *ctx) { return (hipStream_t)ctx->stream; }
+
+static int set_lds_limits(bds_ctx *ctx) {
+    static bool done = false;
+    if (done) return BDS_OK;
+    const int maxlds = 160 * 1024;
+    BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_fwd<SignalLoader>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_fwd<CodeLoader>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_inv<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_inv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_inv_max<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_inv_max<2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    done = true;
+    return BDS_OK;
+}
+
+// forward transform of `nb` batches produced by loader `ld` into dst[b*dst_stride]
+template <class Loader>
+static int forward(bds_ctx *ctx, AcqState &a, Loader ld, int nb, float2 *dst, long dst_stride, int conj_flag,
+                   float scale) {
+    Plan2D &pl = a.plan;
+    dim3 g1(pl.ntiles, nb), g2(pl.L1, nb);
+    hipLaunchKernelGGL(k_cols_fwd<Loader>, g1, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.twl, pl.L2,
+                       pl.logT, pl.Spad, ld, a.d_Bw, pl.L);
+    hipLaunchKernelGGL(k_rows_fwd, g2, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, (const float2 *)a.d_Bw,
+                       pl.L, dst, dst_stride, conj_flag, scale);
+    BDS_HIP(ctx, hipGetLastError());
+    return BDS_OK;
+}
+
+static size_t bw_batches(const AcqState &a) { return (size_t)std::max(a.group * a.ncomp, 8); }
+
+}  // namespace bds
+
+using namespace bds;
+
+// =======================================================================================
+extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s, const int8_t *samples, size_t n_samples,
+                            int is_complex) {
+    if (!ctx || !s || !samples) return BDS_ERR_ARG;
+    if (is_complex || s->fileType == 2)
+        return fail(ctx, BDS_ERR_UNSUPPORTED, "fileType 2 (interleaved I/Q) acquisition input is not built yet");
+    int rc = acq_configure(ctx, *s);
+    if (rc) return rc;
+    AcqState &a = *ctx->acq;
+    if ((long)n_samples < a.N)
+        return fail(ctx, BDS_ERR_ARG, "longSignal has %zu samples; acquisition needs at least %ld (acquisition.m:140)",
+                    n_samples, a.N);
+    BDS_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure(ctx, &a.d_sig, &a.sig_cap, n_samples))) return rc;
+    BDS_HIP(ctx, hipMemcpyAsync(a.d_sig, samples, n_samples, hipMemcpyHostToDevice, st(ctx)));
+    a.h_sig.assign(samples, samples + n_samples);
+    a.h_prefix.resize(n_samples + 1);
+    a.h_prefix[0] = 0;
+    for (size_t i = 0; i < n_samples; ++i) a.h_prefix[i + 1] = a.h_prefix[i] + samples[i];
+    a.n_samples = (long)n_samples;
+    BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+    return BDS_OK;
+}
+
+extern "C" int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s) {
+    if (!ctx || !s) return BDS_ERR_ARG;
+    int rc = acq_configure(ctx, *s);
+    if (rc) return rc;
+    AcqState &a = *ctx->acq;
+    BDS_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = set_lds_limits(ctx))) return rc;
+    Plan2D &pl = a.plan;
+    if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a) * (size_t)pl.L))) return rc;
+    std::vector<int> todo;
+    for (int i = 0; i < s->n_acq; ++i)
+        if (!a.cs_slot.count(s->acqSatelliteList[i]) &&
+            std::find(todo.begin(), todo.end(), s->acqSatelliteList[i]) == todo.end())
+            todo.push_back(s->acqSatelliteList[i]);
+    if (todo.empty()) return BDS_OK;
+    const size_t need_slots = a.cs_slot.size() + todo.size();
+    if (need_slots > a.cs_cap_slots) {
+        // grow: spectra are cheap to rebuild, so drop the cache instead of copying
+        for (auto &kv : a.cs_slot)
+            if (std::find(todo.begin(), todo.end(), kv.first) == todo.end()) todo.push_back(kv.first);
+        a.cs_slot.clear();
+        if (a.d_Cs) (void)hipFree(a.d_Cs), a.d_Cs = nullptr;
+        hipError_t e = hipMalloc((void **)&a.d_Cs, sizeof(float2) * need_slots * a.ncomp * (size_t)pl.L);
+        if (e != hipSuccess) return fail(ctx, BDS_ERR_NOMEM, "code-spectrum cache (%zu PRNs) does not fit: %s", need_slots, hipGetErrorString(e));
+        a.cs_cap_slots = need_slots;
+    }
+    // conj(fft([table zeros]))/L per PRN and component (B2a/acquisition.m:175-184, B1C/acquisition.m:174-187)
+    const int chunk = (int)bw_batches(a);
+    for (int prn : todo) {
+        const int slot = (int)a.cs_slot.size();
+        CodeLoader ld{a.tab, (prn - 1) * 2};
+        // components of one PRN are adjacent code slots: batch index = component
+        (void)chunk;
+        if ((rc = forward(ctx, a, ld, a.ncomp, a.d_Cs + (size_t)slot * a.ncomp * pl.L, pl.L, 1, (float)(1.0 / (double)pl.L))))
+            return rc;
+        a.cs_slot[prn] = slot;
+    }
+    BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+    return BDS_OK;
+}
+
+namespace bds {
+
+struct Cell {
+    int b;     // 0-based bin
+    long lag;  // 0-based
+    bool operator<(const Cell &o) const { return std::tie(b, lag) < std::tie(o.b, o.lag); }
+};
+
+static int run_jobs(bds_ctx *ctx, AcqState &a, const CodeTable &tab, std::vector<CorrJob> &jobs,
+                    std::vector<double2> &out) {
+    out.resize(jobs.size());
+    if (jobs.empty()) return BDS_OK;
+    int rc;
+    if (a.jobs_cap < jobs.size()) {
+        if (a.d_jobs) (void)hipFree(a.d_jobs), a.d_jobs = nullptr;
+        if (a.d_jobout) (void)hipFree(a.d_jobout), a.d_jobout = nullptr;
+        size_t cap = std::max<size_t>(jobs.size(), 1024), dummy = 0;
+        if ((rc = ensure(ctx, &a.d_jobs, &dummy, cap))) return rc;
+        dummy = 0;
+        if ((rc = ensure(ctx, &a.d_jobout, &dummy, cap))) return rc;
+        a.jobs_cap = cap;
+    }
+    BDS_HIP(ctx, hipMemcpyAsync(a.d_jobs, jobs.data(), sizeof(CorrJob) * jobs.size(), hipMemcpyHostToDevice, st(ctx)));
+    hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size()), dim3(256), 0, st(ctx), (const int8_t *)a.d_sig, a.N,
+                       tab, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
+    BDS_HIP(ctx, hipGetLastError());
+    BDS_HIP(ctx, hipMemcpyAsync(out.data(), a.d_jobout, sizeof(double2) * jobs.size(), hipMemcpyDeviceToHost, st(ctx)));
+    BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+    return BDS_OK;
+}
+
+static inline double cabs2(double2 v) { return std::hypot(v.x, v.y); }
+
+// results(bin, lag) in f64 from the per-component coherent sums (B2a/acquisition.m:208-209,
+// B1C/acquisition.m:212,218-219)
+static inline double combine(const AcqState &a, const double2 *v) {
+    if (a.signal == BDS_SIGNAL_B2A) return cabs2(v[0]) + cabs2(v[1]);
+    if (a.ncomp == 1) return cabs2(v[0]);
+    return (cabs2(v[0]) * std::sqrt(11.0) + cabs2(v[1]) * std::sqrt(29.0)) / std::sqrt(40.0);
+}
+
+}  // namespace bds
+
+extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *prn_list, int n_prn, int max_prn,
+                           double *carrFreq, double *codePhase, double *peakMetric, int32_t *detected) {
+    if (!ctx || !s || !carrFreq || !codePhase || !peakMetric) return BDS_ERR_ARG;
+    int rc = acq_configure(ctx, *s);
+    if (rc) return rc;
+    AcqState &a = *ctx->acq;
+    if (!a.d_sig || a.n_samples < a.N) return fail(ctx, BDS_ERR_ARG, "bds_acq_run: no IF block loaded (bds_acq_load)");
+    if ((rc = bds_acq_prepare(ctx, s))) return rc;
+    std::vector<int> prns;
+    if (prn_list && n_prn > 0)
+        prns.assign(prn_list, prn_list + n_prn);
+    else
+        prns.assign(s->acqSatelliteList, s->acqSatelliteList + s->n_acq);
+    int list_max = 0;
+    for (int i = 0; i < s->n_acq; ++i) list_max = std::max(list_max, (int)s->acqSatelliteList[i]);
+    if (max_prn < list_max) return fail(ctx, BDS_ERR_ARG, "max_prn %d < max(acqSatelliteList) %d", max_prn, list_max);
+    for (int p : prns)
+        if (!a.cs_slot.count(p)) return fail(ctx, BDS_ERR_ARG, "PRN %d of the shard is not in settings.acqSatelliteList", p);
+    for (int i = 0; i < max_prn; ++i) {
+        carrFreq[i] = codePhase[i] = peakMetric[i] = 0.0;  // acquisition.m:161-165
+        if (detected) detected[i] = 0;
+    }
+    Plan2D &pl = a.plan;
+    const int D = (int)m_round(s->acqSearchBand * 2 / s->acqStep) + 1;  // numberOfFrqBins :150
+    const double f0 = s->IF - s->acqSearchBand;                         // frqBins :190-191
+    a.D = D;
+    const int P = (int)prns.size();
+    const int ncomp = a.ncomp;
+    const int G = a.group;
+    if ((rc = ensure(ctx, &a.d_Xs, &a.xs_cap, (size_t)D * pl.L))) return rc;
+    if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * D * pl.ntiles))) return rc;
+    if (a.rows_cap < (size_t)P * D) {
+        if (a.d_rowmax) (void)hipFree(a.d_rowmax), a.d_rowmax = nullptr;
+        if (a.d_rowarg) (void)hipFree(a.d_rowarg), a.d_rowarg = nullptr;
+        size_t d0 = 0, d1 = 0;
+        if ((rc = ensure(ctx, &a.d_rowmax, &d0, (size_t)P * D))) return rc;
+        if ((rc = ensure(ctx, &a.d_rowarg, &d1, (size_t)P * D))) return rc;
+        a.rows_cap = (size_t)P * D;
+    }
+
+    hipEvent_t ev0, ev1, ev2, ev3;
+    BDS_HIP(ctx, hipEventCreate(&ev0));
+    BDS_HIP(ctx, hipEventCreate(&ev1));
+    BDS_HIP(ctx, hipEventCreate(&ev2));
+    BDS_HIP(ctx, hipEventCreate(&ev3));
+    constexpr int kSamples = 32;
+    hipEvent_t sa[kSamples], sb[kSamples];
+    int nsamp = 0;
+    for (int i = 0; i < kSamples; ++i) {
+        BDS_HIP(ctx, hipEventCreate(&sa[i]));
+        BDS_HIP(ctx, hipEventCreate(&sb[i]));
+    }
+    BDS_HIP(ctx, hipEventRecord(ev0, st(ctx)));
+
+    // ---- forward transforms, once per Doppler bin -------------------------------------
+    {
+        const int chunk = (int)bw_batches(a);
+        for (int b0 = 0; b0 < D; b0 += chunk) {
+            const int nb = std::min(chunk, D - b0);
+            SignalLoader ld{a.d_sig, a.N, a.n_ext, f0, s->acqStep, 1.0 / a.fs, b0};
+            if ((rc = forward(ctx, a, ld, nb, a.d_Xs + (size_t)b0 * pl.L, pl.L, 0, 1.0f))) return rc;
+        }
+    }
+    BDS_HIP(ctx, hipEventRecord(ev1, st(ctx)));
+
+    // ---- PRN x bin search --------------------------------------------------------------
+    float w0 = 1.f, w1 = 1.f;
+    if (a.signal == BDS_SIGNAL_B1C && ncomp == 2) {
+        w0 = (float)(std::sqrt(11.0) / std::sqrt(40.0));
+        w1 = (float)(std::sqrt(29.0) / std::sqrt(40.0));
+    }
+    const long n_pairs_total = (long)P * ((D + G - 1) / G);
+    const long sample_every = std::max<long>(1, n_pairs_total / kSamples);
+    long pair_idx = 0;
+    auto launch_cells = [&](int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2) {
+        const float2 *Cs = a.d_Cs + (size_t)a.cs_slot[prn] * ncomp * pl.L;
+        dim3 gr(pl.L1, nb), gc(pl.ntiles, nb);
+        if (ncomp == 2) {
+            hipLaunchKernelGGL(k_rows_inv<2>, gr, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, pl.twl,
+                               (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
+            hipLaunchKernelGGL(k_cols_inv_max<2>, gc, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.L2, pl.logT,
+                               pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
+        } else {
+            hipLaunchKernelGGL(k_rows_inv<1>, gr, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, pl.twl,
+                               (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
+            hipLaunchKernelGGL(k_cols_inv_max<1>, gc, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.L2, pl.logT,
+                               pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
+        }
+    };
+    for (int pi = 0; pi < P; ++pi) {
+        for (int b0 = 0; b0 < D; b0 += G, ++pair_idx) {
+            const int nb = std::min(G, D - b0);
+            const bool sample = nb == G && (pair_idx % sample_every) == 0 && nsamp < kSamples;
+            if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], st(ctx)));
+            launch_cells(prns[pi], b0, nb, a.d_recs + ((size_t)pi * D + b0) * pl.ntiles, 0, (int)a.N - 1, 1, 0);
+            if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], st(ctx)));
+        }
+    }
+    BDS_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)(P * D)), dim3(256), 0, st(ctx), (const Rec *)a.d_recs,
+                       pl.ntiles, pl.ntiles, a.d_rowmax, a.d_rowarg);
+    BDS_HIP(ctx, hipEventRecord(ev2, st(ctx)));
+    a.h_rowmax.resize((size_t)P * D);
+    a.h_rowarg.resize((size_t)P * D);
+    std::vector<Rec> h_recs((size_t)P * D * pl.ntiles);
+    BDS_HIP(ctx, hipMemcpyAsync(a.h_rowmax.data(), a.d_rowmax, sizeof(float) * P * D, hipMemcpyDeviceToHost, st(ctx)));
+    BDS_HIP(ctx, hipMemcpyAsync(a.h_rowarg.data(), a.d_rowarg, sizeof(int) * P * D, hipMemcpyDeviceToHost, st(ctx)));
+    BDS_HIP(ctx, hipMemcpyAsync(h_recs.data(), a.d_recs, sizeof(Rec) * h_recs.size(), hipMemcpyDeviceToHost, st(ctx)));
+    BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+    a.run_prns = prns;
+    a.last.clear();
+
+    // ---- f64 refinement of the sieve's candidates ---------------------------------------
+    const double kDelta = 2e-5;
+    auto bin_freq = [&](int b) { return f0 + s->acqStep * (double)b; };
+    std::vector<std::vector<Cell>> cells(P);
+    std::vector<CorrJob> jobs;
+    for (int pi = 0; pi < P; ++pi) {
+        float M = -1.f;
+        for (int b = 0; b < D; ++b) M = std::max(M, a.h_rowmax[(size_t)pi * D + b]);
+        const float thr = (float)((1.0 - kDelta) * (double)M);
+        std::set<Cell> cs;
+        for (int b = 0; b < D; ++b) {
+            if (a.h_rowmax[(size_t)pi * D + b] < thr) continue;
+            const Rec *rr = &h_recs[((size_t)pi * D + b) * pl.ntiles];
+            for (int t = 0; t < pl.ntiles; ++t) {
+                if (rr[t].lag < 0 || rr[t].v < thr) continue;
+                for (int db = -1; db <= 1; ++db)
+                    for (int dl = -1; dl <= 1; ++dl) {
+                        const int bb = b + db;
+                        const long ll = rr[t].lag + dl;
+                        if (bb >= 0 && bb < D && ll >= 0 && ll < a.N) cs.insert(Cell{bb, ll});
+                    }
+            }
+        }
+        cells[pi].assign(cs.begin(), cs.end());
+        for (const Cell &c : cells[pi])
+            for (int comp = 0; comp < ncomp; ++comp) {
+                CorrJob j{};
+                j.start = c.lag;
+                j.len = a.X;
+                j.freq = bin_freq(c.b);
+                j.mean = 0;
+                j.slot = (prns[pi] - 1) * 2 + comp;
+                j.circ = 1;
+                j.mode = 0;
+                jobs.push_back(j);
+            }
+    }
+    std::vector<double2> jout;
+    if ((rc = run_jobs(ctx, a, a.tab, jobs, jout))) return rc;
+    std::vector<PrnResult> res(P);
+    {
+        size_t k = 0;
+        for (int pi = 0; pi < P; ++pi) {
+            double best = -1;
+            Cell bc{0, 0};
+            for (const Cell &c : cells[pi]) {
+                const double v = combine(a, &jout[k]);
+                k += ncomp;
+                // ties: first row / first column, as MATLAB max does (acquisition.m:218-221)
+                if (v > best || (v == best && (c.b < bc.b || (c.b == bc.b && c.lag < bc.lag)))) best = v, bc = c;
+            }
+            res[pi].peak = best;
+            res[pi].fbin = bc.b + 1;
+            res[pi].codePhase = bc.lag + 1;
+        }
+    }
+
+    // ---- detection metric -----------------------------------------------------------------
+    if (a.signal == BDS_SIGNAL_B1C) {
+        // sigPower = sqrt(var(sig(1:X)) * X), unbiased variance (B1C/acquisition.m:150)
+        const double mean = (double)(a.h_prefix[a.X] - a.h_prefix[0]) / (double)a.X;
+        long double acc = 0;
+        for (long i = 0; i < a.X; ++i) {
+            const double d = (double)a.h_sig[i] - mean;
+            acc += (long double)(d * d);
+        }
+        const double var = (double)(acc / (long double)(a.X - 1));
+        const double sigPower = std::sqrt(var * (double)a.X);
+        for (int pi = 0; pi < P; ++pi) {
+            res[pi].denom = sigPower;
+            if (res[pi].codePhase + a.spc - 1 > a.n_samples) res[pi].codePhase -= a.spc;  // :239-241
+        }
+    } else {
+        // second peak in the winning bin, outside +-2 chips and within +-1 code (B2a/acquisition.m:224-249)
+        const long s2c = (long)std::ceil(s->samplingFreq / s->codeFreqBasis) * 2;  // samples2CodeChip :137
+        std::vector<std::array<long, 4>> rng(P);
+        if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * D * pl.ntiles))) return rc;
+        for (int pi = 0; pi < P; ++pi) {
+            const long cp = res[pi].codePhase;
+            const long e1 = cp - s2c, e2 = cp + s2c, e3 = cp - a.spc + s2c, e4 = cp + a.spc - s2c;
+            long lo1 = 1, hi1 = 0, lo2 = 1, hi2 = 0;  // 1-based inclusive, empty when lo > hi
+            if (e1 >= 1) lo1 = std::max<long>(1, e3), hi1 = e1;
+            if (e2 < a.N) lo2 = e2, hi2 = std::min<long>(e4, a.N);
+            rng[pi] = {lo1 - 1, hi1 - 1, lo2 - 1, hi2 - 1};  // 0-based
+            if (hi1 < lo1 && hi2 < lo2)
+                return fail(ctx, BDS_ERR_ARG, "PRN %d: empty second-peak range (acquisition.m:248 would fail)", prns[pi]);
+            launch_cells(prns[pi], res[pi].fbin - 1, 1, a.d_recs + (size_t)pi * pl.ntiles, (int)rng[pi][0],
+                         (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3]);
+        }
+        BDS_HIP(ctx, hipGetLastError());
+        std::vector<Rec> r2((size_t)P * pl.ntiles);
+        BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, st(ctx)));
+        BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+        jobs.clear();
+        std::vector<std::vector<long>> lags(P);
+        for (int pi = 0; pi < P; ++pi) {
+            float M = -1.f;
+            for (int t = 0; t < pl.ntiles; ++t) M = std::max(M, r2[(size_t)pi * pl.ntiles + t].v);
+            const float thr = (float)((1.0 - kDelta) * (double)M);
+            std::set<long> ls;
+            auto inrange = [&](long l) {
+                return (l >= rng[pi][0] && l <= rng[pi][1]) || (l >= rng[pi][2] && l <= rng[pi][3]);
+            };
+            for (int t = 0; t < pl.ntiles; ++t) {
+                const Rec &r = r2[(size_t)pi * pl.ntiles + t];
+                if (r.lag < 0 || r.v < thr) continue;
+                for (long dl = -1; dl <= 1; ++dl)
+                    if (inrange(r.lag + dl)) ls.insert(r.lag + dl);
+            }
+            lags[pi].assign(ls.begin(), ls.end());
+            for (long l : lags[pi])
+                for (int comp = 0; comp < ncomp; ++comp) {
+                    CorrJob j{};
+                    j.start = l;
+                    j.len = a.X;
+                    j.freq = bin_freq(res[pi].fbin - 1);
+                    j.slot = (prns[pi] - 1) * 2 + comp;
+                    j.circ = 1;
+                    j.mode = 0;
+                    jobs.push_back(j);
+                }
+        }
+        if ((rc = run_jobs(ctx, a, a.tab, jobs, jout))) return rc;
+        size_t k = 0;
+        for (int pi = 0; pi < P; ++pi) {
+            double second = -1;
+            for (size_t i = 0; i < lags[pi].size(); ++i, k += ncomp) second = std::max(second, combine(a, &jout[k]));
+            res[pi].denom = second;
+        }
+    }
+
+    // ---- threshold + fine-Doppler search ---------------------------------------------------
+    jobs.clear();
+    std::vector<int> fine_of(P, -1);
+    int nfine = 0;
+    std::vector<std::vector<double>> fine_frq(P);
+    CodeTable tabf = a.tab;
+    tabf.xlen = a.spc;  // the fine search multiplies by the whole table (B1C/acquisition.m:257)
+    for (int pi = 0; pi < P; ++pi) {
+        PrnResult &r = res[pi];
+        const double metric = r.peak / r.denom;  // :252 / B1C :235
+        peakMetric[prns[pi] - 1] = metric;
+        if (!(metric > s->acqThreshold)) continue;  // :255 / B1C :244
+        r.detected = true;
+        const double fb = bin_freq(r.fbin - 1);
+        if (a.signal == BDS_SIGNAL_B1C) {
+            nfine = (int)m_round(s->acqStep / 25) * 2 + 1;  // B1C/acquisition.m:267
+            if (r.codePhase < 1 || r.codePhase - 1 + a.spc > a.n_samples)
+                return fail(ctx, BDS_ERR_ARG, "PRN %d: fine-search block %ld..%ld outside longSignal (B1C/acquisition.m:253)",
+                            prns[pi], r.codePhase, r.codePhase + a.spc - 1);
+            const double mean = (double)(a.h_prefix[r.codePhase - 1 + a.spc] - a.h_prefix[r.codePhase - 1]) / (double)a.spc;  // :254
+            for (int kf = 0; kf < nfine; ++kf) {
+                const double f = fb - s->acqStep + 25.0 * kf;  // :282-283
+                fine_frq[pi].push_back(f);
+                for (int comp = 0; comp < ncomp; ++comp) {
+                    CorrJob j{};
+                    j.start = r.codePhase - 1;
+                    j.len = a.spc;
+                    j.freq = f;
+                    j.mean = mean;
+                    j.slot = (prns[pi] - 1) * 2 + comp;
+                    j.circ = 0;
+                    j.mode = 0;
+                    jobs.push_back(j);
+                }
+            }
+        } else {
+            nfine = (int)m_round(s->acqStep / 25) + 1;  // B2a/acquisition.m:265
+            const long nn = (long)s->fineNoncoh * a.spc;
+            if (r.codePhase - 1 + nn > a.n_samples)
+                return fail(ctx, BDS_ERR_ARG, "PRN %d: fine-search block %ld..%ld outside longSignal (B2a/acquisition.m:290)",
+                            prns[pi], r.codePhase, r.codePhase + nn - 1);
+            for (int kf = 0; kf < nfine; ++kf) {
+                const double f = fb - s->acqStep / 2 + 25.0 * kf;  // :300-301
+                fine_frq[pi].push_back(f);
+                for (int seg = 0; seg < s->fineNoncoh; ++seg)
+                    for (int comp = 0; comp < 2; ++comp) {
+                        CorrJob j{};
+                        j.start = r.codePhase - 1 + (long)seg * a.spc;
+                        j.len = a.spc;
+                        j.code_k0 = (long)seg * a.spc;
+                        j.freq = f;
+                        j.slot = (prns[pi] - 1) * 2 + comp;
+                        j.circ = 0;
+                        j.mode = 1;
+                        jobs.push_back(j);
+                    }
+            }
+        }
+        fine_of[pi] = 1;
+    }
+    if ((rc = run_jobs(ctx, a, tabf, jobs, jout))) return rc;
+    {
+        size_t k = 0;
+        for (int pi = 0; pi < P; ++pi) {
+            if (fine_of[pi] < 0) continue;
+            double best = -1;
+            int kbest = 0;
+            for (int kf = 0; kf < nfine; ++kf) {
+                double v;
+                if (a.signal == BDS_SIGNAL_B1C) {
+                    v = cabs2(jout[k]);
+                    if (ncomp == 2) v = (v * 11 + cabs2(jout[k + 1]) * 29) / 40;  // :291-292
+                    k += ncomp;
+                } else {
+                    double sd = 0, sp = 0;
+                    for (int seg = 0; seg < s->fineNoncoh; ++seg, k += 2) sd += cabs2(jout[k]), sp += cabs2(jout[k + 1]);
+                    v = sd + sp;  // :321
+                }
+                if (v > best) best = v, kbest = kf;
+            }
+            double cf = fine_frq[pi][kbest];
+            if (cf == 0) cf = 1;  // :333-335
+            carrFreq[prns[pi] - 1] = cf;
+            codePhase[prns[pi] - 1] = (double)res[pi].codePhase;
+            if (detected) detected[prns[pi] - 1] = 1;
+        }
+    }
+    BDS_HIP(ctx, hipEventRecord(ev3, st(ctx)));
+    BDS_HIP(ctx, hipEventSynchronize(ev3));
+    for (int pi = 0; pi < P; ++pi) a.last[prns[pi]] = res[pi];
+
+    bds_timing &t = ctx->timing;
+    memset(&t, 0, sizeof(t));
+    float ms = 0;
+    BDS_HIP(ctx, hipEventElapsedTime(&ms, ev0, ev3));
+    t.total_ms = ms;
+    BDS_HIP(ctx, hipEventElapsedTime(&ms, ev0, ev1));
+    t.forward_ms = ms;
+    BDS_HIP(ctx, hipEventElapsedTime(&ms, ev1, ev2));
+    t.search_ms = ms;
+    BDS_HIP(ctx, hipEventElapsedTime(&ms, ev2, ev3));
+    t.refine_ms = ms;
+    double acc = 0;
+    for (int i = 0; i < nsamp; ++i) {
+        BDS_HIP(ctx, hipEventElapsedTime(&ms, sa[i], sb[i]));
+        acc += ms;
+    }
+    t.cell_pair_ms = nsamp ? acc / nsamp : 0;
+    t.cells_per_pair = G;
+    t.n_pairs = n_pairs_total;
+    t.fft_len = pl.L;
+    t.n_circ = a.N;
+    t.n_bins = D;
+    t.n_prn = P;
+    t.n_comp = ncomp;
+    for (hipEvent_t e : {ev0, ev1, ev2, ev3}) (void)hipEventDestroy(e);
+    for (int i = 0; i < kSamples; ++i) (void)hipEventDestroy(sa[i]), (void)hipEventDestroy(sb[i]);
+    return BDS_OK;
+}
+
+extern "C" int bds_acquire(bds_ctx *ctx, const bds_settings *s, const int8_t *samples, size_t n_samples,
+                           int is_complex, int max_prn, double *carrFreq, double *codePhase, double *peakMetric,
+                           int32_t *detected) {
+    int rc = bds_acq_load(ctx, s, samples, n_samples, is_complex);
+    if (rc) return rc;
+    if ((rc = bds_acq_prepare(ctx, s))) return rc;
+    return bds_acq_run(ctx, s, nullptr, 0, max_prn, carrFreq, codePhase, peakMetric, detected);
+}
+
+extern "C" int bds_acq_grid(bds_ctx *ctx, float *row_max, int32_t *row_arg, int cap) {
+    if (!ctx || !ctx->acq) return BDS_ERR_ARG;
+    AcqState &a = *ctx->acq;
+    const int n = (int)a.h_rowmax.size();
+    if (cap < n) return fail(ctx, BDS_ERR_ARG, "bds_acq_grid: capacity %d < %d", cap, n);
+    for (int i = 0; i < n; ++i) {
+        if (row_max) row_max[i] = a.h_rowmax[i];
+        if (row_arg) row_arg[i] = a.h_rowarg[i] + 1;  // 1-based like the reference
+    }
+    return n;
+}
+
+extern "C" int bds_acq_peaks(bds_ctx *ctx, int max_prn, double *peak, double *denom, int32_t *fbin) {
+    if (!ctx || !ctx->acq) return BDS_ERR_ARG;
+    for (int i = 0; i < max_prn; ++i) {
+        if (peak) peak[i] = 0;
+        if (denom) denom[i] = 0;
+        if (fbin) fbin[i] = 0;
+    }
+    for (auto &kv : ctx->acq->last) {
+        if (kv.first > max_prn) continue;
+        if (peak) peak[kv.first - 1] = kv.second.peak;
+        if (denom) denom[kv.first - 1] = kv.second.denom;
+        if (fbin) fbin[kv.first - 1] = kv.second.fbin;
+    }
+    return BDS_OK;
+}

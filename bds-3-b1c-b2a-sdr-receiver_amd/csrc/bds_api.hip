@@ -1,0 +1,195 @@
+// Context management, error reporting and the small host-side helpers of the C ABI.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <numeric>
+
+#include "bds_internal.h"
+
+namespace bds {
+
+static thread_local std::string g_create_error;
+
+int fail(bds_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+}  // namespace bds
+
+extern "C" bds_ctx *bds_create(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        bds::fail(nullptr, BDS_ERR_HIP, "no HIP device visible (%s): libbds_mi355x has no CPU fallback",
+                  e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= n) {
+        bds::fail(nullptr, BDS_ERR_ARG, "device_id %d out of range (0..%d)", device_id, n - 1);
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device_id)) != hipSuccess) {
+        bds::fail(nullptr, BDS_ERR_HIP, "hipSetDevice(%d): %s", device_id, hipGetErrorString(e));
+        return nullptr;
+    }
+    bds_ctx *ctx = new bds_ctx();
+    ctx->device = device_id;
+    hipStream_t s;
+    if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) {
+        bds::fail(nullptr, BDS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        delete ctx;
+        return nullptr;
+    }
+    ctx->stream = (void *)s;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        ctx->devname = prop.name;
+        ctx->devname += " ";
+        ctx->devname += prop.gcnArchName;
+    }
+    return ctx;
+}
+
+extern "C" void bds_destroy(bds_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize((hipStream_t)ctx->stream);
+    bds::acq_state_free(ctx->acq);
+    bds::track_state_free(ctx->trk);
+    if (ctx->stream) (void)hipStreamDestroy((hipStream_t)ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *bds_last_error(const bds_ctx *ctx) {
+    return ctx ? ctx->err.c_str() : bds::g_create_error.c_str();
+}
+
+extern "C" int bds_device_name(const bds_ctx *ctx, char *buf, int buflen) {
+    if (!ctx || !buf || buflen < 1) return BDS_ERR_ARG;
+    snprintf(buf, (size_t)buflen, "%s", ctx->devname.c_str());
+    return BDS_OK;
+}
+
+extern "C" int bds_abi_check(int sz_settings, int sz_channel, int sz_track_out, int sz_timing) {
+    return (sz_settings == (int)sizeof(bds_settings) && sz_channel == (int)sizeof(bds_channel) &&
+            sz_track_out == (int)sizeof(bds_track_out) && sz_timing == (int)sizeof(bds_timing))
+               ? BDS_OK
+               : BDS_ERR_ARG;
+}
+
+extern "C" int bds_get_timing(bds_ctx *ctx, bds_timing *t) {
+    if (!ctx || !t) return BDS_ERR_ARG;
+    *t = ctx->timing;
+    return BDS_OK;
+}
+
+// Common/calcLoopCoef.m:41-45
+extern "C" void bds_calc_loop_coef(double lbw, double zeta, double k, double *tau1, double *tau2) {
+    const double wn = lbw * 8 * zeta / (4 * zeta * zeta + 1);
+    if (tau1) *tau1 = k / (wn * wn);
+    if (tau2) *tau2 = 2.0 * zeta / wn;
+}
+
+// Common/calcLoopCoefCarr.m:41-56  (a3 = b3 = 2, Wn = 1.2*LBW)
+extern "C" void bds_calc_loop_coef_carr(const bds_settings *s, double *pf3, double *pf2, double *pf1) {
+    const double wn = 1.2 * s->pllNoiseBandwidth;
+    const double t = s->intTime;
+    if (pf3) *pf3 = wn * wn * wn * t * t;
+    if (pf2) *pf2 = 2 * wn * wn * t;
+    if (pf1) *pf1 = 2 * wn;
+}
+
+// B1C/include/CalcWeighingFactor.m:43-81.  The PSDs are written with the removable
+// singularities cancelled analytically:
+//   sin(pi f/fc)/cos(pi f/(2fc))  = 2 sin(pi f/(2fc))
+//   sin(pi f/fc)/cos(pi f/(12fc)) = 2 sum_{m=0..5} (-1)^(m+1)... = 2[sin11b - sin9b + sin7b - sin5b + sin3b - sinb], b = pi f/(12fc)
+// and integrated with composite 16-point Gauss-Legendre (MATLAB integral() is adaptive
+// Gauss-Kronrod; both agree to ~1e-12 relative on these smooth integrands).
+static double gl16_integrate(double (*fn)(double, double, double), double fc, double tc, double a, double b, int panels) {
+    static const double x[8] = {0.0950125098376374401853193, 0.2816035507792589132304605, 0.4580167776572273863424194,
+                                0.6178762444026437484466718, 0.7554044083550030338951012, 0.8656312023878317438804679,
+                                0.9445750230732325760779884, 0.9894009349916499325961542};
+    static const double w[8] = {0.1894506104550684962853967, 0.1826034150449235888667637, 0.1691565193950025381893121,
+                                0.1495959888165767320815017, 0.1246289712555338720524763, 0.0951585116824927848099251,
+                                0.0622535239386478928628438, 0.0271524594117540948517806};
+    double total = 0;
+    const double h = (b - a) / panels;
+    for (int p = 0; p < panels; ++p) {
+        const double c = a + (p + 0.5) * h, r = 0.5 * h;
+        double acc = 0;
+        for (int i = 0; i < 8; ++i) acc += w[i] * (fn(c + r * x[i], fc, tc) + fn(c - r * x[i], fc, tc));
+        total += acc * r;
+    }
+    return total;
+}
+static const double kPiD = 3.14159265358979323846;
+static double g_boc11(double f, double fc, double tc) {
+    if (f == 0) return 0;
+    const double a = kPiD / 2 * f / fc;
+    const double v = std::sin(a) * 2 * std::sin(a) * fc / f / kPiD;
+    return tc * v * v;
+}
+static double g_boc61(double f, double fc, double tc) {
+    if (f == 0) return 0;
+    const double b = kPiD / 12 * f / fc;
+    const double ratio = 2 * (std::sin(11 * b) - std::sin(9 * b) + std::sin(7 * b) - std::sin(5 * b) + std::sin(3 * b) - std::sin(b));
+    const double v = std::sin(b) * ratio * fc / f / kPiD;
+    return tc * v * v;
+}
+static double g_pilot(double f, double fc, double tc) { return 29.0 / 33 * g_boc11(f, fc, tc) + 4.0 / 33 * g_boc61(f, fc, tc); }
+static double g_boc11_f2(double f, double fc, double tc) { return g_boc11(f, fc, tc) * f * f; }
+static double g_pilot_f2(double f, double fc, double tc) { return g_pilot(f, fc, tc) * f * f; }
+
+extern "C" double bds_calc_weighing_factor(const bds_settings *s) {
+    const double fc = s->codeFreqBasis, tc = 1 / fc, br = s->FEBW;
+    const int panels = 4096;
+    // even integrands: 2 * integral over [0, Br/2]
+    const double p11_2 = 2 * gl16_integrate(g_boc11_f2, fc, tc, 0, br / 2, panels);
+    const double p11 = 2 * gl16_integrate(g_boc11, fc, tc, 0, br / 2, panels);
+    const double pp_2 = 2 * gl16_integrate(g_pilot_f2, fc, tc, 0, br / 2, panels);
+    const double pp = 2 * gl16_integrate(g_pilot, fc, tc, 0, br / 2, panels);
+    const double rem11 = std::sqrt(p11_2 / p11), remp = std::sqrt(pp_2 / pp);
+    const double t1 = 11 * p11 * rem11 * rem11, t2 = 33 * pp * remp * remp;
+    return t1 / (t1 + t2);
+}
+
+// preRun.m:61-76
+extern "C" int bds_pre_run(const bds_settings *s, int max_prn, const double *carrFreq, const double *codePhase,
+                           const double *peakMetric, bds_channel *channel) {
+    if (!s || !carrFreq || !codePhase || !peakMetric || !channel || max_prn < 1) return BDS_ERR_ARG;
+    const int nch = s->numberOfChannels;
+    for (int i = 0; i < nch; ++i) {
+        channel[i].PRN = 0;
+        channel[i].status = '-';
+        channel[i].acquiredFreq = channel[i].codePhase = channel[i].codeFreq = 0;
+    }
+    std::vector<int> idx((size_t)max_prn);
+    std::iota(idx.begin(), idx.end(), 0);
+    // sort(peakMetric, 'descend') -- stable, ties keep ascending PRN order
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return peakMetric[a] > peakMetric[b]; });
+    int ndet = 0;
+    for (int i = 0; i < max_prn; ++i) ndet += carrFreq[i] != 0;
+    for (int ii = 0; ii < std::min(nch, ndet); ++ii) {
+        const int p = idx[(size_t)ii];
+        channel[ii].PRN = p + 1;
+        channel[ii].acquiredFreq = carrFreq[p];
+        channel[ii].codePhase = codePhase[p];
+        if (s->signal == BDS_SIGNAL_B1C)  // B1C/include/preRun.m:71-73
+            channel[ii].codeFreq = s->codeFreqBasis - (channel[ii].acquiredFreq - s->IF) / s->carrFreqBasis * s->codeFreqBasis;
+        else  // B2a/include/preRun.m:70
+            channel[ii].codeFreq = s->codeFreqBasis;
+        channel[ii].status = 'T';
+    }
+    return BDS_OK;
+}

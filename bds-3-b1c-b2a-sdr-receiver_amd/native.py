@@ -1,0 +1,378 @@
+"""ctypes binding of ``libbds_mi355x.so`` (the C ABI declared in include/bds_mi355x.h).
+
+This is the repo's counterpart of the MEX gateway (mex/bds_mex.c): the same
+entry points, called from Python instead of MATLAB.  There is no CPU fallback --
+if the library is missing or no GPU is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+BDS_MAX_PRN = 63
+SIGNAL = {"B1C": 1, "B2A": 2}
+TRACK_MODE = {"B2A": 0, "NB": 1, "WB": 2}
+CODE_KIND = {"data": 0, "pilot": 1, "data_boc11": 2, "pilot_boc11": 3, "pilot_boc61": 4}
+CODE_LEN = {0: 10230, 1: 10230, 2: 20460, 3: 20460, 4: 122760}
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbds_mi355x.so")
+
+
+class BdsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libbds_mi355x error {code}: {msg}")
+        self.code = code
+
+
+class Settings(C.Structure):
+    _fields_ = [
+        ("signal", C.c_int32), ("fileType", C.c_int32),
+        ("samplingFreq", C.c_double), ("IF", C.c_double), ("codeFreqBasis", C.c_double),
+        ("carrFreqBasis", C.c_double),
+        ("codeLength", C.c_int32), ("numberOfChannels", C.c_int32),
+        ("skipNumberOfBytes", C.c_int64), ("msToProcess", C.c_double),
+        ("acqSearchBand", C.c_double), ("acqStep", C.c_double), ("acqThreshold", C.c_double),
+        ("acqCohT", C.c_double), ("pilotACQflag", C.c_int32), ("fineNoncoh", C.c_int32),
+        ("resamplingThreshold", C.c_double), ("resamplingflag", C.c_int32), ("n_acq", C.c_int32),
+        ("acqSatelliteList", C.c_int32 * BDS_MAX_PRN),
+        ("pilotTRKflag", C.c_int32), ("intTime", C.c_double),
+        ("dllCorrelatorSpacing", C.c_double), ("dllDampingRatio", C.c_double),
+        ("dllNoiseBandwidth", C.c_double), ("pllNoiseBandwidth", C.c_double),
+        ("CNoInterval", C.c_int32), ("reserved0", C.c_int32), ("FEBW", C.c_double),
+    ]
+
+
+class Channel(C.Structure):
+    _fields_ = [("PRN", C.c_int32), ("status", C.c_int32), ("acquiredFreq", C.c_double),
+                ("codePhase", C.c_double), ("codeFreq", C.c_double)]
+
+
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int32)
+
+TRACK_FIELDS = ["absoluteSample", "codeFreq", "carrFreq", "I_P", "I_E", "I_L", "Q_E", "Q_P", "Q_L",
+                "Pilot_I_P", "Pilot_Q_P", "Pilot_I_E", "Pilot_I_L", "Pilot_Q_E", "Pilot_Q_L",
+                "dllDiscr", "dllDiscrFilt", "pllDiscr", "pllDiscrFilt", "remCodePhase", "remCarrPhase",
+                "DataCNo", "DataPLD", "PilotCNo", "PilotPLD", "SigCNo"]
+
+
+class TrackOut(C.Structure):
+    _fields_ = ([("n_ch", C.c_int32), ("n_epochs", C.c_int32), ("n_cno", C.c_int32), ("reserved0", C.c_int32)]
+                + [(f, _DP) for f in TRACK_FIELDS] + [("completed", _IP), ("status", _IP)])
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("forward_ms", C.c_double), ("search_ms", C.c_double),
+                ("refine_ms", C.c_double), ("cell_pair_ms", C.c_double), ("cells_per_pair", C.c_double),
+                ("n_pairs", C.c_int64), ("fft_len", C.c_int64), ("n_circ", C.c_int64),
+                ("n_bins", C.c_int32), ("n_prn", C.c_int32), ("n_comp", C.c_int32), ("reserved0", C.c_int32)]
+
+
+EXPORTS = [
+    "bds_create", "bds_destroy", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_gen_code", "bds_acquire",
+    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_acq_grid", "bds_acq_peaks", "bds_get_timing",
+    "bds_track", "bds_track_mem", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
+    "bds_calc_weighing_factor", "bds_pre_run",
+]
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f"{_LIB_PATH} is missing: run ./build.sh (or __graft_entry__.build()); "
+                          "there is no CPU fallback")
+    # Share ONE HIP runtime with PyTorch when both live in a process: torch bundles its own
+    # libamdhip64.so.7; importing it first makes the loader reuse it for our DT_NEEDED entry.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing only; the library also runs without it
+        pass
+    L = C.CDLL(_LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    i8p = C.POINTER(C.c_int8)
+    SP = C.POINTER(Settings)
+    L.bds_create.restype, L.bds_create.argtypes = vp, [i32]
+    L.bds_destroy.restype, L.bds_destroy.argtypes = None, [vp]
+    L.bds_last_error.restype, L.bds_last_error.argtypes = C.c_char_p, [vp]
+    L.bds_device_name.restype, L.bds_device_name.argtypes = i32, [vp, C.c_char_p, i32]
+    L.bds_gen_code.restype, L.bds_gen_code.argtypes = i32, [i32, i32, i32, i8p, i32]
+    L.bds_acquire.restype = i32
+    L.bds_acquire.argtypes = [vp, SP, i8p, sz, i32, i32, _DP, _DP, _DP, _IP]
+    L.bds_acq_load.restype, L.bds_acq_load.argtypes = i32, [vp, SP, i8p, sz, i32]
+    L.bds_acq_prepare.restype, L.bds_acq_prepare.argtypes = i32, [vp, SP]
+    L.bds_acq_run.restype = i32
+    L.bds_acq_run.argtypes = [vp, SP, _IP, i32, i32, _DP, _DP, _DP, _IP]
+    L.bds_acq_grid.restype, L.bds_acq_grid.argtypes = i32, [vp, C.POINTER(C.c_float), _IP, i32]
+    L.bds_acq_peaks.restype, L.bds_acq_peaks.argtypes = i32, [vp, i32, _DP, _DP, _IP]
+    L.bds_get_timing.restype, L.bds_get_timing.argtypes = i32, [vp, C.POINTER(Timing)]
+    L.bds_track.restype = i32
+    L.bds_track.argtypes = [vp, SP, C.c_char_p, i32, C.POINTER(Channel), C.POINTER(TrackOut)]
+    L.bds_track_mem.restype = i32
+    L.bds_track_mem.argtypes = [vp, SP, i8p, sz, i32, C.POINTER(Channel), C.POINTER(TrackOut)]
+    L.bds_track_correlate.restype = i32
+    L.bds_track_correlate.argtypes = [vp, SP, i8p, sz, i32, _IP, _DP, _DP]
+    L.bds_calc_loop_coef.restype = None
+    L.bds_calc_loop_coef.argtypes = [C.c_double, C.c_double, C.c_double, _DP, _DP]
+    L.bds_calc_loop_coef_carr.restype, L.bds_calc_loop_coef_carr.argtypes = None, [SP, _DP, _DP, _DP]
+    L.bds_calc_weighing_factor.restype, L.bds_calc_weighing_factor.argtypes = C.c_double, [SP]
+    L.bds_pre_run.restype = i32
+    L.bds_pre_run.argtypes = [SP, i32, _DP, _DP, _DP, C.POINTER(Channel)]
+    L.bds_abi_check.restype, L.bds_abi_check.argtypes = i32, [i32, i32, i32, i32]
+    if L.bds_abi_check(C.sizeof(Settings), C.sizeof(Channel), C.sizeof(TrackOut), C.sizeof(Timing)) != 0:
+        raise ImportError("ctypes struct layout does not match libbds_mi355x.so (include/bds_mi355x.h changed?)")
+    _lib = L
+    return L
+
+
+def pack_settings(s) -> Settings:
+    """MATLAB-style settings struct -> bds_settings (missing field -> error naming the field)."""
+    cs = Settings()
+    sig = str(getattr(s, "signal", "")).upper()
+    if sig not in SIGNAL:
+        raise ValueError("settings.signal must be 'B1C' or 'B2A'")
+    cs.signal = SIGNAL[sig]
+
+    def need(name):
+        if not hasattr(s, name):
+            raise AttributeError(f"settings.{name} is missing")
+        return getattr(s, name)
+
+    def opt(name, default):
+        return getattr(s, name, default)
+
+    if str(opt("dataType", "schar")) not in ("schar", "int8"):
+        raise ValueError("settings.dataType must be 'schar' (int8 samples)")
+    cs.fileType = int(opt("fileType", 1))
+    cs.samplingFreq = float(need("samplingFreq"))
+    cs.IF = float(need("IF"))
+    cs.codeFreqBasis = float(need("codeFreqBasis"))
+    cs.carrFreqBasis = float(opt("carrFreqBasis", 0.0))
+    cs.codeLength = int(need("codeLength"))
+    cs.numberOfChannels = int(opt("numberOfChannels", 0))
+    cs.skipNumberOfBytes = int(opt("skipNumberOfBytes", 0))
+    cs.msToProcess = float(opt("msToProcess", 0))
+    cs.acqSearchBand = float(opt("acqSearchBand", 0))
+    cs.acqStep = float(opt("acqStep", 1))
+    cs.acqThreshold = float(opt("acqThreshold", 0))
+    cs.acqCohT = float(opt("acqCohT", 10))
+    cs.pilotACQflag = int(opt("pilotACQflag", 1))
+    cs.fineNoncoh = int(opt("fineNoncoh", 15))
+    cs.resamplingThreshold = float(opt("resamplingThreshold", 0))
+    cs.resamplingflag = int(opt("resamplingflag", 0))
+    sats = [int(p) for p in np.atleast_1d(opt("acqSatelliteList", []))]
+    if len(sats) > BDS_MAX_PRN:
+        raise ValueError("settings.acqSatelliteList longer than 63")
+    cs.n_acq = len(sats)
+    for i, p in enumerate(sats):
+        cs.acqSatelliteList[i] = p
+    cs.pilotTRKflag = int(opt("pilotTRKflag", 0))
+    cs.intTime = float(opt("intTime", 0.001))
+    cs.dllCorrelatorSpacing = float(opt("dllCorrelatorSpacing", 0.5))
+    cs.dllDampingRatio = float(opt("dllDampingRatio", 0.7))
+    cs.dllNoiseBandwidth = float(opt("dllNoiseBandwidth", 1))
+    cs.pllNoiseBandwidth = float(opt("pllNoiseBandwidth", 10))
+    cs.CNoInterval = int(opt("CNoInterval", 50))
+    cs.FEBW = float(opt("FEBW", 0))
+    return cs
+
+
+def _i8(a):
+    a = np.ascontiguousarray(a, dtype=np.int8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int8))
+
+
+def gen_code(signal: str, kind: str, prn: int) -> np.ndarray:
+    """bds_gen_code -> int8 array of +-1 (host side; works without a GPU)."""
+    k = CODE_KIND[kind]
+    out = np.empty(CODE_LEN[k], dtype=np.int8)
+    rc = lib().bds_gen_code(SIGNAL[signal.upper()], k, int(prn), out.ctypes.data_as(C.POINTER(C.c_int8)), out.size)
+    if rc < 0:
+        raise BdsError(rc, f"bds_gen_code({signal}, {kind}, {prn})")
+    return out
+
+
+def gen_primary_code(signal: str, kind: str, prn: int) -> np.ndarray:
+    return gen_code(signal, kind, prn)
+
+
+class Context:
+    """One bds_ctx (one GPU)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = lib()
+        self._h = self._lib.bds_create(int(device))
+        if not self._h:
+            raise BdsError(-2, self._lib.bds_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bds_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc < 0:
+            raise BdsError(rc, self._lib.bds_last_error(self._h).decode())
+        return rc
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self._check(self._lib.bds_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    # -- acquisition -----------------------------------------------------------------
+    def acq_load(self, settings, samples, is_complex=False):
+        cs = pack_settings(settings)
+        a, p = _i8(samples)
+        n = a.size // 2 if is_complex else a.size
+        self._check(self._lib.bds_acq_load(self._h, C.byref(cs), p, n, int(is_complex)))
+
+    def acq_prepare(self, settings):
+        cs = pack_settings(settings)
+        self._check(self._lib.bds_acq_prepare(self._h, C.byref(cs)))
+
+    def acq_run(self, settings, prn_list=None):
+        cs = pack_settings(settings)
+        max_prn = max(int(p) for p in np.atleast_1d(settings.acqSatelliteList))
+        carr = np.zeros(max_prn)
+        cph = np.zeros(max_prn)
+        pm = np.zeros(max_prn)
+        det = np.zeros(max_prn, dtype=np.int32)
+        if prn_list is None:
+            pl, npl = None, 0
+        else:
+            arr = np.ascontiguousarray(prn_list, dtype=np.int32)
+            pl, npl = arr.ctypes.data_as(_IP), arr.size
+        self._check(self._lib.bds_acq_run(self._h, C.byref(cs), pl, npl, max_prn,
+                                          carr.ctypes.data_as(_DP), cph.ctypes.data_as(_DP),
+                                          pm.ctypes.data_as(_DP), det.ctypes.data_as(_IP)))
+        return carr, cph, pm, det
+
+    def acquire(self, settings, samples, is_complex=False):
+        cs = pack_settings(settings)
+        a, p = _i8(samples)
+        n = a.size // 2 if is_complex else a.size
+        max_prn = max(int(q) for q in np.atleast_1d(settings.acqSatelliteList))
+        carr = np.zeros(max_prn)
+        cph = np.zeros(max_prn)
+        pm = np.zeros(max_prn)
+        det = np.zeros(max_prn, dtype=np.int32)
+        self._check(self._lib.bds_acquire(self._h, C.byref(cs), p, n, int(is_complex), max_prn,
+                                          carr.ctypes.data_as(_DP), cph.ctypes.data_as(_DP),
+                                          pm.ctypes.data_as(_DP), det.ctypes.data_as(_IP)))
+        return carr, cph, pm, det
+
+    def acq_grid(self, n_prn, n_bins):
+        rm = np.zeros(n_prn * n_bins, dtype=np.float32)
+        ra = np.zeros(n_prn * n_bins, dtype=np.int32)
+        self._check(self._lib.bds_acq_grid(self._h, rm.ctypes.data_as(C.POINTER(C.c_float)),
+                                           ra.ctypes.data_as(_IP), rm.size))
+        return rm.reshape(n_prn, n_bins), ra.reshape(n_prn, n_bins)
+
+    def acq_peaks(self, max_prn):
+        pk = np.zeros(max_prn)
+        dn = np.zeros(max_prn)
+        fb = np.zeros(max_prn, dtype=np.int32)
+        self._check(self._lib.bds_acq_peaks(self._h, max_prn, pk.ctypes.data_as(_DP), dn.ctypes.data_as(_DP),
+                                            fb.ctypes.data_as(_IP)))
+        return pk, dn, fb
+
+    def timing(self) -> dict:
+        t = Timing()
+        self._check(self._lib.bds_get_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in Timing._fields_ if f != "reserved0"}
+
+    # -- tracking --------------------------------------------------------------------
+    def track(self, settings, source, channels, n_epochs, n_cno, fields):
+        """source: file path (str/bytes) or int8 array of raw file bytes.
+        Returns dict field -> array [n_ch, n_epochs] (C/N0 fields [n_ch, n_cno])."""
+        cs = pack_settings(settings)
+        nch = len(channels)
+        carr = (Channel * nch)()
+        for i, ch in enumerate(channels):
+            carr[i].PRN = int(ch.PRN)
+            carr[i].status = ord(ch.status) if isinstance(ch.status, str) else int(ch.status)
+            carr[i].acquiredFreq = float(ch.acquiredFreq)
+            carr[i].codePhase = float(ch.codePhase)
+            carr[i].codeFreq = float(ch.codeFreq)
+        out = TrackOut()
+        out.n_ch, out.n_epochs, out.n_cno = nch, n_epochs, n_cno
+        arrays = {}
+        for f in fields:
+            n = n_cno if f in ("DataCNo", "DataPLD", "PilotCNo", "PilotPLD", "SigCNo") else n_epochs
+            arrays[f] = np.zeros((nch, n))
+            setattr(out, f, arrays[f].ctypes.data_as(_DP))
+        completed = np.zeros(nch, dtype=np.int32)
+        status = np.zeros(nch, dtype=np.int32)
+        out.completed = completed.ctypes.data_as(_IP)
+        out.status = status.ctypes.data_as(_IP)
+        if isinstance(source, (str, bytes, os.PathLike)):
+            path = os.fsencode(source)
+            self._check(self._lib.bds_track(self._h, C.byref(cs), path, nch, carr, C.byref(out)))
+        else:
+            a, p = _i8(source)
+            self._check(self._lib.bds_track_mem(self._h, C.byref(cs), p, a.size, nch, carr, C.byref(out)))
+        arrays["completed"] = completed
+        arrays["status"] = status
+        return arrays
+
+    def track_correlate(self, settings, file_bytes, prns, state6):
+        cs = pack_settings(settings)
+        a, p = _i8(file_bytes)
+        prn = np.ascontiguousarray(prns, dtype=np.int32)
+        st = np.ascontiguousarray(state6, dtype=np.float64).reshape(prn.size, 6)
+        sums = np.zeros((prn.size, 18))
+        self._check(self._lib.bds_track_correlate(self._h, C.byref(cs), p, a.size, prn.size,
+                                                  prn.ctypes.data_as(_IP), st.ctypes.data_as(_DP),
+                                                  sums.ctypes.data_as(_DP)))
+        return sums
+
+
+def calc_loop_coef(lbw, zeta, k):
+    t1, t2 = C.c_double(), C.c_double()
+    lib().bds_calc_loop_coef(lbw, zeta, k, C.byref(t1), C.byref(t2))
+    return t1.value, t2.value
+
+
+def calc_loop_coef_carr(settings):
+    cs = pack_settings(settings)
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    lib().bds_calc_loop_coef_carr(C.byref(cs), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def calc_weighing_factor(settings):
+    cs = pack_settings(settings)
+    return float(lib().bds_calc_weighing_factor(C.byref(cs)))
+
+
+def pre_run(settings, carr_freq, code_phase, peak_metric):
+    cs = pack_settings(settings)
+    n = len(carr_freq)
+    nch = int(settings.numberOfChannels)
+    ch = (Channel * nch)()
+    a = np.ascontiguousarray(carr_freq, dtype=np.float64)
+    b = np.ascontiguousarray(code_phase, dtype=np.float64)
+    c = np.ascontiguousarray(peak_metric, dtype=np.float64)
+    rc = lib().bds_pre_run(C.byref(cs), n, a.ctypes.data_as(_DP), b.ctypes.data_as(_DP), c.ctypes.data_as(_DP), ch)
+    if rc < 0:
+        raise BdsError(rc, "bds_pre_run")
+    return ch

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Build libbds_mi355x.so (HIP, gfx950 only) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+PKG="$ROOT/bds-3-b1c-b2a-sdr-receiver_amd"
+SRC="$PKG/csrc"
+OUT="$PKG/libbds_mi355x.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off
+       -Wall -Wno-unused-result -I"$ROOT/include" -I"$SRC")
+mkdir -p "$PKG/build"
+objs=()
+for f in bds_codes.cpp bds_api.hip bds_acq.hip bds_track.hip; do
+    o="$PKG/build/${f%.*}.o"
+    # rebuild when the source or any header is newer than the object
+    if [ ! -f "$o" ] || [ -n "$(find "$SRC/$f" "$SRC"/*.h "$ROOT/include"/*.h -newer "$o" 2>/dev/null)" ]; then
+        echo "hipcc $f"
+        if [[ "$f" == *.cpp ]]; then
+            "$HIPCC" "${FLAGS[@]}" -x c++ -c "$SRC/$f" -o "$o"
+        else
+            "$HIPCC" "${FLAGS[@]}" -c "$SRC/$f" -o "$o" ${BDS_HIPCC_EXTRA:-}
+        fi
+    fi
+    objs+=("$o")
+done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT" -Wl,-rpath,/opt/rocm/lib
+echo "built $OUT"

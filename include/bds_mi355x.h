@@ -1,0 +1,229 @@
+/*
+ * bds_mi355x.h -- C ABI of libbds_mi355x.so: MI355X (gfx950) acquisition and
+ * tracking correlators for BDS-3 B1C / B2a.
+ *
+ * The reference (lyf8118/BDS-3-B1C-B2a-SDR-receiver) is pure MATLAB and has no
+ * FFI layer of its own; the drop-in boundary is the MATLAB call surface used by
+ * postProcessing.m.  Every entry point below names the reference interface it
+ * replaces (paths relative to /root/reference/BDS3_B1C_B2a).  The MEX gateway
+ * (mex/bds_mex.c) and the ctypes host layer (bds_amd/native.py) bind exactly
+ * these symbols.  Plain pointers and sizes only; all buffers are caller-owned
+ * host memory unless stated.
+ *
+ * Conventions: every function returning int returns 0 on success, <0 on error
+ * (BDS_ERR_*); bds_last_error() gives the message.  Indices that the reference
+ * reports 1-based (codePhase) stay 1-based; absoluteSample stays 0-based.
+ */
+#ifndef BDS_MI355X_H
+#define BDS_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDS_API __attribute__((visibility("default")))
+
+#define BDS_MAX_PRN 63
+
+enum { BDS_SIGNAL_B1C = 1, BDS_SIGNAL_B2A = 2 };
+/* tracking variant: B2a/tracking.m | B1C/NB_tracking.m | B1C/WB_tracking.m */
+enum { BDS_TRACK_B2A = 0, BDS_TRACK_NB = 1, BDS_TRACK_WB = 2 };
+/* bds_gen_code kinds */
+enum {
+    BDS_CODE_DATA_PRIMARY = 0,  /* 10230 chips (+-1)                                        */
+    BDS_CODE_PILOT_PRIMARY = 1, /* 10230 chips                                               */
+    BDS_CODE_DATA_BOC11 = 2,    /* B1C only, 20460 half-chips   generateDataBOC11.m:85-91    */
+    BDS_CODE_PILOT_BOC11 = 3,   /* B1C only, 20460              generatePilotBOC11.m:88-94   */
+    BDS_CODE_PILOT_BOC61 = 4    /* B1C only, 122760             generatePilotBOC61.m:89-96   */
+};
+
+enum {
+    BDS_OK = 0,
+    BDS_ERR_ARG = -1,         /* bad argument / settings field                    */
+    BDS_ERR_HIP = -2,         /* HIP runtime error                                */
+    BDS_ERR_UNSUPPORTED = -3, /* valid in the reference, not built yet            */
+    BDS_ERR_IO = -4,          /* file open/read failure (fopen error, B2a/postProcessing.m:152-154) */
+    BDS_ERR_NOMEM = -5
+};
+
+/*
+ * Flat mirror of the `settings` struct fields the acquisition/tracking path
+ * reads (B1C/initSettings.m:48-151, B2a/initSettings.m:44-130).
+ * Field names are the MATLAB names.
+ */
+typedef struct bds_settings {
+    int32_t signal; /* BDS_SIGNAL_*: which receiver directory the struct came from */
+    int32_t fileType;              /* 1 = real int8, 2 = interleaved I/Q int8        */
+    double samplingFreq;           /* [Hz] */
+    double IF;                     /* [Hz] */
+    double codeFreqBasis;          /* [Hz] */
+    double carrFreqBasis;          /* [Hz] (B1C preRun Doppler aiding)               */
+    int32_t codeLength;            /* [chips] 10230                                  */
+    int32_t numberOfChannels;
+    int64_t skipNumberOfBytes;
+    double msToProcess;            /* [ms] */
+    /* acquisition */
+    double acqSearchBand;          /* [Hz] half width                                */
+    double acqStep;                /* [Hz] */
+    double acqThreshold;
+    double acqCohT;                /* [ms] B1C only                                  */
+    int32_t pilotACQflag;          /* B1C only                                       */
+    int32_t fineNoncoh;            /* B2a only: code periods in the fine search      */
+    double resamplingThreshold;
+    int32_t resamplingflag;        /* must be 0 (resampling branch not built)        */
+    int32_t n_acq;                 /* length of acqSatelliteList                     */
+    int32_t acqSatelliteList[BDS_MAX_PRN];
+    /* tracking */
+    int32_t pilotTRKflag;          /* B2a 0/1; B1C 0 / 1 (NB) / 2 (WB)               */
+    double intTime;                /* [s] */
+    double dllCorrelatorSpacing;   /* [chips] */
+    double dllDampingRatio;
+    double dllNoiseBandwidth;      /* [Hz] */
+    double pllNoiseBandwidth;      /* [Hz] */
+    int32_t CNoInterval;
+    int32_t reserved0;
+    double FEBW;                   /* [Hz] B1C WB only (CalcWeighingFactor.m:46)     */
+} bds_settings;
+
+/* channel(1 x nCh) of preRun.m:46-56 */
+typedef struct bds_channel {
+    int32_t PRN;          /* 0 = unused */
+    int32_t status;       /* '-' or 'T' */
+    double acquiredFreq;  /* [Hz] */
+    double codePhase;     /* 1-based sample */
+    double codeFreq;      /* [Hz] */
+} bds_channel;
+
+/*
+ * trackResults(1 x nCh) of B2a/tracking.m:48-96 / B1C/WB_tracking.m:53-112 as
+ * structure-of-arrays: every pointer is caller-allocated double[n_ch * n_epochs]
+ * (channel-major) except the C/N0 arrays, double[n_ch * n_cno], and
+ * `completed`/`status`.  Pointers of fields the selected variant does not create
+ *  may be NULL.  The library initialises the arrays the way
+ * the reference template does (zeros / inf) before tracking.
+ */
+typedef struct bds_track_out {
+    int32_t n_ch, n_epochs, n_cno, reserved0;
+    double *absoluteSample, *codeFreq, *carrFreq;
+    double *I_P, *I_E, *I_L, *Q_E, *Q_P, *Q_L;
+    double *Pilot_I_P, *Pilot_Q_P;                         /* pilot tracking on     */
+    double *Pilot_I_E, *Pilot_I_L, *Pilot_Q_E, *Pilot_Q_L; /* WB only               */
+    double *dllDiscr, *dllDiscrFilt, *pllDiscr, *pllDiscrFilt;
+    double *remCodePhase, *remCarrPhase;
+    double *DataCNo, *DataPLD, *PilotCNo, *PilotPLD, *SigCNo; /* SigCNo = B1C_CNo | B2a_CNo */
+    int32_t *completed; /* [n_ch] epochs finished per channel                        */
+    int32_t *status;    /* [n_ch] '-' or 'T' (B2a/tracking.m:48,441)                 */
+} bds_track_out;
+
+/* per-stage device timing of the last bds_acq_run / bds_track call (hipEvent, ms) */
+typedef struct bds_timing {
+    double total_ms;        /* whole call, stream time                              */
+    double forward_ms;      /* wipe-off + forward transforms, all bins              */
+    double search_ms;       /* all (PRN, bin) cells: multiply + inverse + |.| max   */
+    double refine_ms;       /* f64 re-evaluation of candidate cells + fine search   */
+    double cell_pair_ms;    /* average duration of one (rows+cols) launch pair, sampled */
+    double cells_per_pair;  /* (PRN, bin) cells one launch pair processes           */
+    int64_t n_pairs;        /* launch pairs in the call                             */
+    int64_t fft_len;        /* padded transform length L                            */
+    int64_t n_circ;         /* N: the reference's circular correlation length       */
+    int32_t n_bins, n_prn, n_comp, reserved0;
+} bds_timing;
+
+typedef struct bds_ctx bds_ctx;
+
+/* ---- context ---------------------------------------------------------------- */
+/* One context per GPU (one process per GPU under torch.distributed / RCCL). */
+BDS_API bds_ctx *bds_create(int device_id);
+BDS_API void bds_destroy(bds_ctx *ctx);
+BDS_API const char *bds_last_error(const bds_ctx *ctx); /* ctx may be NULL: creation errors */
+BDS_API int bds_device_name(const bds_ctx *ctx, char *buf, int buflen);
+/* Binding self-check: returns 0 when the caller's struct sizes equal the library's. */
+BDS_API int bds_abi_check(int sizeof_settings, int sizeof_channel, int sizeof_track_out, int sizeof_timing);
+
+/* ---- ranging codes (host side, no GPU needed) -------------------------------- */
+/* Replaces generateB2aDataCode.m / generateB2aPilotCode.m / generateDataBOC11.m /
+ * generatePilotBOC11.m / generatePilotBOC61.m.  Writes +-1 into out[0..n); returns
+ * the code length, or <0.  n must be >= the code length. */
+BDS_API int bds_gen_code(int signal, int kind, int prn, int8_t *out, int n);
+
+/* ---- acquisition -------------------------------------------------------------
+ * acqResults = acquisition(longSignal, settings)
+ *   B2a/acquisition.m:1, B1C/acquisition.m:1, B1C/GPU_acquisition.m:1
+ * samples: int8 IF samples as fread(...,'schar') delivers them
+ *   (B2a/postProcessing.m:89-90, B1C/postProcessing.m:94); n_samples real samples
+ *   (or I/Q pairs when is_complex, fileType 2).
+ * carrFreq/codePhase/peakMetric: double[max_prn], max_prn >= max(acqSatelliteList);
+ *   zero where not searched / not detected (B2a/acquisition.m:161-165).
+ * detected (optional, may be NULL): int32[max_prn], 1 where the PRN passed the
+ *   threshold -- lets the caller print the reference's "(19 20 . )" line
+ *   (B2a/acquisition.m:167,259,360,366).
+ */
+BDS_API int bds_acquire(bds_ctx *ctx, const bds_settings *s, const int8_t *samples,
+                        size_t n_samples, int is_complex, int max_prn, double *carrFreq,
+                        double *codePhase, double *peakMetric, int32_t *detected);
+
+/* The same call split in three so that the timed region of a benchmark starts with
+ * the IF block resident in HBM and the code spectra cached:
+ *   bds_acq_load    H2D copy of the IF block
+ *   bds_acq_prepare code spectra for settings.acqSatelliteList (cached in ctx)
+ *   bds_acq_run     forward transforms, PRN x Doppler search, refinement, fine search
+ * prn_list/n_prn select the PRN shard this rank searches (NULL/0 = acqSatelliteList);
+ * outputs are zero for PRNs outside the shard so that an all-reduce(SUM) across
+ * ranks reassembles acqResults bit-exactly (x + 0). */
+BDS_API int bds_acq_load(bds_ctx *ctx, const bds_settings *s, const int8_t *samples,
+                         size_t n_samples, int is_complex);
+BDS_API int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s);
+BDS_API int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *prn_list, int n_prn,
+                        int max_prn, double *carrFreq, double *codePhase, double *peakMetric,
+                        int32_t *detected);
+
+/* Diagnostics of the last bds_acq_run: per searched PRN (in search order) and Doppler
+ * bin, the maximum of results(bin,:) (fp32 search value) and its 1-based lag.
+ * row_max/row_arg: [n_prn * n_bins].  Returns n_prn*n_bins or <0. */
+BDS_API int bds_acq_grid(bds_ctx *ctx, float *row_max, int32_t *row_arg, int cap);
+/* Peak / second-peak (B2a) or peak / sigPower (B1C) of the last run, per PRN slot:
+ * peak[max_prn], denom[max_prn], fbin[max_prn] (1-based frequency bin). */
+BDS_API int bds_acq_peaks(bds_ctx *ctx, int max_prn, double *peak, double *denom, int32_t *fbin);
+BDS_API int bds_get_timing(bds_ctx *ctx, bds_timing *t);
+
+/* ---- tracking -----------------------------------------------------------------
+ * [trackResults, channel] = tracking(fid, channel, settings)
+ *   B2a/tracking.m:1, B1C/NB_tracking.m:1, B1C/WB_tracking.m:1
+ * The reference seeks absolutely from 'bof' (B2a/tracking.m:151-153), so the MATLAB
+ * wrapper passes the file *path* (fopen(fid)) instead of the handle.
+ * Returns 0 also when the file ends early: like B2a/tracking.m:250-254 the results
+ * gathered so far are returned, `completed[ch]` says how far each channel got and
+ * status stays '-' for the channel that hit EOF and all later ones.
+ */
+BDS_API int bds_track(bds_ctx *ctx, const bds_settings *s, const char *path, int n_ch,
+                      const bds_channel *channel, bds_track_out *out);
+/* Same, on an IF record already in host memory (n_bytes raw file bytes). */
+BDS_API int bds_track_mem(bds_ctx *ctx, const bds_settings *s, const int8_t *file_bytes,
+                          size_t n_bytes, int n_ch, const bds_channel *channel,
+                          bds_track_out *out);
+/* Open-loop check entry: one correlate-and-dump epoch per channel with the caller's
+ * NCO state (no loop update).  state: per channel {sample offset (0-based), blksize,
+ * remCodePhase, codeFreq, remCarrPhase, carrFreq}; sums: [n_ch][18] raw correlator
+ * outputs in the order I_E,Q_E,I_P,Q_P,I_L,Q_L, pilot(6), pilot BOC61 (6). */
+BDS_API int bds_track_correlate(bds_ctx *ctx, const bds_settings *s, const int8_t *file_bytes,
+                                size_t n_bytes, int n_ch, const int32_t *prn,
+                                const double *state6, double *sums18);
+
+/* ---- helpers replacing small host functions on the path ------------------------ */
+/* Common/calcLoopCoef.m:41-45 */
+BDS_API void bds_calc_loop_coef(double lbw, double zeta, double k, double *tau1, double *tau2);
+/* Common/calcLoopCoefCarr.m:41-56 */
+BDS_API void bds_calc_loop_coef_carr(const bds_settings *s, double *pf3, double *pf2, double *pf1);
+/* B1C/include/CalcWeighingFactor.m:43-81 */
+BDS_API double bds_calc_weighing_factor(const bds_settings *s);
+/* preRun.m:61-76 (B1C applies Doppler aiding to codeFreq, B2a does not) */
+BDS_API int bds_pre_run(const bds_settings *s, int max_prn, const double *carrFreq,
+                        const double *codePhase, const double *peakMetric, bds_channel *channel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDS_MI355X_H */

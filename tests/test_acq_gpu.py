@@ -1,0 +1,68 @@
+"""GPU parity: HIP acquisition (through the C ABI) vs the float64 oracle on the same int8 block.
+
+Tolerances: codePhase exact, carrFreq exact (a grid value),
+peakMetric <= 1e-6 relative; the fp32 search grid (diagnostic) <= 2e-5 relative.
+"""
+import numpy as np
+import pytest
+
+import bds_amd
+from oracle import acquisition as oacq
+
+from helpers import cfg1_b2a, medium_b2a, small_b1c
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(s, x, ctx, oracle_fn):
+    diag = {}
+    ref = oracle_fn(x.astype(np.float64), s, diag)
+    got = bds_amd.acquisition(x, s)
+    sats = [int(p) for p in s.acqSatelliteList]
+    np.testing.assert_array_equal(got.codePhase, ref.codePhase)
+    np.testing.assert_array_equal(got.carrFreq, ref.carrFreq)
+    np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0)
+    nb = len(oacq.freq_bins(s))
+    rm, ra = ctx.acq_grid(len(sats), nb)
+    pk, dn, fb = ctx.acq_peaks(max(sats))
+    for i, p in enumerate(sats):
+        np.testing.assert_allclose(rm[i], diag[p]["row_max"], rtol=2e-5)
+        assert np.mean(ra[i] == diag[p]["row_arg"]) > 0.9
+        assert fb[p - 1] == diag[p]["fbin"]
+        np.testing.assert_allclose(pk[p - 1], diag[p]["peak"], rtol=1e-9)
+    return ref, got
+
+
+def test_cfg1_b2a_one_prn_three_bins(ctx):
+    s, x, _ = cfg1_b2a()
+    ref, got = _compare(s, x, ctx, oacq.acquisition_b2a)
+    assert got.carrFreq[18] != 0  # PRN 19 detected
+
+
+def test_b2a_four_prns_full_grid(ctx):
+    s, x, sats = medium_b2a()
+    ref, got = _compare(s, x, ctx, oacq.acquisition_b2a)
+    for sat in sats:
+        assert got.carrFreq[sat.prn - 1] != 0
+        assert abs(got.carrFreq[sat.prn - 1] - (s.IF + sat.doppler)) <= 25
+
+
+def test_b1c_reduced_rate(ctx):
+    s, x, sats = small_b1c()
+    ref, got = _compare(s, x, ctx, oacq.acquisition_b1c)
+    assert got.carrFreq[2] != 0 and got.carrFreq[6] == 0
+
+
+def test_b1c_data_only_and_short_coherent(ctx):
+    s, x, _ = small_b1c(prns=(3, 7), band=300)
+    s = s.copy(pilotACQflag=0, acqCohT=5, acqStep=100)
+    _compare(s, x, ctx, oacq.acquisition_b1c)
+
+
+def test_prn_shards_sum_to_the_full_result(ctx):
+    s, x, _ = medium_b2a()
+    full = bds_amd.acquisition(x, s, verbose=False)
+    a = bds_amd.acquisition(x, s, prn_list=[5, 19], verbose=False)
+    b = bds_amd.acquisition(x, s, prn_list=[9, 33], verbose=False)
+    for f in ("carrFreq", "codePhase", "peakMetric"):
+        np.testing.assert_array_equal(getattr(a, f) + getattr(b, f), getattr(full, f))
