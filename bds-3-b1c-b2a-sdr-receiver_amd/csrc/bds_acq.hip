@@ -307,7 +307,7 @@ static hipStream_t st(bds_ctx *ctx) { return (hipStream_t)ctx->stream; }
 static int set_lds_limits(bds_ctx *ctx) {
     static bool done = false;
     if (done) return BDS_OK;
-    const int maxlds = 160 * 1024;
+    const int maxlds = 160 * 1024 - 4096;  // leave room for the kernels' small static LDS
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_fwd<SignalLoader>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_fwd<CodeLoader>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
