@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Acquisition throughput benchmark (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload b1c|b2a]
+
+A *step* is one complete acquisition pass of the hot path over one synthetic IF
+block: forward transforms of every Doppler bin, the PRN x Doppler parallel
+code-phase search, f64 refinement and the fine-Doppler search, with the int8 IF
+block already resident in HBM and the code spectra cached (bds_acq_load /
+bds_acq_prepare are outside the timed region).
+
+Workload at N=1 (default): BASELINE.json configs[2] -- BDS-3 B1C full acquisition,
+63 PRNs x 201 Doppler bins, 10 ms coherent data+pilot, fs = 99.375 MS/s,
+IF = 14.58 MHz -- the configuration the north star quotes its roofline target on.
+``--workload b2a`` runs configs[1] (B2a, 63 PRNs x 26 bins).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the PRN list is
+sharded round-robin over ranks; every step ends with one RCCL all-reduce(SUM) of the
+three per-PRN result vectors (3 x 63 f64), the only exchange the path has.  Total
+work is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def build_workload(name):
+    import bds_amd
+    from bds_amd import synth
+
+    prns_present = [1, 4, 9, 14, 19, 20, 27, 35, 46, 58]
+    rng = np.random.default_rng(3550)
+    if name == "b1c":
+        s = bds_amd.init_settings_b1c(samplingFreq=99.375e6, IF=14.58e6, acqSatelliteList=list(range(1, 64)),
+                                      acqCohT=10, pilotACQflag=1)
+        spc = 993750
+        n_samples = 20 * spc  # B1C/postProcessing.m:94
+        label = "BDS-3 B1C full acquisition: 63 PRNs x 201 Doppler bins, 10 ms coherent data+pilot, fs=99.375 MS/s"
+    else:
+        s = bds_amd.init_settings_b2a(acqSatelliteList=list(range(1, 64)))
+        spc = 99375
+        n_samples = 17 * spc  # (fineNoncoh+2)*spc, B2a/postProcessing.m:89-90
+        label = "BDS-3 B2a full acquisition: 63 PRNs x 26 Doppler bins (+-5 kHz / 400 Hz), 1 ms code, fs=99.375 MS/s"
+    sats = synth.random_sats(rng, prns_present, spc, cn0_dbhz=45.0)
+    # only the first N + spc samples can be touched by acquisition;
+    # the tail is noise-only to keep generation fast
+    head = min(n_samples, 4 * spc if name == "b1c" else n_samples)
+    x = np.empty(n_samples, dtype=np.int8)
+    synth.make_if(s, sats, head, seed=3550, out=x[:head])
+    if head < n_samples:
+        x[head:] = np.clip(np.rint(rng.normal(0, 20.0, n_samples - head)), -127, 127).astype(np.int8)
+    return s, x, sats, label
+
+
+def cpu_baseline(s, x, name, budget_s=20.0):
+    """The oracle (NumPy/SciPy float64 restatement = 'port') timed on the host cores on a
+    bounded sample of the same workload: whole Doppler rows of one PRN until the budget is used."""
+    cores = os.cpu_count() or 1
+    os.environ["BDS_ORACLE_FFT_WORKERS"] = str(cores)
+    from oracle import acquisition as oacq
+
+    gen = oacq.b1c_coarse_rows if name == "b1c" else oacq.b2a_coarse_rows
+    xf = x.astype(np.float64)
+    t0 = time.perf_counter()
+    cells = 0
+    n = None
+    for prn in range(1, 64):
+        for b, row in gen(xf, s, prn):
+            n = row.size
+            cells += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": cells * n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{cells} (PRN, Doppler-bin) cells of the same block (code-spectrum FFTs included), "
+                      f"{dt:.1f} s, scipy.fft workers={cores}; float64 NumPy restatement of acquisition.m, not MATLAB"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="b1c", choices=["b1c", "b2a"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import bds_amd
+
+    s, x, sats, label = build_workload(args.workload)
+    all_prns = [int(p) for p in s.acqSatelliteList]
+    shard = all_prns[rank::world]  # PRN shard of this rank (cost per PRN is uniform)
+    ctx = bds_amd.get_context(local_rank)
+    ctx.acq_load(s, x)
+    ctx.acq_prepare(s)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        carr, cph, pm, det = ctx.acq_run(s, shard)
+        if dist is not None:
+            buf = torch.from_numpy(np.stack([carr, cph, pm])).cuda()
+            dist.all_reduce(buf)  # RCCL all-reduce(SUM) of 3 x max_prn f64: x + 0 is exact
+            carr, cph, pm = buf.cpu().numpy()
+        return carr, cph, pm
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    tim = []
+    for _ in range(args.steps):
+        res = step()
+        tim.append(ctx.timing())
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    tm = tim[-1]
+    n_circ, n_bins, ncomp = tm["n_circ"], tm["n_bins"], tm["n_comp"]
+    p_total = len(all_prns)
+    ms_per_step = dt / args.steps * 1e3
+    cell_msps = n_circ * p_total * n_bins / (dt / args.steps) / 1e6
+    # algorithmic bytes: per cell 8*(1+ncomp)*N (signal + code spectra, fp32 complex);
+    # per bin 9*N (int8 in, spectrum out).  One launch pair (rows+cols kernels) = cells_per_pair cells.
+    pair_ms = float(np.mean([t["cell_pair_ms"] for t in tim]))
+    cells_per_pair = tm["cells_per_pair"]
+    bytes_per_pair = cells_per_pair * 8 * (1 + ncomp) * n_circ
+    achieved = bytes_per_pair / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+    b_alg = 9 * n_circ * n_bins + 8 * (1 + ncomp) * n_circ * p_total * n_bins
+
+    detected = sorted(int(p) for p in np.nonzero(res[0])[0] + 1)
+    out = {
+        "metric": "IF Msamples/s through acquisition (all PRNs x Doppler bins)",
+        "value": cell_msps,
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32 search + f64 refinement",
+        "data": "synthetic",
+        "config": {"workload": label, "prns": p_total, "doppler_bins": n_bins, "n_circ": n_circ,
+                   "fft_len": tm["fft_len"], "components": ncomp, "parallelism": f"prn-shard x{world}",
+                   "satellites_injected": sorted(sat.prn for sat in sats), "satellites_detected": detected},
+        "block_msps": n_circ / (dt / args.steps) / 1e6,
+        "whole_job_algorithmic_GBps": b_alg / (dt / args.steps) / 1e9,
+        "whole_job_frac_of_hbm_peak": b_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+        "stage_ms": {k: float(np.mean([t[k] for t in tim])) for k in ("total_ms", "forward_ms", "search_ms", "refine_ms")},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_rows_inv + k_cols_inv_max launch pair (one pair = %d cells)" % int(cells_per_pair),
+                     "pair_ms": pair_ms},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(s, x, args.workload)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
