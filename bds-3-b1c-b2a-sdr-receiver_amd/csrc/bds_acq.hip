@@ -54,14 +54,16 @@ static bool is_5smooth(long v) {
 }
 
 static void factor_radices(int S, Plan1D &p) {
-    // radix order: 4s first (cheapest per bit), then a 2, then 3s and 5s
+    // few, large stages: 16s, then one 8/4/2 for the remaining power of two, then 5s and 3s.
+    // The largest radix goes first: the first autosort stage (Ns = 1) needs no twiddles.
     int v = S, n = 0;
     int rad[kMaxStages];
-    while (v % 4 == 0) rad[n++] = 4, v /= 4;
-    while (v % 2 == 0) rad[n++] = 2, v /= 2;
-    while (v % 3 == 0) rad[n++] = 3, v /= 3;
+    while (v % 16 == 0) rad[n++] = 16, v /= 16;
+    if (v % 8 == 0) rad[n++] = 8, v /= 8;
+    if (v % 4 == 0) rad[n++] = 4, v /= 4;
+    if (v % 2 == 0) rad[n++] = 2, v /= 2;
     while (v % 5 == 0) rad[n++] = 5, v /= 5;
-    // larger radices late (their twiddle tables index stays small early): sort descending cost last
+    while (v % 3 == 0) rad[n++] = 3, v /= 3;
     std::sort(rad, rad + n, [](int a, int b) { return a > b; });
     p.S = S;
     p.nstage = n;
@@ -77,38 +79,68 @@ static void factor_radices(int S, Plan1D &p) {
 
 static constexpr int kMaxColLen = 1280;   // column-pass transform length limit (LDS: T*L1*8 B)
 static constexpr int kMaxRowLen = 8192;   // row-pass transform length limit
-static constexpr int kColPoints = 10240;  // T*L1 budget (80 KiB of LDS)
+static constexpr int kColPoints = 8192;   // T*L1 budget (<= 72 KiB of LDS: two workgroups per CU)
 
-static int stage_count(int S) {
+// Relative cost of one length-S LDS transform per point: every stage is an LDS round trip
+// (dominant) plus radix-dependent arithmetic.
+static double plan_cost(int S) {
     Plan1D p{};
     factor_radices(S, p);
-    return p.nstage;
+    if (p.nstage > kMaxStages) return 1e30;
+    double c = 0;
+    for (int i = 0; i < p.nstage; ++i) {
+        switch (p.radix[i]) {
+            case 2: c += 1.0; break;
+            case 3: c += 1.1; break;
+            case 4: c += 1.1; break;
+            case 5: c += 1.3; break;
+            case 8: c += 1.3; break;
+            default: c += 1.6; break;
+        }
+    }
+    return c;
 }
 
-// smallest 5-smooth L >= need that splits as L1*L2 within the kernel limits
+// Padded length L >= need (5-smooth) and its split L1 x L2, chosen by a cost model:
+// L * (stage costs of both passes + a memory term) -- a slightly longer transform made of
+// radix-16 stages beats the tightest 5-smooth length made of 3s and 5s.
 static bool choose_lengths(long need, long &L, int &L1, int &L2) {
-    for (long cand = std::max<long>(need, 16);; ++cand) {
-        if (cand > (long)kMaxColLen * kMaxRowLen) return false;
-        if (!is_5smooth(cand)) continue;
-        int best = 0;
-        for (int a = 2; a <= kMaxColLen && (long)a * a <= cand; ++a)
-            if (cand % a == 0 && cand / a <= kMaxRowLen && stage_count(a) <= kMaxStages &&
-                stage_count((int)(cand / a)) <= kMaxStages)
-                best = a;
-        if (best) {
-            L = cand;
-            L1 = best;
-            L2 = (int)(cand / best);
+    const double kMem = 3.0;  // HBM/L2 traffic of the two passes, in units of one LDS stage
+    double best = 1e30;
+    const long lo = std::max<long>(need, 64), hi = lo + lo / 2 + 64;
+    if (const char *e = std::getenv("BDS_ACQ_FORCE_L1L2")) {  // "L1xL2" (tuning / tests)
+        int a = 0, b = 0;
+        if (sscanf(e, "%dx%d", &a, &b) == 2 && (long)a * b >= need && is_5smooth(a) && is_5smooth(b) &&
+            a <= kMaxColLen && b <= kMaxRowLen) {
+            L = (long)a * b;
+            L1 = a;
+            L2 = b;
             return true;
         }
     }
+    for (long cand = lo; cand <= hi; ++cand) {
+        if (!is_5smooth(cand)) continue;
+        for (int a = 4; a <= kMaxColLen; ++a) {
+            if (cand % a) continue;
+            const long b = cand / a;
+            if (b > kMaxRowLen || b < a / 4) continue;
+            const double c = (double)cand * (plan_cost(a) + plan_cost((int)b) + kMem);
+            if (c < best) best = c, L = cand, L1 = a, L2 = (int)b;
+        }
+    }
+    return best < 1e29;
 }
 
-static int threads_for(long points) {
-    // (S/R)*T <= floor(16/R)*nthr for R in {2,3,4,5}  <=>  points <= 15*nthr
-    long nt = (points + 14) / 15;
-    nt = ((nt + 63) / 64) * 64;
-    return (int)std::min<long>(1024, std::max<long>(256, nt));
+// threads a workgroup needs for T transforms of plan p: every stage must fit
+// (S/R)*T butterflies into floor(16/R) per thread, and loaders hold <= 16 points per thread
+static int threads_for(const Plan1D &p, int T) {
+    long need = ((long)p.S * T + kPointsPerThread - 1) / kPointsPerThread;
+    for (int i = 0; i < p.nstage; ++i) {
+        const int R = p.radix[i], mb = kPointsPerThread / R;
+        need = std::max<long>(need, ((long)(p.S / R) * T + mb - 1) / mb);
+    }
+    need = ((need + 63) / 64) * 64;
+    return (int)std::max<long>(64, need);
 }
 
 static void plan_free(Plan2D &pl) {
@@ -139,14 +171,21 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
     while (logT > 0 && ((long)pl.L1 << logT) > kColPoints) --logT;
     while (logT > 0 && (1 << logT) > pl.L2) --logT;
     pl.logT = logT;
-    pl.Spad = pl.L1 | 1;
+    pl.Spad = lds_span(pl.L1) + 4;  // +4: successive columns start 8 dwords apart in the bank row
     pl.ntiles = (pl.L2 + (1 << logT) - 1) >> logT;
-    pl.nt_cols = threads_for((long)pl.L1 << logT);
-    pl.nt_rows = threads_for(pl.L2);
-    if (((long)pl.L1 << logT) > 15L * pl.nt_cols || pl.L2 > 15L * pl.nt_rows)
+    pl.nt_cols = threads_for(pl.p1, 1 << logT);
+    pl.nt_rows = threads_for(pl.p2, 1);
+    if (pl.nt_cols > 1024 || pl.nt_rows > 1024)
         return fail(ctx, BDS_ERR_UNSUPPORTED, "transform %d x %d exceeds the per-workgroup budget", pl.L1, pl.L2);
     pl.lds_cols = sizeof(float2) * (size_t)pl.Spad * (size_t)(1 << logT);
-    pl.lds_rows = sizeof(float2) * (size_t)pl.L2;
+    pl.lds_rows = sizeof(float2) * (size_t)lds_span(pl.L2);
+    if (std::getenv("BDS_VERBOSE")) {
+        fprintf(stderr, "[bds] plan: need %ld -> L %ld = %d (cols:", need, pl.L, pl.L1);
+        for (int i = 0; i < pl.p1.nstage; ++i) fprintf(stderr, " %d", pl.p1.radix[i]);
+        fprintf(stderr, "; T=%d, %d thr, %zu B LDS) x %d (rows:", 1 << logT, pl.nt_cols, pl.lds_cols, pl.L2);
+        for (int i = 0; i < pl.p2.nstage; ++i) fprintf(stderr, " %d", pl.p2.radix[i]);
+        fprintf(stderr, "; %d thr, %zu B LDS)\n", pl.nt_rows, pl.lds_rows);
+    }
     int rc;
     if ((rc = upload_twiddles(ctx, pl.L1, pl.L1, 1, &pl.d_tw1))) return rc;
     if ((rc = upload_twiddles(ctx, pl.L2, pl.L2, 1, &pl.d_tw2))) return rc;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(1024) void k_cols_fwd(Plan1D p, TwiddleL twl, int L
         const int col = c0 + j;
         float2 v = make_float2(0.f, 0.f);
         if (col < L2) v = ld(batch, (long)r * L2 + col);
-        lds[j * Spad + r] = v;
+        lds[j * Spad + lds_phys(r)] = v;
     }
     __syncthreads();
     fft_lds<-1>(lds, p, Spad, T, tid, nthr);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(1024) void k_cols_fwd(Plan1D p, TwiddleL twl, int L
         const int col = c0 + j;
         if (col < L2) {
             const float2 w = twl.get<-1>((uint32_t)k1 * (uint32_t)col);
-            o[(long)k1 * L2 + col] = cmul(lds[j * Spad + k1], w);
+            o[(long)k1 * L2 + col] = cmul(lds[j * Spad + lds_phys(k1)], w);
         }
     }
 }
@@ -121,12 +121,12 @@ __global__ __launch_bounds__(1024) void k_rows_fwd(Plan1D p, const float2 *__res
     const int row = blockIdx.x, batch = blockIdx.y;
     const int S = p.S;
     const float2 *src = in + (long)batch * in_stride + (long)row * S;
-    for (int e = tid; e < S; e += nthr) lds[e] = src[e];
+    for (int e = tid; e < S; e += nthr) lds[lds_phys(e)] = src[e];
     __syncthreads();
     fft_lds<-1>(lds, p, S, 1, tid, nthr);
     float2 *dst = out + (long)batch * out_stride + (long)row * S;
     for (int e = tid; e < S; e += nthr) {
-        float2 v = lds[e];
+        float2 v = lds[lds_phys(e)];
         v.x *= scale;
         v.y *= conj_flag ? -scale : scale;
         dst[e] = v;
@@ -147,6 +147,15 @@ __global__ __launch_bounds__(1024) void k_rows_inv(Plan1D p, TwiddleL twl, const
     const int S = p.S;
     const float2 *xr = Xs + (long)(bin0 + g) * L + (long)k1 * S;
     constexpr int MAXE = kPointsPerThread;
+    // inter-pass twiddle W_L^(-k1 e), e = tid + i*nthr, as base(tid) * step(i): the per-element
+    // table gather (64 cache lines per instruction) is replaced by one gather per thread and a
+    // broadcast LDS read per element.
+    __shared__ float2 s_step[MAXE];
+    if (tid < MAXE) {
+        const long m = (long)k1 * ((long)tid * nthr);
+        s_step[tid] = m < L ? twl.get<+1>((uint32_t)m) : make_float2(1.f, 0.f);
+    }
+    const float2 wbase = tid < S ? twl.get<+1>((uint32_t)k1 * (uint32_t)tid) : make_float2(1.f, 0.f);
     float2 xv[MAXE];
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) {
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(1024) void k_rows_inv(Plan1D p, TwiddleL twl, const
 #pragma unroll
         for (int i = 0; i < MAXE; ++i) {
             const int e = tid + i * nthr;
-            if (e < S) lds[e] = cmul(xv[i], cr[e]);
+            if (e < S) lds[lds_phys(e)] = cmul(xv[i], cr[e]);
         }
         __syncthreads();
         fft_lds<+1>(lds, p, S, 1, tid, nthr);
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(1024) void k_rows_inv(Plan1D p, TwiddleL twl, const
 #pragma unroll
         for (int i = 0; i < MAXE; ++i) {
             const int e = tid + i * nthr;
-            if (e < S) dst[e] = cmul(lds[e], twl.get<+1>((uint32_t)k1 * (uint32_t)e));
+            if (e < S) dst[e] = cmul(lds[lds_phys(e)], cmul(wbase, s_step[i]));
         }
         __syncthreads();
     }
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(1024) void k_cols_inv_max(Plan1D p, int L2, int log
             const int col = c0 + j;
             float2 v = make_float2(0.f, 0.f);
             if (col < L2) v = src[(long)r * L2 + col];
-            lds[j * Spad + r] = v;
+            lds[j * Spad + lds_phys(r)] = v;
         }
         __syncthreads();
         fft_lds<+1>(lds, p, Spad, T, tid, nthr);
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(1024) void k_cols_inv_max(Plan1D p, int L2, int log
             const int e = tid + i * nthr;
             if (e < (S << logT)) {
                 const int n1 = e >> logT, j = e & (T - 1);
-                const float2 y = lds[j * Spad + n1];
+                const float2 y = lds[j * Spad + lds_phys(n1)];
                 const float a = w * sqrtf(y.x * y.x + y.y * y.y);
                 mag[i] = comp == 0 ? a : mag[i] + a;
             }

@@ -24,6 +24,14 @@ namespace bds {
 constexpr int kMaxStages = 12;
 constexpr int kPointsPerThread = 16;  // register budget per stage: floor(16/R)*R points
 
+// LDS transforms are stored with one pad element after every 16: physical index of
+// logical element i.  A radix-R autosort stage writes with a lane stride of R elements
+// (a multiple of the 128-B bank row for R = 16); the pad turns that into an odd-ish
+// stride so the 64 lanes of a ds_write_b64 spread over all banks.
+__host__ __device__ __forceinline__ constexpr int lds_phys(int i) { return i + (i >> 4); }
+// elements an LDS transform of logical length S occupies
+__host__ __device__ __forceinline__ constexpr int lds_span(int S) { return lds_phys(S - 1) + 1; }
+
 struct FastDiv {
     uint32_t d, m;  // m = ceil(2^32/d), or 0 when d == 1
     __host__ __device__ FastDiv() : d(1), m(0) {}
@@ -132,8 +140,73 @@ struct Butterfly<5, DIR> {
     }
 };
 
+// multiply by the forward constant (cr - j ci) (DIR < 0) or its conjugate (DIR > 0)
+template <int DIR>
+__device__ __forceinline__ float2 mulc(float2 a, float cr, float ci) {
+    return DIR < 0 ? make_float2(a.x * cr + a.y * ci, a.y * cr - a.x * ci)
+                   : make_float2(a.x * cr - a.y * ci, a.y * cr + a.x * ci);
+}
+
+template <int DIR>
+struct Butterfly<8, DIR> {
+    // n = 2 n1 + n2, k = k1 + 4 k2:  X[k1 + 4 k2] = sum_n2 W2^(n2 k2) W8^(n2 k1) sum_n1 x[2 n1 + n2] W4^(n1 k1)
+    __device__ __forceinline__ static void run(float2 *v) {
+        const float h = 0.70710678118654752440f;
+        float2 a0[4] = {v[0], v[2], v[4], v[6]};
+        float2 a1[4] = {v[1], v[3], v[5], v[7]};
+        Butterfly<4, DIR>::run(a0);
+        Butterfly<4, DIR>::run(a1);
+        a1[1] = mulc<DIR>(a1[1], h, h);    // W8^1
+        a1[2] = rot90<DIR>(a1[2]);         // W8^2 = -j
+        a1[3] = mulc<DIR>(a1[3], -h, h);   // W8^3
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) {
+            v[k1] = cadd(a0[k1], a1[k1]);
+            v[k1 + 4] = csub(a0[k1], a1[k1]);
+        }
+    }
+};
+
+template <int DIR>
+struct Butterfly<16, DIR> {
+    // n = 4 n1 + n2, k = k1 + 4 k2:  X[k1 + 4 k2] = sum_n2 W4^(n2 k2) W16^(n2 k1) sum_n1 x[4 n1 + n2] W4^(n1 k1)
+    __device__ __forceinline__ static void run(float2 *v) {
+        const float h = 0.70710678118654752440f;
+        const float c = 0.92387953251128675613f;  // cos(pi/8)
+        const float s = 0.38268343236508977173f;  // sin(pi/8)
+        float2 a[4][4];
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) {
+            a[n2][0] = v[n2];
+            a[n2][1] = v[n2 + 4];
+            a[n2][2] = v[n2 + 8];
+            a[n2][3] = v[n2 + 12];
+            Butterfly<4, DIR>::run(a[n2]);
+        }
+        // W16^(n2 k1)
+        a[1][1] = mulc<DIR>(a[1][1], c, s);    // W16^1
+        a[1][2] = mulc<DIR>(a[1][2], h, h);    // W16^2
+        a[1][3] = mulc<DIR>(a[1][3], s, c);    // W16^3
+        a[2][1] = mulc<DIR>(a[2][1], h, h);    // W16^2
+        a[2][2] = rot90<DIR>(a[2][2]);         // W16^4 = -j
+        a[2][3] = mulc<DIR>(a[2][3], -h, h);   // W16^6
+        a[3][1] = mulc<DIR>(a[3][1], s, c);    // W16^3
+        a[3][2] = mulc<DIR>(a[3][2], -h, h);   // W16^6
+        a[3][3] = mulc<DIR>(a[3][3], -c, -s);  // W16^9 = -W16^1
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) {
+            float2 u[4] = {a[0][k1], a[1][k1], a[2][k1], a[3][k1]};
+            Butterfly<4, DIR>::run(u);
+            v[k1] = u[0];
+            v[k1 + 4] = u[1];
+            v[k1 + 8] = u[2];
+            v[k1 + 12] = u[3];
+        }
+    }
+};
+
 // One Stockham stage of radix R over T transforms of length p.S in buf[j*Spad + i].
-// Requires (S/R)*T <= floor(16/R) * blockDim.x  (checked on the host).
+// buf[j*Spad + lds_phys(i)]; requires (S/R)*T <= floor(16/R) * blockDim.x  (checked on the host).
 template <int R, int DIR>
 __device__ __forceinline__ void fft_stage(float2 *__restrict__ buf, const Plan1D &p, int st, int Spad,
                                           int T, int tid, int nthr) {
@@ -154,9 +227,9 @@ __device__ __forceinline__ void fft_stage(float2 *__restrict__ buf, const Plan1D
             const int bb = b - j * nb;
             jbase[i] = j * Spad;
             bbv[i] = bb;
-            const float2 *src = buf + jbase[i] + bb;
+            const float2 *src = buf + jbase[i];
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[i][q] = src[q * nb];
+            for (int q = 0; q < R; ++q) v[i][q] = src[lds_phys(bb + q * nb)];
         }
     }
     __syncthreads();
@@ -169,17 +242,45 @@ __device__ __forceinline__ void fft_stage(float2 *__restrict__ buf, const Plan1D
             const int k = bb - hi * Ns;
             if (Ns > 1) {
                 const int kt = k * tws;
+                // Table gathers are texture-addresser bound (up to 64 cache lines per
+                // instruction), so the large radices fetch only the power-of-two multiples
+                // and build the rest as products of at most four exact factors.
+                if constexpr (R == 16 || R == 8) {
+                    float2 w[R];
+                    w[1] = p.tw[kt];
+                    w[2] = p.tw[2 * kt];
+                    w[4] = p.tw[4 * kt];
+                    if constexpr (R == 16) w[8] = p.tw[8 * kt];
+                    if (DIR > 0) {
+                        w[1].y = -w[1].y;
+                        w[2].y = -w[2].y;
+                        w[4].y = -w[4].y;
+                        if constexpr (R == 16) w[8].y = -w[8].y;
+                    }
+                    w[3] = cmul(w[1], w[2]);
+                    w[5] = cmul(w[1], w[4]);
+                    w[6] = cmul(w[2], w[4]);
+                    w[7] = cmul(w[3], w[4]);
+                    if constexpr (R == 16) {
 #pragma unroll
-                for (int q = 1; q < R; ++q) {
-                    float2 w = p.tw[q * kt];
-                    if (DIR > 0) w.y = -w.y;
-                    v[i][q] = cmul(v[i][q], w);
+                        for (int q = 1; q < 8; ++q) w[8 + q] = cmul(w[q], w[8]);
+                    }
+#pragma unroll
+                    for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], w[q]);
+                } else {
+#pragma unroll
+                    for (int q = 1; q < R; ++q) {
+                        float2 w = p.tw[q * kt];
+                        if (DIR > 0) w.y = -w.y;
+                        v[i][q] = cmul(v[i][q], w);
+                    }
                 }
             }
             Butterfly<R, DIR>::run(v[i]);
-            float2 *dst = buf + jbase[i] + hi * Ns * R + k;
+            float2 *dst = buf + jbase[i];
+            const int j0 = hi * Ns * R + k;
 #pragma unroll
-            for (int q = 0; q < R; ++q) dst[q * Ns] = v[i][q];
+            for (int q = 0; q < R; ++q) dst[lds_phys(j0 + q * Ns)] = v[i][q];
         }
     }
     __syncthreads();
@@ -195,7 +296,9 @@ __device__ __forceinline__ void fft_lds(float2 *__restrict__ buf, const Plan1D &
             case 2: fft_stage<2, DIR>(buf, p, st, Spad, T, tid, nthr); break;
             case 3: fft_stage<3, DIR>(buf, p, st, Spad, T, tid, nthr); break;
             case 4: fft_stage<4, DIR>(buf, p, st, Spad, T, tid, nthr); break;
-            default: fft_stage<5, DIR>(buf, p, st, Spad, T, tid, nthr); break;
+            case 5: fft_stage<5, DIR>(buf, p, st, Spad, T, tid, nthr); break;
+            case 8: fft_stage<8, DIR>(buf, p, st, Spad, T, tid, nthr); break;
+            default: fft_stage<16, DIR>(buf, p, st, Spad, T, tid, nthr); break;
         }
     }
 }

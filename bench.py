@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="b1c", choices=["b1c", "b2a"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prns", type=int, default=63, help="tuning only: search PRNs 1..N instead of all 63")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +116,9 @@ def main():
     import bds_amd
 
     s, x, sats, label = build_workload(args.workload)
+    if args.prns != 63:
+        s.acqSatelliteList = list(range(1, args.prns + 1))
+        label += f" [TUNING RUN: PRNs 1..{args.prns} only]"
     all_prns = [int(p) for p in s.acqSatelliteList]
     shard = all_prns[rank::world]  # PRN shard of this rank (cost per PRN is uniform)
     ctx = bds_amd.get_context(local_rank)
