@@ -1,16 +1,768 @@
-// Tracking (placeholder while the acquisition path is brought up).
+// Tracking: channel-batched correlate-and-dump + DLL/PLL loop update on the GPU.
+//
+// Replaces BDS-3_B2a/tracking.m:98-441, BDS-3_B1C/NB_tracking.m:107-448 and
+// BDS-3_B1C/WB_tracking.m:114-488 (the per-channel, per-epoch MATLAB loops), plus the
+// C/N0 + lock-detector post-pass of include/Calc_CNo_PLD.m.
+//
+// Structure: the IF record lives in HBM (int8).  Every epoch is two launches on one stream:
+//   k_trk_correlate  grid (blocks, channels): every block re-derives the epoch geometry
+//                    (blksize, code / carrier NCO start values) from the channel's f64 loop
+//                    state, walks its slice of the block of samples and emits 6/12/18 partial
+//                    correlator sums (per-thread fp32 over <= 16 samples, f64 from there on;
+//                    wave reduction by DPP shuffles, one LDS hop per workgroup)
+//   k_trk_update     one workgroup per channel: fixed-order sum of the partials, the
+//                    discriminators and loop filters in f64 exactly in the reference's
+//                    operation order, result arrays at epoch k, next NCO state
+// The host enqueues all epochs back to back and never synchronises inside the loop: the
+// sequential dependence (next blksize / phases depend on this epoch's discriminators) is
+// carried entirely by device memory.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
 #include "bds_internal.h"
+
 namespace bds {
-struct TrackState {};
-void track_state_free(TrackState *t) { delete t; }
+
+static constexpr int kChunk = 4096;    // samples per correlate workgroup
+static constexpr int kTrkThreads = 256;
+static constexpr int kNSums = 18;      // I_E,Q_E,I_P,Q_P,I_L,Q_L x {data, pilot BOC11 / B2a pilot, pilot BOC61}
+
+struct ChanState {
+    double codeFreq, remCodePhase, carrFreq, carrFreqBasis, remCarrPhase;
+    double oldCodeNco, oldCodeError, d2CarrError, dCarrError;
+    double codeFreqBasis;  // channel.codeFreq (tracking.m:389)
+    long long pos;         // byte/sample offset of the next read (ftell, fileType 1)
+    int prn;               // 0 = channel unused
+    int active;            // 1 while the channel keeps tracking
+    int completed;         // epochs finished
+    int pad;
+};
+
+struct TrkParams {
+    int mode;        // BDS_TRACK_*
+    int pilot;       // pilot correlators on
+    int code_len;    // 10230
+    int n_epochs;
+    double fs, inv_fs;
+    double spacing;  // dllCorrelatorSpacing (earlyLateSpc)
+    double tau1, tau2, pdi, pf1, pf2, pf3, factor;
+    long long n_bytes;
+};
+
+struct TrkOut {  // device arrays [n_ch][n_epochs]
+    double *absoluteSample, *codeFreq, *carrFreq, *I_P, *I_E, *I_L, *Q_E, *Q_P, *Q_L;
+    double *Pilot_I_P, *Pilot_Q_P, *Pilot_I_E, *Pilot_I_L, *Pilot_Q_E, *Pilot_Q_L;
+    double *dllDiscr, *dllDiscrFilt, *pllDiscr, *pllDiscrFilt, *remCodePhase, *remCarrPhase;
+};
+
+// padded-array lookup of the reference: [c(L) c(1..L) c(1)], 1-based index i in 1..L+2
+// (B2a/tracking.m:158; B1C/WB_tracking.m:181,187,192), evaluated on the primary code.
+//   units = 1  : chips           (B2a)
+//   units = 2  : BOC(1,1) half-chips  [-c, +c]         (generateDataBOC11.m:85-91)
+//   units = 12 : BOC(6,1) twelfths    (-1)^ii c, ii=1..12 (generatePilotBOC61.m:89-96)
+template <int UNITS>
+__device__ __forceinline__ float code_at(const int8_t *__restrict__ prim, int code_len, long i1) {
+    const long n = (long)code_len * UNITS;
+    long u = i1 - 2;  // 0-based index into the unpadded array
+    if (u < 0) u += n;
+    if (u >= n) u -= n;
+    if (UNITS == 1) return (float)prim[u];
+    if (UNITS == 2) {
+        const float c = (float)prim[u >> 1];
+        return (u & 1) ? c : -c;
+    }
+    const long chip = u / 12;
+    const int ii = (int)(u - chip * 12);  // ii-1
+    const float c = (float)prim[chip];
+    return (ii & 1) ? c : -c;  // ii-1 even -> ii odd -> (-1)^ii = -1
 }
-extern "C" int bds_track(bds_ctx *ctx, const bds_settings *, const char *, int, const bds_channel *, bds_track_out *) {
-    return bds::fail(ctx, BDS_ERR_UNSUPPORTED, "bds_track: not built yet");
+
+struct EpochGeom {
+    long long pos;
+    long blk;
+    double step, rem, carrFreq, remCarr;
+};
+
+__device__ __forceinline__ EpochGeom epoch_geom(const ChanState &s, const TrkParams &p) {
+    EpochGeom g;
+    g.pos = s.pos;
+    g.step = s.codeFreq / p.fs;                                               // tracking.m:230
+    g.blk = (long)ceil(((double)p.code_len - s.remCodePhase) / g.step);       // :233
+    g.rem = s.remCodePhase;
+    g.carrFreq = s.carrFreq;
+    g.remCarr = s.remCarrPhase;
+    return g;
 }
-extern "C" int bds_track_mem(bds_ctx *ctx, const bds_settings *, const int8_t *, size_t, int, const bds_channel *, bds_track_out *) {
-    return bds::fail(ctx, BDS_ERR_UNSUPPORTED, "bds_track_mem: not built yet");
+
+// One block of samples [k0, k1) of one channel: 18 partial sums (f64) to part[].
+template <int MODE>
+__device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data, const int8_t *__restrict__ prim_d,
+                                                const int8_t *__restrict__ prim_p, const TrkParams &p,
+                                                const EpochGeom &g, long k0, long k1, bool pilot, double *sums) {
+    constexpr double scale = MODE == BDS_TRACK_B2A ? 1.0 : 2.0;
+    constexpr int UNITS = MODE == BDS_TRACK_B2A ? 1 : 2;
+    const double inc = g.step * scale;
+    const double st_e = (g.rem - p.spacing) * scale;  // tracking.m:260-262 / WB_tracking.m:289-291
+    const double st_l = (g.rem + p.spacing) * scale;
+    const double st_p = g.rem * scale;
+    const double two_pi = 6.283185307179586476925286766559;
+    const double cyc0 = g.remCarr / two_pi;
+    float acc[kNSums];
+#pragma unroll
+    for (int i = 0; i < kNSums; ++i) acc[i] = 0.f;
+    for (long k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+        const float raw = (float)data[g.pos + k];
+        const double kd = (double)k;
+        const double te = st_e + kd * inc, tl = st_l + kd * inc, tp = st_p + kd * inc;
+        const long ie = (long)ceil(te) + 1, il = (long)ceil(tl) + 1, ip = (long)ceil(tp) + 1;
+        // carrier: trigarg = (carrFreq*2*pi)*(k/fs) + remCarrPhase  (tracking.m:303-304), in cycles
+        const double cyc = g.carrFreq * (kd * p.inv_fs) + cyc0;
+        const double fr = cyc - floor(cyc);
+        const float hi = (float)fr, lo = (float)(fr - (double)hi);
+        float sn, cs;
+        sincospif(2.0f * hi, &sn, &cs);
+        const float d = 6.28318530717958647692f * lo;
+        const float c2 = cs - d * sn, s2 = sn + d * cs;
+        float ib, qb;
+        if (MODE == BDS_TRACK_B2A) {  // exp(+j th): q = real, i = imag (tracking.m:309-314)
+            qb = raw * c2;
+            ib = raw * s2;
+        } else {  // exp(-j th): i = real, q = imag (NB_tracking.m:320-325)
+            ib = raw * c2;
+            qb = -raw * s2;
+        }
+        const float ce = code_at<UNITS>(prim_d, p.code_len, ie);
+        const float cp = code_at<UNITS>(prim_d, p.code_len, ip);
+        const float cl = code_at<UNITS>(prim_d, p.code_len, il);
+        acc[0] += ce * ib;
+        acc[1] += ce * qb;
+        acc[2] += cp * ib;
+        acc[3] += cp * qb;
+        acc[4] += cl * ib;
+        acc[5] += cl * qb;
+        if (pilot) {
+            const float pe = code_at<UNITS>(prim_p, p.code_len, ie);
+            const float pp = code_at<UNITS>(prim_p, p.code_len, ip);
+            const float pl = code_at<UNITS>(prim_p, p.code_len, il);
+            acc[6] += pe * ib;
+            acc[7] += pe * qb;
+            acc[8] += pp * ib;
+            acc[9] += pp * qb;
+            acc[10] += pl * ib;
+            acc[11] += pl * qb;
+            if (MODE == BDS_TRACK_WB) {  // pilotBOC61(ceil(tcode*6)+1)  (WB_tracking.m:298,311,324)
+                const float se = code_at<12>(prim_p, p.code_len, (long)ceil(te * 6) + 1);
+                const float sp = code_at<12>(prim_p, p.code_len, (long)ceil(tp * 6) + 1);
+                const float sl = code_at<12>(prim_p, p.code_len, (long)ceil(tl * 6) + 1);
+                acc[12] += se * ib;
+                acc[13] += se * qb;
+                acc[14] += sp * ib;
+                acc[15] += sp * qb;
+                acc[16] += sl * ib;
+                acc[17] += sl * qb;
+            }
+        }
+    }
+    // wave reduction (f64 from here), then one LDS hop
+    __shared__ double s_part[kTrkThreads / 64][kNSums];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kNSums; ++i) {
+        double v = (double)acc[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) s_part[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double v = 0;
+        for (int w = 0; w < kTrkThreads / 64; ++w) v += s_part[w][threadIdx.x];
+        sums[threadIdx.x] = v;
+    }
 }
-extern "C" int bds_track_correlate(bds_ctx *ctx, const bds_settings *, const int8_t *, size_t, int, const int32_t *, const double *, double *) {
-    return bds::fail(ctx, BDS_ERR_UNSUPPORTED, "bds_track_correlate: not built yet");
+
+// grid (nblocks, n_ch); part: [n_ch][nblocks][18]
+template <int MODE>
+__global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__restrict__ data,
+                                                              const int8_t *__restrict__ prim, TrkParams p,
+                                                              const ChanState *__restrict__ st,
+                                                              double *__restrict__ part, int nblocks) {
+    const int ch = blockIdx.y;
+    const ChanState s = st[ch];
+    double *out = part + ((long)ch * nblocks + blockIdx.x) * kNSums;
+    if (!s.active) return;
+    const EpochGeom g = epoch_geom(s, p);
+    const long k0 = (long)blockIdx.x * kChunk;
+    if (k0 >= g.blk || g.pos + g.blk > p.n_bytes) {  // beyond the block, or short read (update kernel aborts)
+        if (threadIdx.x < kNSums) out[threadIdx.x] = 0.0;
+        return;
+    }
+    const long k1 = min(g.blk, k0 + kChunk);
+    const int8_t *pd = prim + ((long)(s.prn - 1) * 2 + 0) * p.code_len;
+    const int8_t *pp = prim + ((long)(s.prn - 1) * 2 + 1) * p.code_len;
+    correlate_slice<MODE>(data, pd, pp, p, g, k0, k1, p.pilot != 0, out);
+}
+
+// Open-loop variant: geometry supplied by the caller (bds_track_correlate).
+template <int MODE>
+__global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t *__restrict__ data,
+                                                                   const int8_t *__restrict__ prim, TrkParams p,
+                                                                   const int *__restrict__ prn,
+                                                                   const double *__restrict__ state6,
+                                                                   double *__restrict__ part, int nblocks) {
+    const int ch = blockIdx.y;
+    const double *s6 = state6 + (long)ch * 6;
+    EpochGeom g;
+    g.pos = (long long)s6[0];
+    g.blk = (long)s6[1];
+    g.rem = s6[2];
+    g.step = s6[3] / p.fs;
+    g.remCarr = s6[4];
+    g.carrFreq = s6[5];
+    double *out = part + ((long)ch * nblocks + blockIdx.x) * kNSums;
+    const long k0 = (long)blockIdx.x * kChunk;
+    if (k0 >= g.blk || g.pos + g.blk > p.n_bytes || g.pos < 0) {
+        if (threadIdx.x < kNSums) out[threadIdx.x] = 0.0;
+        return;
+    }
+    const long k1 = min(g.blk, k0 + kChunk);
+    const int8_t *pd = prim + ((long)(prn[ch] - 1) * 2 + 0) * p.code_len;
+    const int8_t *pp = prim + ((long)(prn[ch] - 1) * 2 + 1) * p.code_len;
+    correlate_slice<MODE>(data, pd, pp, p, g, k0, k1, p.pilot != 0, out);
+}
+
+__global__ void k_trk_reduce_open(const double *__restrict__ part, int nblocks, double *__restrict__ sums) {
+    const int ch = blockIdx.x;
+    if (threadIdx.x < kNSums) {
+        double v = 0;
+        for (int b = 0; b < nblocks; ++b) v += part[((long)ch * nblocks + b) * kNSums + threadIdx.x];
+        sums[(long)ch * kNSums + threadIdx.x] = v;
+    }
+}
+
+// one workgroup (64 lanes) per channel
+template <int MODE>
+__global__ __launch_bounds__(64) void k_trk_update(TrkParams p, ChanState *__restrict__ st,
+                                                   const double *__restrict__ part, int nblocks, int epoch,
+                                                   TrkOut o) {
+    const int ch = blockIdx.x;
+    __shared__ double s_sum[kNSums];
+    ChanState s = st[ch];
+    if (!s.active) return;
+    const EpochGeom g = epoch_geom(s, p);
+    if (threadIdx.x < kNSums) {
+        // fixed-order sum over the correlate workgroups: bit-stable from run to run
+        const long nb = min((long)nblocks, (g.blk + kChunk - 1) / kChunk);
+        double v = 0;
+        for (long b = 0; b < nb; ++b) v += part[((long)ch * nblocks + b) * kNSums + threadIdx.x];
+        s_sum[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const long e = (long)ch * p.n_epochs + epoch;
+    o.absoluteSample[e] = (double)s.pos;  // tracking.m:226 (assigned before the read)
+    if (g.pos + g.blk > p.n_bytes || g.blk > (long)nblocks * kChunk) {
+        // short read: message + return in the reference (tracking.m:250-254); partial results stay
+        s.active = 0;
+        st[ch] = s;
+        return;
+    }
+    const double two_pi = 6.283185307179586476925286766559;
+    const double pi = 3.14159265358979323846;
+    const double L = (double)p.code_len;
+    o.remCodePhase[e] = s.remCodePhase;  // :258
+    o.remCarrPhase[e] = s.remCarrPhase;  // :300
+    // remCodePhase = tcode(blksize) + codePhaseStep - codeLength  (:295; B1C: tcode/2, WB:327)
+    double rem_next;
+    if (MODE == BDS_TRACK_B2A) {
+        const double tp_last = g.rem + (double)(g.blk - 1) * g.step;
+        rem_next = (tp_last + g.step) - L;
+    } else {
+        const double tp_last = g.rem * 2.0 + (double)(g.blk - 1) * (g.step * 2.0);
+        rem_next = tp_last / 2 + g.step - L;
+    }
+    // remCarrPhase = rem(trigarg(blksize+1), 2*pi)  (:303-305)
+    const double t_end = (double)g.blk / p.fs;
+    const double trig_end = ((s.carrFreq * 2.0 * pi) * t_end) + s.remCarrPhase;
+    const double carr_next = fmod(trig_end, two_pi);
+
+    const double I_E = s_sum[0], Q_E = s_sum[1], I_P = s_sum[2], Q_P = s_sum[3], I_L = s_sum[4], Q_L = s_sum[5];
+    double pI_E = s_sum[6], pQ_E = s_sum[7], pI_P = s_sum[8], pQ_P = s_sum[9], pI_L = s_sum[10], pQ_L = s_sum[11];
+    double cI_E = 0, cQ_E = 0, cI_P = 0, cQ_P = 0, cI_L = 0, cQ_L = 0;
+    if (MODE == BDS_TRACK_WB && p.pilot) {  // QMBOC composite, WB_tracking.m:375-380
+        const double a = sqrt(4.0 / 33), b = sqrt(29.0 / 33);
+        cI_E = -a * s_sum[12] + b * pQ_E;
+        cQ_E = -a * s_sum[13] - b * pI_E;
+        cI_P = -a * s_sum[14] + b * pQ_P;
+        cQ_P = -a * s_sum[15] - b * pI_P;
+        cI_L = -a * s_sum[16] + b * pQ_L;
+        cQ_L = -a * s_sum[17] - b * pI_L;
+    }
+    // ---- PLL discriminator (true division: I = 0 -> +-pi/2, 0/0 -> NaN, as MATLAB) ----------
+    double carrError = atan(Q_P / I_P) / two_pi;  // :337
+    if (p.pilot) {
+        if (MODE == BDS_TRACK_B2A) {
+            // QI = (pI + j pQ) * exp(-j pi/2); atan(imag/real)  (:345-348)
+            const double cr = cos(-pi / 2), sr = sin(-pi / 2);  // exp(-1i*pi/2) as MATLAB evaluates it
+            const double re = pI_P * cr - pQ_P * sr, im = pI_P * sr + pQ_P * cr;
+            const double cq = atan(im / re) / two_pi;
+            carrError = (carrError + cq) / 2;  // :352
+        } else if (MODE == BDS_TRACK_NB) {
+            const double cq = atan(-pI_P / pQ_P) / two_pi;  // NB:357
+            carrError = (carrError * 11 + cq * 29) / 40;    // NB:360
+        } else {
+            const double cq = atan(cQ_P / cI_P) / two_pi;  // WB:392
+            carrError = (carrError * 1 + cq * 3) / 4;      // WB:395
+        }
+    }
+    s.d2CarrError = s.d2CarrError + carrError * p.pf3;                    // :356
+    s.dCarrError = s.d2CarrError + carrError * p.pf2 + s.dCarrError;      // :357
+    const double carrNco = s.dCarrError + carrError * p.pf1;              // :358
+    o.carrFreq[e] = s.carrFreq;                                           // :361
+    // ---- DLL discriminator ---------------------------------------------------------------------
+    const double eE = sqrt(I_E * I_E + Q_E * Q_E), eL = sqrt(I_L * I_L + Q_L * Q_L);
+    double codeError = (eE - eL) / (eE + eL);  // :366
+    if (MODE != BDS_TRACK_B2A) codeError = codeError * (1 - p.spacing);  // WB:409-410
+    if (p.pilot) {
+        double pE, pL;
+        if (MODE == BDS_TRACK_WB) {
+            pE = sqrt(cI_E * cI_E + cQ_E * cQ_E);
+            pL = sqrt(cI_L * cI_L + cQ_L * cQ_L);
+        } else {
+            pE = sqrt(pI_E * pI_E + pQ_E * pQ_E);
+            pL = sqrt(pI_L * pI_L + pQ_L * pQ_L);
+        }
+        const double pce = (pE - pL) / (pE + pL);
+        if (MODE == BDS_TRACK_B2A)
+            codeError = (codeError + pce) / 2;  // :377
+        else if (MODE == BDS_TRACK_NB)
+            codeError = (codeError * 11 + pce * (1 - p.spacing) * 29) / 40;  // NB:381-384
+        else
+            codeError = codeError * p.factor + pce * (1 - p.spacing) * (1 - p.factor);  // WB:418
+    }
+    const double codeNco = s.oldCodeNco + (p.tau2 / p.tau1) * (codeError - s.oldCodeError) + codeError * (p.pdi / p.tau1);  // :381
+    s.oldCodeNco = codeNco;
+    s.oldCodeError = codeError;
+    o.codeFreq[e] = s.codeFreq;  // :387
+    o.dllDiscr[e] = codeError;
+    o.dllDiscrFilt[e] = codeNco;
+    o.pllDiscr[e] = carrError;
+    o.pllDiscrFilt[e] = carrNco;
+    o.I_E[e] = I_E;
+    o.I_P[e] = I_P;
+    o.I_L[e] = I_L;
+    o.Q_E[e] = Q_E;
+    o.Q_P[e] = Q_P;
+    o.Q_L[e] = Q_L;
+    if (p.pilot) {
+        if (MODE == BDS_TRACK_WB) {
+            o.Pilot_I_E[e] = cI_E;
+            o.Pilot_Q_E[e] = cQ_E;
+            o.Pilot_I_P[e] = cI_P;
+            o.Pilot_Q_P[e] = cQ_P;
+            o.Pilot_I_L[e] = cI_L;
+            o.Pilot_Q_L[e] = cQ_L;
+        } else {
+            o.Pilot_I_P[e] = pI_P;
+            o.Pilot_Q_P[e] = pQ_P;
+        }
+    }
+    s.carrFreq = s.carrFreqBasis + carrNco;   // :363
+    s.codeFreq = s.codeFreqBasis - codeNco;   // :389
+    s.remCodePhase = rem_next;
+    s.remCarrPhase = carr_next;
+    s.pos += g.blk;
+    s.completed = epoch + 1;
+    st[ch] = s;
+}
+
+struct TrackState {
+    int8_t *d_data = nullptr;
+    size_t data_cap = 0;
+    int8_t *d_prim = nullptr;
+    int prim_signal = 0;
+};
+
+void track_state_free(TrackState *t) {
+    if (!t) return;
+    if (t->d_data) (void)hipFree(t->d_data);
+    if (t->d_prim) (void)hipFree(t->d_prim);
+    delete t;
+}
+
+static hipStream_t st(bds_ctx *ctx) { return (hipStream_t)ctx->stream; }
+
+static int track_mode(const bds_settings &s) {
+    if (s.signal == BDS_SIGNAL_B2A) return BDS_TRACK_B2A;
+    return s.pilotTRKflag == 2 ? BDS_TRACK_WB : BDS_TRACK_NB;  // B1C/postProcessing.m:137-143
+}
+
+static int pilot_on(const bds_settings &s, int mode) {
+    if (mode == BDS_TRACK_WB) return s.pilotTRKflag == 2;
+    return s.pilotTRKflag == 1;  // tracking.m:70, NB_tracking.m:78
+}
+
+static int ensure_prim(bds_ctx *ctx, TrackState &t, int signal) {
+    if (t.d_prim && t.prim_signal == signal) return BDS_OK;
+    if (!t.d_prim) BDS_HIP(ctx, hipMalloc((void **)&t.d_prim, (size_t)BDS_MAX_PRN * 2 * 10230));
+    std::vector<int8_t> prim((size_t)BDS_MAX_PRN * 2 * 10230);
+    for (int prn = 1; prn <= BDS_MAX_PRN; ++prn)
+        for (int c = 0; c < 2; ++c) gen_primary(signal, c == 1, prn, &prim[((size_t)(prn - 1) * 2 + c) * 10230]);
+    BDS_HIP(ctx, hipMemcpy(t.d_prim, prim.data(), prim.size(), hipMemcpyHostToDevice));
+    t.prim_signal = signal;
+    return BDS_OK;
+}
+
+static int fill_params(bds_ctx *ctx, const bds_settings &s, TrkParams &p, int n_epochs, size_t n_bytes) {
+    if (s.signal != BDS_SIGNAL_B1C && s.signal != BDS_SIGNAL_B2A) return fail(ctx, BDS_ERR_ARG, "settings.signal invalid");
+    if (s.fileType != 1) return fail(ctx, BDS_ERR_UNSUPPORTED, "fileType 2 (interleaved I/Q) tracking input is not built yet");
+    if (s.codeLength != 10230 || !(s.samplingFreq > 0) || !(s.intTime > 0))
+        return fail(ctx, BDS_ERR_ARG, "settings.codeLength/samplingFreq/intTime invalid");
+    p.mode = track_mode(s);
+    p.pilot = pilot_on(s, p.mode);
+    p.code_len = s.codeLength;
+    p.n_epochs = n_epochs;
+    p.fs = s.samplingFreq;
+    p.inv_fs = 1.0 / s.samplingFreq;
+    p.spacing = s.dllCorrelatorSpacing;
+    bds_calc_loop_coef(s.dllNoiseBandwidth, s.dllDampingRatio, 1.0, &p.tau1, &p.tau2);  // tracking.m:110-112
+    bds_calc_loop_coef_carr(&s, &p.pf3, &p.pf2, &p.pf1);                                 // :116
+    p.pdi = s.intTime;                                                                   // :107
+    p.factor = p.mode == BDS_TRACK_WB ? bds_calc_weighing_factor(&s) : 0.0;              // WB_tracking.m:138
+    p.n_bytes = (long long)n_bytes;
+    return BDS_OK;
+}
+
+template <class F>
+static void for_each_field(bds_track_out *o, TrkOut *d, F f) {
+    f(o->absoluteSample, d->absoluteSample, 0.0);
+    f(o->codeFreq, d->codeFreq, INFINITY);
+    f(o->carrFreq, d->carrFreq, INFINITY);
+    f(o->I_P, d->I_P, 0.0);
+    f(o->I_E, d->I_E, 0.0);
+    f(o->I_L, d->I_L, 0.0);
+    f(o->Q_E, d->Q_E, 0.0);
+    f(o->Q_P, d->Q_P, 0.0);
+    f(o->Q_L, d->Q_L, 0.0);
+    f(o->Pilot_I_P, d->Pilot_I_P, 0.0);
+    f(o->Pilot_Q_P, d->Pilot_Q_P, 0.0);
+    f(o->Pilot_I_E, d->Pilot_I_E, 0.0);
+    f(o->Pilot_I_L, d->Pilot_I_L, 0.0);
+    f(o->Pilot_Q_E, d->Pilot_Q_E, 0.0);
+    f(o->Pilot_Q_L, d->Pilot_Q_L, 0.0);
+    f(o->dllDiscr, d->dllDiscr, INFINITY);
+    f(o->dllDiscrFilt, d->dllDiscrFilt, INFINITY);
+    f(o->pllDiscr, d->pllDiscr, INFINITY);
+    f(o->pllDiscrFilt, d->pllDiscrFilt, INFINITY);
+    f(o->remCodePhase, d->remCodePhase, INFINITY);
+    f(o->remCarrPhase, d->remCarrPhase, INFINITY);
+}
+
+// include/Calc_CNo_PLD.m (B1C :45-114, B2a :38-100) over prompt values [k-M, k)
+static void cno_pld_one(const double *I, const double *Q, int M, double T, double *lin, double *cno, double *pld) {
+    double zm = 0;
+    std::vector<double> z((size_t)M);
+    for (int i = 0; i < M; ++i) z[i] = I[i] * I[i] + Q[i] * Q[i], zm += z[i];
+    zm /= M;
+    double zv = 0;
+    for (int i = 0; i < M; ++i) zv += (z[i] - zm) * (z[i] - zm);
+    zv /= (M - 1);  // var(): N-1
+    const double pav = std::sqrt(zm * zm - zv);
+    const double nv = 0.5 * (zm - pav);
+    *lin = std::fabs((1 / T) * pav / (2 * nv));
+    *cno = 10 * std::log10(*lin);
+    double sp = 0, sn = 0, sq = 0;
+    for (int i = 0; i < M; ++i) {
+        if (I[i] > 0) sp += I[i];
+        if (I[i] < 0) sn += I[i];
+        sq += Q[i];
+    }
+    const double a = (sp - sn) * (sp - sn);
+    *pld = (a - sq * sq) / (a + sq * sq);
+}
+
+static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_bytes, size_t n_bytes, bool on_device,
+                    int n_ch, const bds_channel *channel, bds_track_out *out) {
+    if (!ctx || !s || !channel || !out) return BDS_ERR_ARG;
+    if (n_ch < 1 || out->n_ch != n_ch || out->n_epochs < 1) return fail(ctx, BDS_ERR_ARG, "bds_track: n_ch / n_epochs mismatch");
+    if (!out->completed || !out->status || !out->absoluteSample || !out->I_P || !out->Q_P)
+        return fail(ctx, BDS_ERR_ARG, "bds_track: required output arrays missing");
+    BDS_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->trk) ctx->trk = new TrackState();
+    TrackState &t = *ctx->trk;
+    TrkParams p{};
+    const int n_epochs = out->n_epochs;
+    int rc = fill_params(ctx, *s, p, n_epochs, n_bytes);
+    if (rc) return rc;
+    if ((rc = ensure_prim(ctx, t, s->signal))) return rc;
+    if (!on_device) {
+        if (t.data_cap < n_bytes) {
+            if (t.d_data) (void)hipFree(t.d_data), t.d_data = nullptr, t.data_cap = 0;
+            hipError_t e = hipMalloc((void **)&t.d_data, std::max<size_t>(n_bytes, 1));
+            if (e != hipSuccess) return fail(ctx, BDS_ERR_NOMEM, "IF record of %zu bytes does not fit in HBM: %s", n_bytes, hipGetErrorString(e));
+            t.data_cap = n_bytes;
+        }
+        BDS_HIP(ctx, hipMemcpyAsync(t.d_data, file_bytes, n_bytes, hipMemcpyHostToDevice, st(ctx)));
+    }
+    // channel state (tracking.m:170-188)
+    std::vector<ChanState> hs((size_t)n_ch);
+    const double max_step_inv = 0;
+    (void)max_step_inv;
+    double min_code_freq = 1e300;
+    for (int c = 0; c < n_ch; ++c) {
+        ChanState &cs = hs[c];
+        memset(&cs, 0, sizeof(cs));
+        cs.prn = channel[c].PRN;
+        out->completed[c] = 0;
+        out->status[c] = '-';
+        if (cs.prn == 0) continue;
+        if (cs.prn < 1 || cs.prn > BDS_MAX_PRN) return fail(ctx, BDS_ERR_ARG, "channel(%d).PRN = %d out of range", c + 1, cs.prn);
+        cs.active = 1;
+        cs.codeFreq = cs.codeFreqBasis = channel[c].codeFreq;
+        cs.carrFreq = cs.carrFreqBasis = channel[c].acquiredFreq;
+        cs.pos = (long long)s->skipNumberOfBytes + (long long)channel[c].codePhase - 1;  // fseek, :151-153
+        if (cs.pos < 0) return fail(ctx, BDS_ERR_ARG, "channel(%d): negative file offset", c + 1);
+        if (!(cs.codeFreq > 0)) return fail(ctx, BDS_ERR_ARG, "channel(%d).codeFreq must be > 0", c + 1);
+        min_code_freq = std::min(min_code_freq, cs.codeFreq);
+    }
+    // correlate grid: blksize stays near codeLength*fs/codeFreq; allow +-2 % code-rate excursions
+    long max_blk = (long)std::ceil((double)s->codeLength / ((min_code_freq < 1e299 ? min_code_freq : s->codeFreqBasis) * 0.98 / s->samplingFreq)) + 2;
+    const int nblocks = (int)((max_blk + kChunk - 1) / kChunk);
+    ChanState *d_st = nullptr;
+    double *d_part = nullptr;
+    BDS_HIP(ctx, hipMalloc((void **)&d_st, sizeof(ChanState) * n_ch));
+    BDS_HIP(ctx, hipMalloc((void **)&d_part, sizeof(double) * (size_t)n_ch * nblocks * kNSums));
+    BDS_HIP(ctx, hipMemcpyAsync(d_st, hs.data(), sizeof(ChanState) * n_ch, hipMemcpyHostToDevice, st(ctx)));
+    // device result arrays, initialised like the reference template (tracking.m:48-82)
+    const size_t ne = (size_t)n_ch * n_epochs;
+    TrkOut d{};
+    std::vector<double *> allocs;
+    std::vector<double> init(ne);
+    int err = BDS_OK;
+    for_each_field(out, &d, [&](double *host, double *&dev, double v0) {
+        if (err) return;
+        // arrays the variant does not create still need a device target when the kernel writes them
+        hipError_t e = hipMalloc((void **)&dev, sizeof(double) * ne);
+        if (e != hipSuccess) {
+            err = fail(ctx, BDS_ERR_NOMEM, "hipMalloc track output: %s", hipGetErrorString(e));
+            return;
+        }
+        allocs.push_back(dev);
+        std::fill(init.begin(), init.end(), v0);
+        (void)hipMemcpyAsync(dev, init.data(), sizeof(double) * ne, hipMemcpyHostToDevice, st(ctx));
+        (void)hipStreamSynchronize(st(ctx));
+        (void)host;
+    });
+    if (err) return err;
+
+    hipEvent_t ev0, ev1;
+    BDS_HIP(ctx, hipEventCreate(&ev0));
+    BDS_HIP(ctx, hipEventCreate(&ev1));
+    BDS_HIP(ctx, hipEventRecord(ev0, st(ctx)));
+    const int8_t *data = on_device ? file_bytes : t.d_data;
+    dim3 gc(nblocks, n_ch);
+    for (int k = 0; k < n_epochs; ++k) {
+        switch (p.mode) {
+            case BDS_TRACK_B2A:
+                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_B2A>, gc, dim3(kTrkThreads), 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
+                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_B2A>, dim3(n_ch), dim3(64), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
+                break;
+            case BDS_TRACK_NB:
+                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_NB>, gc, dim3(kTrkThreads), 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
+                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_NB>, dim3(n_ch), dim3(64), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
+                break;
+            default:
+                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_WB>, gc, dim3(kTrkThreads), 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
+                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_WB>, dim3(n_ch), dim3(64), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
+                break;
+        }
+    }
+    BDS_HIP(ctx, hipGetLastError());
+    BDS_HIP(ctx, hipEventRecord(ev1, st(ctx)));
+    BDS_HIP(ctx, hipMemcpyAsync(hs.data(), d_st, sizeof(ChanState) * n_ch, hipMemcpyDeviceToHost, st(ctx)));
+    BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+    float ms = 0;
+    BDS_HIP(ctx, hipEventElapsedTime(&ms, ev0, ev1));
+    memset(&ctx->timing, 0, sizeof(ctx->timing));
+    ctx->timing.total_ms = ms;
+    ctx->timing.n_pairs = n_epochs;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+
+    // The reference tracks channels one after another and returns at the first short read
+    // (tracking.m:250-254): that channel keeps its partial results, later ones are never started.
+    int first_abort = n_ch;
+    for (int c = 0; c < n_ch; ++c)
+        if (hs[c].prn != 0 && hs[c].completed < n_epochs) {
+            first_abort = c;
+            break;
+        }
+    for_each_field(out, &d, [&](double *host, double *&dev, double v0) {
+        if (!host) return;
+        (void)hipMemcpy(host, dev, sizeof(double) * ne, hipMemcpyDeviceToHost);
+        for (int c = first_abort + 1; c < n_ch; ++c)
+            std::fill(host + (size_t)c * n_epochs, host + (size_t)(c + 1) * n_epochs, v0);
+        // epochs after the abort stay at the template value (device never wrote them), except
+        // absoluteSample of the aborted epoch which the reference assigns before the read
+    });
+    for (int c = 0; c < n_ch; ++c) {
+        if (hs[c].prn == 0 || c > first_abort) {
+            out->completed[c] = 0;
+            continue;
+        }
+        out->completed[c] = hs[c].completed;
+        if (hs[c].completed == n_epochs) out->status[c] = channel[c].status;  // :441
+    }
+    // C/N0 + lock detector post-pass (tracking.m:411-434)
+    const int M = s->CNoInterval;
+    if (M > 1 && out->n_cno > 0 && out->DataCNo) {
+        const int pm = p.pilot ? (p.mode == BDS_TRACK_WB ? 2 : 1) : 0;
+        for (int c = 0; c < n_ch; ++c) {
+            for (int q = 0; q < out->n_cno; ++q) {
+                const size_t e = (size_t)c * out->n_cno + q;
+                out->DataCNo[e] = 0;
+                if (out->DataPLD) out->DataPLD[e] = 0;
+                if (out->PilotCNo) out->PilotCNo[e] = 0;
+                if (out->PilotPLD) out->PilotPLD[e] = 0;
+                if (out->SigCNo) out->SigCNo[e] = 0;
+            }
+            double prev[3] = {0, 0, 0};
+            for (int q = 0; q < out->n_cno && (q + 1) * M <= out->completed[c]; ++q) {
+                const size_t o0 = (size_t)c * n_epochs + (size_t)q * M, e = (size_t)c * out->n_cno + q;
+                double dlin, dcno, dpld, plin = 0, pcno = 0, ppld = 0;
+                cno_pld_one(out->I_P + o0, out->Q_P + o0, M, s->intTime, &dlin, &dcno, &dpld);
+                if (pm == 2 && out->Pilot_I_P && out->Pilot_Q_P)
+                    cno_pld_one(out->Pilot_I_P + o0, out->Pilot_Q_P + o0, M, s->intTime, &plin, &pcno, &ppld);
+                else if (pm == 1 && out->Pilot_I_P && out->Pilot_Q_P)  // I/Q swapped (Calc_CNo_PLD.m:84-87)
+                    cno_pld_one(out->Pilot_Q_P + o0, out->Pilot_I_P + o0, M, s->intTime, &plin, &pcno, &ppld);
+                const double c3 = 10 * std::log10(dlin + plin);
+                out->DataCNo[e] = dcno * 0.5 + prev[0] * 0.5;  // :420-421
+                if (out->DataPLD) out->DataPLD[e] = dpld;
+                if (pm) {
+                    if (out->PilotCNo) out->PilotCNo[e] = pcno * 0.5 + prev[1] * 0.5;
+                    if (out->SigCNo) out->SigCNo[e] = c3 * 0.5 + prev[2] * 0.5;
+                    if (out->PilotPLD) out->PilotPLD[e] = ppld;
+                }
+                prev[0] = dcno;
+                prev[1] = pcno;
+                prev[2] = c3;
+            }
+        }
+    }
+    for (double *a : allocs) (void)hipFree(a);
+    (void)hipFree(d_st);
+    (void)hipFree(d_part);
+    return BDS_OK;
+}
+
+}  // namespace bds
+
+using namespace bds;
+
+extern "C" int bds_track_mem(bds_ctx *ctx, const bds_settings *s, const int8_t *file_bytes, size_t n_bytes, int n_ch,
+                             const bds_channel *channel, bds_track_out *out) {
+    if (!file_bytes) return BDS_ERR_ARG;
+    return do_track(ctx, s, file_bytes, n_bytes, false, n_ch, channel, out);
+}
+
+extern "C" int bds_track(bds_ctx *ctx, const bds_settings *s, const char *path, int n_ch, const bds_channel *channel,
+                         bds_track_out *out) {
+    if (!ctx || !path) return BDS_ERR_ARG;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(ctx, BDS_ERR_IO, "Unable to read file %s", path);  // postProcessing.m:152-154
+    fseek(f, 0, SEEK_END);
+    const long long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz <= 0) {
+        fclose(f);
+        return fail(ctx, BDS_ERR_IO, "file %s is empty", path);
+    }
+    // stage through pinned memory in 256 MiB pieces straight into HBM
+    BDS_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->trk) ctx->trk = new TrackState();
+    TrackState &t = *ctx->trk;
+    if (t.data_cap < (size_t)sz) {
+        if (t.d_data) (void)hipFree(t.d_data), t.d_data = nullptr, t.data_cap = 0;
+        hipError_t e = hipMalloc((void **)&t.d_data, (size_t)sz);
+        if (e != hipSuccess) {
+            fclose(f);
+            return fail(ctx, BDS_ERR_NOMEM, "IF record of %lld bytes does not fit in HBM: %s", sz, hipGetErrorString(e));
+        }
+        t.data_cap = (size_t)sz;
+    }
+    const size_t piece = 256u << 20;
+    void *pin = nullptr;
+    if (hipHostMalloc(&pin, std::min<size_t>(piece, (size_t)sz), 0) != hipSuccess) {
+        fclose(f);
+        return fail(ctx, BDS_ERR_NOMEM, "pinned staging buffer");
+    }
+    size_t off = 0;
+    while (off < (size_t)sz) {
+        const size_t n = std::min(piece, (size_t)sz - off);
+        if (fread(pin, 1, n, f) != n) {
+            fclose(f);
+            (void)hipHostFree(pin);
+            return fail(ctx, BDS_ERR_IO, "short read on %s", path);
+        }
+        hipError_t e = hipMemcpy(t.d_data + off, pin, n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            fclose(f);
+            (void)hipHostFree(pin);
+            return fail(ctx, BDS_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+        }
+        off += n;
+    }
+    fclose(f);
+    (void)hipHostFree(pin);
+    return do_track(ctx, s, t.d_data, (size_t)sz, true, n_ch, channel, out);
+}
+
+extern "C" int bds_track_correlate(bds_ctx *ctx, const bds_settings *s, const int8_t *file_bytes, size_t n_bytes,
+                                   int n_ch, const int32_t *prn, const double *state6, double *sums18) {
+    if (!ctx || !s || !file_bytes || !prn || !state6 || !sums18 || n_ch < 1) return BDS_ERR_ARG;
+    BDS_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->trk) ctx->trk = new TrackState();
+    TrackState &t = *ctx->trk;
+    TrkParams p{};
+    int rc = fill_params(ctx, *s, p, 1, n_bytes);
+    if (rc) return rc;
+    if ((rc = ensure_prim(ctx, t, s->signal))) return rc;
+    long max_blk = 0;
+    for (int c = 0; c < n_ch; ++c) {
+        if (prn[c] < 1 || prn[c] > BDS_MAX_PRN) return fail(ctx, BDS_ERR_ARG, "prn[%d] out of range", c);
+        max_blk = std::max(max_blk, (long)state6[c * 6 + 1]);
+    }
+    const int nblocks = (int)std::max<long>(1, (max_blk + kChunk - 1) / kChunk);
+    int8_t *d_data = nullptr;
+    int *d_prn = nullptr;
+    double *d_s6 = nullptr, *d_part = nullptr, *d_sums = nullptr;
+    BDS_HIP(ctx, hipMalloc((void **)&d_data, std::max<size_t>(n_bytes, 1)));
+    BDS_HIP(ctx, hipMalloc((void **)&d_prn, sizeof(int) * n_ch));
+    BDS_HIP(ctx, hipMalloc((void **)&d_s6, sizeof(double) * 6 * n_ch));
+    BDS_HIP(ctx, hipMalloc((void **)&d_part, sizeof(double) * (size_t)n_ch * nblocks * kNSums));
+    BDS_HIP(ctx, hipMalloc((void **)&d_sums, sizeof(double) * (size_t)n_ch * kNSums));
+    BDS_HIP(ctx, hipMemcpyAsync(d_data, file_bytes, n_bytes, hipMemcpyHostToDevice, st(ctx)));
+    BDS_HIP(ctx, hipMemcpyAsync(d_prn, prn, sizeof(int) * n_ch, hipMemcpyHostToDevice, st(ctx)));
+    BDS_HIP(ctx, hipMemcpyAsync(d_s6, state6, sizeof(double) * 6 * n_ch, hipMemcpyHostToDevice, st(ctx)));
+    dim3 gc(nblocks, n_ch);
+    switch (p.mode) {
+        case BDS_TRACK_B2A:
+            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_B2A>, gc, dim3(kTrkThreads), 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
+            break;
+        case BDS_TRACK_NB:
+            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_NB>, gc, dim3(kTrkThreads), 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
+            break;
+        default:
+            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_WB>, gc, dim3(kTrkThreads), 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
+            break;
+    }
+    hipLaunchKernelGGL(k_trk_reduce_open, dim3(n_ch), dim3(64), 0, st(ctx), (const double *)d_part, nblocks, d_sums);
+    BDS_HIP(ctx, hipGetLastError());
+    BDS_HIP(ctx, hipMemcpyAsync(sums18, d_sums, sizeof(double) * (size_t)n_ch * kNSums, hipMemcpyDeviceToHost, st(ctx)));
+    BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+    for (void *q : {(void *)d_data, (void *)d_prn, (void *)d_s6, (void *)d_part, (void *)d_sums}) (void)hipFree(q);
+    return BDS_OK;
 }

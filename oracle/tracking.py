@@ -371,7 +371,14 @@ def tracking(fid: RawFile, channel, settings, mode=None, trace=None):
                 else:
                     r.Pilot_I_P[k - 1], r.Pilot_Q_P[k - 1] = pI_P, pQ_P
             if trace is not None:
-                trace.append(dict(ch=c, k=k, blk=blk))
+                # NCO state this epoch was correlated with + the raw correlator sums
+                # (order of include/bds_mi355x.h bds_track_correlate)
+                raw18 = [I_E, Q_E, I_P, Q_P, I_L, Q_L]
+                raw18 += [pI_E, pQ_E, pI_P, pQ_P, pI_L, pQ_L] if pilot else [0.0] * 6
+                raw18 += [sI_E, sQ_E, sI_P, sQ_P, sI_L, sQ_L] if (pilot and mode == "WB") else [0.0] * 6
+                trace.append(dict(ch=c, k=k, blk=blk, pos=r.absoluteSample[k - 1], rem=r.remCodePhase[k - 1],
+                                  codeFreq=r.codeFreq[k - 1], remCarr=r.remCarrPhase[k - 1],
+                                  carrFreq=r.carrFreq[k - 1], sums=np.array(raw18, dtype=np.float64)))
 
             if k % cno_int == 0:  # :411-433
                 sl = slice(k - cno_int, k)

@@ -34,3 +34,32 @@ def medium_b2a(prns=(5, 9, 19, 33)):
     sats = synth.random_sats(rng, [9, 19], spc, cn0_dbhz=46.0)
     x = synth.make_if(s, sats, 17 * spc, seed=6)
     return s, x, sats
+
+
+def track_case(signal, mode, n_epochs, seed=21):
+    """Synthetic record + channels for the tracking tests at a reduced sampling rate.
+
+    Returns (settings, file_bytes int8, channels) with channels filled the way preRun
+    would from a perfect acquisition (codePhase = first sample of a code period)."""
+    from types import SimpleNamespace
+
+    if signal == "B2A":
+        s = bds_amd.init_settings_b2a(samplingFreq=25e6, IF=6.5e6, msToProcess=n_epochs, numberOfChannels=3,
+                                      CNoInterval=20)
+        sat_list = [synth.Sat(9, -1230.0, 12345.6, 2.0, 50.0), synth.Sat(19, 2210.0, 3001.2, 0.4, 47.0),
+                    synth.Sat(33, 355.0, 20111.9, 1.3, 45.0)]
+    else:
+        flag = {"NB": 1, "WB": 2}[mode]
+        s = bds_amd.init_settings_b1c(samplingFreq=12.5e6, IF=3.5e6, msToProcess=n_epochs * 10, numberOfChannels=3,
+                                      pilotTRKflag=flag, CNoInterval=10, FEBW=10e6)
+        sat_list = [synth.Sat(3, 230.0, 40000.3, 1.0, 48.0), synth.Sat(12, -410.0, 99000.8, 2.0, 45.0),
+                    synth.Sat(27, 1800.0, 7000.5, 0.2, 46.0)]
+    spc = spc_of(s)
+    x = synth.make_if(s, sat_list, (n_epochs + 3) * spc, seed=seed)
+    chans = []
+    for sat in sat_list:
+        cf = s.IF + round(sat.doppler / 25) * 25
+        code_freq = (s.codeFreqBasis - (cf - s.IF) / s.carrFreqBasis * s.codeFreqBasis) if signal == "B1C" else s.codeFreqBasis
+        chans.append(SimpleNamespace(PRN=sat.prn, acquiredFreq=float(cf), codePhase=float(int(np.ceil(sat.delay)) + 1),
+                                     codeFreq=float(code_freq), status="T"))
+    return s, x, chans
