@@ -80,6 +80,8 @@ def tracking(fid, channel, settings, mode=None, device: int = 0):
     # by passing the flag the variant tests for
     if mode == "NB" and int(s.pilotTRKflag) == 2:
         s = settings.copy(pilotTRKflag=0)
+    if mode == "WB" and int(s.pilotTRKflag) != 2:  # WB_tracking.m:78 only tests == 2
+        s = settings.copy(pilotTRKflag=0)
     arr = ctx.track(s, source, channel, n, m, ep + cn)
     sig_name = "B2a_CNo" if mode == "B2A" else "B1C_CNo"
     out = []

@@ -1,0 +1,194 @@
+/*
+ * bds_mex.c -- MEX gateway: MATLAB <-> libbds_mi355x.so (C ABI of include/bds_mi355x.h).
+ *
+ * Build (on a machine that has MATLAB; this image has none, so the file is kept
+ * logic-free -- everything it calls is exercised through the same C ABI by the
+ * repo's ctypes layer and tests):
+ *
+ *   mex -R2018a -I../include bds_mex.c -L../bds-3-b1c-b2a-sdr-receiver_amd -lbds_mi355x \
+ *       LDFLAGS='$LDFLAGS -Wl,-rpath,/opt/rocm/lib'
+ *
+ * Usage from the drop-in wrappers in this directory:
+ *   [carrFreq, codePhase, peakMetric, detected] = bds_mex('acquire', int8(longSignal), settings, signal)
+ *   out = bds_mex('track', path, channel, settings, signal)        % struct of [nCh x nEpochs] arrays
+ *   code = bds_mex('gen_code', signal, kind, prn)
+ * signal: 1 = B1C, 2 = B2a (the reference keeps one directory per receiver).
+ */
+#include <string.h>
+
+#include "bds_mi355x.h"
+#include "mex.h"
+
+static bds_ctx *g_ctx = NULL;
+
+static void cleanup(void) {
+    if (g_ctx) bds_destroy(g_ctx);
+    g_ctx = NULL;
+}
+
+static bds_ctx *ctx(void) {
+    if (!g_ctx) {
+        g_ctx = bds_create(0);
+        if (!g_ctx) mexErrMsgIdAndTxt("bds:create", "%s", bds_last_error(NULL));
+        mexAtExit(cleanup);
+    }
+    return g_ctx;
+}
+
+static double field(const mxArray *s, const char *name, int required, double dflt) {
+    const mxArray *f = mxGetField(s, 0, name);
+    if (!f) {
+        if (required) mexErrMsgIdAndTxt("bds:settings", "settings.%s is missing", name);
+        return dflt;
+    }
+    return mxGetScalar(f);
+}
+
+static void pack_settings(const mxArray *s, int signal, bds_settings *o) {
+    const mxArray *lst;
+    memset(o, 0, sizeof(*o));
+    o->signal = signal;
+    o->fileType = (int)field(s, "fileType", 0, 1);
+    o->samplingFreq = field(s, "samplingFreq", 1, 0);
+    o->IF = field(s, "IF", 1, 0);
+    o->codeFreqBasis = field(s, "codeFreqBasis", 1, 0);
+    o->carrFreqBasis = field(s, "carrFreqBasis", 0, 0);
+    o->codeLength = (int)field(s, "codeLength", 1, 0);
+    o->numberOfChannels = (int)field(s, "numberOfChannels", 0, 0);
+    o->skipNumberOfBytes = (int64_t)field(s, "skipNumberOfBytes", 0, 0);
+    o->msToProcess = field(s, "msToProcess", 0, 0);
+    o->acqSearchBand = field(s, "acqSearchBand", 0, 0);
+    o->acqStep = field(s, "acqStep", 0, 1);
+    o->acqThreshold = field(s, "acqThreshold", 0, 0);
+    o->acqCohT = field(s, "acqCohT", 0, 10);
+    o->pilotACQflag = (int)field(s, "pilotACQflag", 0, 1);
+    o->fineNoncoh = (int)field(s, "fineNoncoh", 0, 15);
+    o->resamplingThreshold = field(s, "resamplingThreshold", 0, 0);
+    o->resamplingflag = (int)field(s, "resamplingflag", 0, 0);
+    lst = mxGetField(s, 0, "acqSatelliteList");
+    if (lst) {
+        size_t n = mxGetNumberOfElements(lst), i;
+        const double *p = mxGetDoubles(lst);
+        if (n > BDS_MAX_PRN) mexErrMsgIdAndTxt("bds:settings", "settings.acqSatelliteList longer than 63");
+        o->n_acq = (int)n;
+        for (i = 0; i < n; ++i) o->acqSatelliteList[i] = (int)p[i];
+    }
+    o->pilotTRKflag = (int)field(s, "pilotTRKflag", 0, 0);
+    o->intTime = field(s, "intTime", 0, 0.001);
+    o->dllCorrelatorSpacing = field(s, "dllCorrelatorSpacing", 0, 0.5);
+    o->dllDampingRatio = field(s, "dllDampingRatio", 0, 0.7);
+    o->dllNoiseBandwidth = field(s, "dllNoiseBandwidth", 0, 1);
+    o->pllNoiseBandwidth = field(s, "pllNoiseBandwidth", 0, 10);
+    o->CNoInterval = (int)field(s, "CNoInterval", 0, 50);
+    o->FEBW = field(s, "FEBW", 0, 0);
+}
+
+static void do_acquire(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+    bds_settings s;
+    int max_prn = 0, i, rc;
+    mxArray *det;
+    if (nrhs != 4 || !mxIsInt8(prhs[1])) mexErrMsgIdAndTxt("bds:args", "acquire: (int8 longSignal, settings, signal)");
+    pack_settings(prhs[2], (int)mxGetScalar(prhs[3]), &s);
+    for (i = 0; i < s.n_acq; ++i)
+        if (s.acqSatelliteList[i] > max_prn) max_prn = s.acqSatelliteList[i];
+    plhs[0] = mxCreateDoubleMatrix(1, max_prn, mxREAL);
+    plhs[1] = mxCreateDoubleMatrix(1, max_prn, mxREAL);
+    plhs[2] = mxCreateDoubleMatrix(1, max_prn, mxREAL);
+    det = mxCreateNumericMatrix(1, max_prn, mxINT32_CLASS, mxREAL);
+    rc = bds_acquire(ctx(), &s, (const int8_t *)mxGetInt8s(prhs[1]), mxGetNumberOfElements(prhs[1]), 0, max_prn,
+                     mxGetDoubles(plhs[0]), mxGetDoubles(plhs[1]), mxGetDoubles(plhs[2]), (int32_t *)mxGetInt32s(det));
+    if (rc) mexErrMsgIdAndTxt("bds:acquire", "%s", bds_last_error(g_ctx));
+    if (nlhs > 3)
+        plhs[3] = det;
+    else
+        mxDestroyArray(det);
+}
+
+static double *out_field(mxArray *st, const char *name, int rows, int cols) {
+    mxArray *a = mxCreateDoubleMatrix(rows, cols, mxREAL); /* column-major: [epoch x channel] */
+    mxAddField(st, name);
+    mxSetField(st, 0, name, a);
+    return mxGetDoubles(a);
+}
+
+static void do_track(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+    bds_settings s;
+    bds_track_out o;
+    bds_channel *ch;
+    char path[4096];
+    int n_ch, n_ep, n_cno, c, rc, wb, pilot;
+    mxArray *st, *comp, *stat;
+    (void)nlhs;
+    if (nrhs != 5) mexErrMsgIdAndTxt("bds:args", "track: (path, channel, settings, signal)");
+    mxGetString(prhs[1], path, sizeof(path));
+    pack_settings(prhs[3], (int)mxGetScalar(prhs[4]), &s);
+    n_ch = (int)mxGetNumberOfElements(prhs[2]);
+    ch = (bds_channel *)mxCalloc((size_t)n_ch, sizeof(bds_channel));
+    for (c = 0; c < n_ch; ++c) {
+        const mxArray *stc = mxGetField(prhs[2], c, "status");
+        ch[c].PRN = (int)mxGetScalar(mxGetField(prhs[2], c, "PRN"));
+        ch[c].acquiredFreq = mxGetScalar(mxGetField(prhs[2], c, "acquiredFreq"));
+        ch[c].codePhase = mxGetScalar(mxGetField(prhs[2], c, "codePhase"));
+        ch[c].codeFreq = mxGetScalar(mxGetField(prhs[2], c, "codeFreq"));
+        ch[c].status = stc ? (int)mxGetChars(stc)[0] : '-';
+    }
+    /* epochs: msToProcess (B2a/tracking.m:100) or round(msToProcess/1000/intTime) (WB_tracking.m:56) */
+    n_ep = s.signal == BDS_SIGNAL_B2A ? (int)s.msToProcess : (int)(s.msToProcess / 1000 / s.intTime + 0.5);
+    n_cno = n_ep / s.CNoInterval;
+    wb = s.signal == BDS_SIGNAL_B1C && s.pilotTRKflag == 2;
+    pilot = wb || s.pilotTRKflag == 1;
+    memset(&o, 0, sizeof(o));
+    o.n_ch = n_ch;
+    o.n_epochs = n_ep;
+    o.n_cno = n_cno;
+    st = mxCreateStructMatrix(1, 1, 0, NULL);
+#define F(name) o.name = out_field(st, #name, n_ep, n_ch)
+    F(absoluteSample); F(codeFreq); F(carrFreq); F(I_P); F(I_E); F(I_L); F(Q_E); F(Q_P); F(Q_L);
+    if (pilot) { F(Pilot_I_P); F(Pilot_Q_P); }
+    if (wb) { F(Pilot_I_E); F(Pilot_I_L); F(Pilot_Q_E); F(Pilot_Q_L); }
+    F(dllDiscr); F(dllDiscrFilt); F(pllDiscr); F(pllDiscrFilt); F(remCodePhase); F(remCarrPhase);
+#undef F
+#define G(name) o.name = out_field(st, #name, n_cno, n_ch)
+    G(DataCNo); G(DataPLD);
+    if (pilot) { G(PilotCNo); G(PilotPLD); G(SigCNo); }
+#undef G
+    comp = mxCreateNumericMatrix(1, n_ch, mxINT32_CLASS, mxREAL);
+    stat = mxCreateNumericMatrix(1, n_ch, mxINT32_CLASS, mxREAL);
+    o.completed = (int32_t *)mxGetInt32s(comp);
+    o.status = (int32_t *)mxGetInt32s(stat);
+    mxAddField(st, "completed");
+    mxSetField(st, 0, "completed", comp);
+    mxAddField(st, "status");
+    mxSetField(st, 0, "status", stat);
+    /* the C arrays are channel-major [n_ch][n_epochs] == MATLAB column-major [n_epochs x n_ch] */
+    rc = bds_track(ctx(), &s, path, n_ch, ch, &o);
+    mxFree(ch);
+    if (rc) mexErrMsgIdAndTxt("bds:track", "%s", bds_last_error(g_ctx));
+    plhs[0] = st;
+}
+
+static void do_gen_code(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+    int8_t buf[122760];
+    int n, i;
+    double *p;
+    (void)nlhs;
+    if (nrhs != 4) mexErrMsgIdAndTxt("bds:args", "gen_code: (signal, kind, prn)");
+    n = bds_gen_code((int)mxGetScalar(prhs[1]), (int)mxGetScalar(prhs[2]), (int)mxGetScalar(prhs[3]), buf, 122760);
+    if (n < 0) mexErrMsgIdAndTxt("bds:gen_code", "bad signal/kind/prn");
+    plhs[0] = mxCreateDoubleMatrix(1, n, mxREAL);
+    p = mxGetDoubles(plhs[0]);
+    for (i = 0; i < n; ++i) p[i] = buf[i];
+}
+
+void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+    char cmd[32];
+    if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof(cmd))) mexErrMsgIdAndTxt("bds:args", "first argument: command string");
+    if (!strcmp(cmd, "acquire"))
+        do_acquire(nlhs, plhs, nrhs, prhs);
+    else if (!strcmp(cmd, "track"))
+        do_track(nlhs, plhs, nrhs, prhs);
+    else if (!strcmp(cmd, "gen_code"))
+        do_gen_code(nlhs, plhs, nrhs, prhs);
+    else
+        mexErrMsgIdAndTxt("bds:args", "unknown command %s", cmd);
+}
