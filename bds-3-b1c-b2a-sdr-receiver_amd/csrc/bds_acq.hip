@@ -29,7 +29,7 @@
 #include <set>
 #include <tuple>
 
-#include "bds_acq_kernels.h"
+#include "bds_acq_fast.h"
 #include "bds_internal.h"
 
 namespace bds {
@@ -44,6 +44,7 @@ struct Plan2D {
     TwiddleL twl{};
     int logT = 0, Spad = 0, nt_cols = 0, nt_rows = 0, ntiles = 0;
     size_t lds_cols = 0, lds_rows = 0;
+    bool fast = false;  // both lengths have compile-time specialised search kernels (bds_acq_fast.h)
     float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_hi = nullptr, *d_lo = nullptr;
 };
 
@@ -101,6 +102,9 @@ static double plan_cost(int S) {
     return c;
 }
 
+static bool fast_cols(int a) { return a == 256 || a == 512 || a == 768 || a == 1024; }
+static bool fast_rows(int b) { return b == 1280 || b == 2048 || b == 3072 || b == 4096; }
+
 // Padded length L >= need (5-smooth) and its split L1 x L2, chosen by a cost model:
 // L * (stage costs of both passes + a memory term) -- a slightly longer transform made of
 // radix-16 stages beats the tightest 5-smooth length made of 3s and 5s.
@@ -124,7 +128,8 @@ static bool choose_lengths(long need, long &L, int &L1, int &L2) {
             if (cand % a) continue;
             const long b = cand / a;
             if (b > kMaxRowLen || b < a / 4) continue;
-            const double c = (double)cand * (plan_cost(a) + plan_cost((int)b) + kMem);
+            double c = (double)cand * (plan_cost(a) + plan_cost((int)b) + kMem);
+            if (fast_cols(a) && fast_rows((int)b)) c *= 0.6;  // specialised kernels exist
             if (c < best) best = c, L = cand, L1 = a, L2 = (int)b;
         }
     }
@@ -170,6 +175,9 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
     int logT = 5;
     while (logT > 0 && ((long)pl.L1 << logT) > kColPoints) --logT;
     while (logT > 0 && (1 << logT) > pl.L2) --logT;
+    if (const char *e = std::getenv("BDS_ACQ_LOGT")) logT = std::max(0, std::min(logT, atoi(e)));  // tuning
+    const bool want_fast = fast_cols(pl.L1) && fast_rows(pl.L2) && !std::getenv("BDS_ACQ_GENERIC");
+    if (want_fast) logT = 3;  // the specialised column kernel is built for T = 8
     pl.logT = logT;
     pl.Spad = lds_span(pl.L1) + 4;  // +4: successive columns start 8 dwords apart in the bank row
     pl.ntiles = (pl.L2 + (1 << logT) - 1) >> logT;
@@ -179,7 +187,9 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
         return fail(ctx, BDS_ERR_UNSUPPORTED, "transform %d x %d exceeds the per-workgroup budget", pl.L1, pl.L2);
     pl.lds_cols = sizeof(float2) * (size_t)pl.Spad * (size_t)(1 << logT);
     pl.lds_rows = sizeof(float2) * (size_t)lds_span(pl.L2);
+    pl.fast = fast_cols(pl.L1) && fast_rows(pl.L2) && logT == 3 && !std::getenv("BDS_ACQ_GENERIC");
     if (std::getenv("BDS_VERBOSE")) {
+        fprintf(stderr, "[bds] search kernels: %s\n", pl.fast ? "specialised" : "generic");
         fprintf(stderr, "[bds] plan: need %ld -> L %ld = %d (cols:", need, pl.L, pl.L1);
         for (int i = 0; i < pl.p1.nstage; ++i) fprintf(stderr, " %d", pl.p1.radix[i]);
         fprintf(stderr, "; T=%d, %d thr, %zu B LDS) x %d (rows:", 1 << logT, pl.nt_cols, pl.lds_cols, pl.L2);
@@ -311,7 +321,9 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
                       a.cohT == s.acqCohT && a.pilotACQ == s.pilotACQflag && a.code_len == s.codeLength &&
                       a.plan.L > 0;
     if (same) return BDS_OK;
-    a.cs_slot.clear();
+    a.cs_slot.clear();  // the spectra cache is keyed by everything above: drop it (slot size depends on L)
+    if (a.d_Cs) (void)hipFree(a.d_Cs), a.d_Cs = nullptr;
+    a.cs_cap_slots = 0;
     a.signal = s.signal;
     a.fs = s.samplingFreq;
     a.cfb = s.codeFreqBasis;
@@ -370,6 +382,41 @@ static int forward(bds_ctx *ctx, AcqState &a, Loader ld, int nb, float2 *dst, lo
                        pl.L, dst, dst_stride, conj_flag, scale);
     BDS_HIP(ctx, hipGetLastError());
     return BDS_OK;
+}
+
+// ---- specialised search kernels: dispatch on the compile-time lengths ------------------------
+template <int S, int NC>
+static void launch_rows_t(bds_ctx *ctx, const Plan2D &pl, const float2 *Xs, int G, int bin0, const float2 *Cs, float2 *Bw) {
+    static bool attr = false;
+    const size_t lds = sizeof(float2) * tspan<S>();
+    if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_inv_t<S, NC, float2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    hipLaunchKernelGGL((k_rows_inv_t<S, NC, float2>), dim3(pl.L1 * G), dim3(rows_threads<S>()), lds, (hipStream_t)ctx->stream,
+                       (const float2 *)pl.d_tw2, pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, 1.0f);
+}
+template <int S, int NC>
+static void launch_cols_t(bds_ctx *ctx, const Plan2D &pl, int G, const float2 *Bw, float w0, float w1, int lo1, int hi1,
+                          int lo2, int hi2, Rec *recs) {
+    static bool attr = false;
+    const size_t lds = sizeof(float2) * kFastT * tspan<S>();
+    if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_t<S, NC, float2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    hipLaunchKernelGGL((k_cols_inv_max_t<S, NC, float2>), dim3(pl.ntiles, G), dim3(cols_threads<S>()), lds, (hipStream_t)ctx->stream,
+                       (const float2 *)pl.d_tw1, pl.L2, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
+}
+template <int NC>
+static void launch_fast(bds_ctx *ctx, const Plan2D &pl, const float2 *Xs, int G, int bin0, const float2 *Cs, float2 *Bw,
+                        float w0, float w1, int lo1, int hi1, int lo2, int hi2, Rec *recs) {
+    switch (pl.L2) {
+        case 1280: launch_rows_t<1280, NC>(ctx, pl, Xs, G, bin0, Cs, Bw); break;
+        case 2048: launch_rows_t<2048, NC>(ctx, pl, Xs, G, bin0, Cs, Bw); break;
+        case 3072: launch_rows_t<3072, NC>(ctx, pl, Xs, G, bin0, Cs, Bw); break;
+        default: launch_rows_t<4096, NC>(ctx, pl, Xs, G, bin0, Cs, Bw); break;
+    }
+    switch (pl.L1) {
+        case 256: launch_cols_t<256, NC>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        case 512: launch_cols_t<512, NC>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        case 768: launch_cols_t<768, NC>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        default: launch_cols_t<1024, NC>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+    }
 }
 
 static size_t bw_batches(const AcqState &a) { return (size_t)std::max(a.group * a.ncomp, 8); }
@@ -563,7 +610,12 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     auto launch_cells = [&](int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2) {
         const float2 *Cs = a.d_Cs + (size_t)a.cs_slot[prn] * ncomp * pl.L;
         dim3 gr(pl.L1, nb), gc(pl.ntiles, nb);
-        if (ncomp == 2) {
+        if (pl.fast) {
+            if (ncomp == 2)
+                launch_fast<2>(ctx, pl, a.d_Xs, nb, b0, Cs, a.d_Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
+            else
+                launch_fast<1>(ctx, pl, a.d_Xs, nb, b0, Cs, a.d_Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
+        } else if (ncomp == 2) {
             hipLaunchKernelGGL(k_rows_inv<2>, gr, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, pl.twl,
                                (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
             hipLaunchKernelGGL(k_cols_inv_max<2>, gc, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.L2, pl.logT,

@@ -1,0 +1,128 @@
+// Compile-time specialised LDS transform stages for the hot plans (gfx950).
+//
+// Same algorithm and LDS layout as the run-time engine in bds_fft.h (mixed-radix Stockham
+// autosort, logical element i at physical i + (i >> 4)), but the transform length S, the
+// batch T, the workgroup size NT and the radix list are template parameters: butterfly ->
+// thread assignment, LDS strides and the autosort scatter all become immediates (the generic
+// engine spends ~3/4 of its instructions on that index arithmetic, not on the butterflies).
+// Requirements, checked with static_assert: the first radix is 16 and S/R is a multiple of 16
+// for every stage, i.e. S = 256*m; later stages then have NS a multiple of 16 and both the
+// gather and the scatter of a butterfly are "base + q * constant".
+#pragma once
+
+#include "bds_fft.h"
+
+namespace bds {
+
+template <int S>
+__host__ __device__ constexpr int tspan() { return lds_span(S) + 4; }  // per-transform LDS stride (elements)
+
+template <int S, int T, int NT, int DIR, int NS, int R>
+__device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *__restrict__ tw, int tid) {
+    constexpr int NB = S / R;
+    constexpr int TOTAL = NB * T;
+    constexpr int MB = (TOTAL + NT - 1) / NT;
+    constexpr bool FULL = (TOTAL % NT) == 0;
+    constexpr int SP = tspan<S>();
+    constexpr int RSTR = NB + NB / 16;  // physical stride between the R inputs of a butterfly
+    constexpr int WSTR = NS + NS / 16;  // physical stride between its outputs (NS >= 16)
+    constexpr int TWS = S / (NS * R);   // stride into the W_S table
+    static_assert(NB % 16 == 0, "S/R must be a multiple of 16");
+    static_assert(NS == 1 || NS % 16 == 0, "later stages need NS % 16 == 0");
+    static_assert(NS > 1 || R == 16, "the first stage must be radix 16");
+    float2 v[MB][R];
+    int wofs[MB], kidx[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int b = tid + i * NT;
+        if (FULL || b < TOTAL) {
+            const int j = b / NB, bb = b - j * NB;
+            const float2 *src = buf + j * SP + bb + (bb >> 4);
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[i][q] = src[q * RSTR];
+            if (NS == 1) {
+                wofs[i] = j * SP + bb * 17;  // phys(16*bb + q) = 17*bb + q
+                kidx[i] = 0;
+            } else {
+                const int hi = bb / NS, k = bb - hi * NS;
+                const int j0 = hi * (NS * R) + k;
+                wofs[i] = j * SP + j0 + (j0 >> 4);
+                kidx[i] = k;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int b = tid + i * NT;
+        if (FULL || b < TOTAL) {
+            if (NS > 1) {
+                const int kt = kidx[i] * TWS;
+                if constexpr (R == 16 || R == 8) {
+                    float2 w[R];
+                    w[1] = tw[kt];
+                    w[2] = tw[2 * kt];
+                    w[4] = tw[4 * kt];
+                    if constexpr (R == 16) w[8] = tw[8 * kt];
+                    if (DIR > 0) {
+                        w[1].y = -w[1].y;
+                        w[2].y = -w[2].y;
+                        w[4].y = -w[4].y;
+                        if constexpr (R == 16) w[8].y = -w[8].y;
+                    }
+                    w[3] = cmul(w[1], w[2]);
+                    w[5] = cmul(w[1], w[4]);
+                    w[6] = cmul(w[2], w[4]);
+                    w[7] = cmul(w[3], w[4]);
+                    if constexpr (R == 16) {
+#pragma unroll
+                        for (int q = 1; q < 8; ++q) w[8 + q] = cmul(w[q], w[8]);
+                    }
+#pragma unroll
+                    for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], w[q]);
+                } else {
+#pragma unroll
+                    for (int q = 1; q < R; ++q) {
+                        float2 w = tw[q * kt];
+                        if (DIR > 0) w.y = -w.y;
+                        v[i][q] = cmul(v[i][q], w);
+                    }
+                }
+            }
+            Butterfly<R, DIR>::run(v[i]);
+            float2 *dst = buf + wofs[i];
+#pragma unroll
+            for (int q = 0; q < R; ++q) dst[NS == 1 ? q : q * WSTR] = v[i][q];
+        }
+    }
+    __syncthreads();
+}
+
+template <int S, int T, int NT, int DIR, int NS, int R, int... REST>
+__device__ __forceinline__ void tfft_run(float2 *__restrict__ buf, const float2 *__restrict__ tw, int tid) {
+    tstage<S, T, NT, DIR, NS, R>(buf, tw, tid);
+    if constexpr (sizeof...(REST) > 0) tfft_run<S, T, NT, DIR, NS * R, REST...>(buf, tw, tid);
+}
+
+// Radix lists of the supported lengths (must equal factor_radices() on the host: 16s first).
+template <int S>
+struct TPlan;
+#define BDS_TPLAN(S_, ...)                                                                         \
+    template <>                                                                                    \
+    struct TPlan<S_> {                                                                             \
+        template <int T, int NT, int DIR>                                                          \
+        __device__ __forceinline__ static void run(float2 *buf, const float2 *tw, int tid) {       \
+            tfft_run<S_, T, NT, DIR, 1, __VA_ARGS__>(buf, tw, tid);                                \
+        }                                                                                          \
+    };
+BDS_TPLAN(256, 16, 16)
+BDS_TPLAN(512, 16, 16, 2)
+BDS_TPLAN(768, 16, 16, 3)
+BDS_TPLAN(1024, 16, 16, 4)
+BDS_TPLAN(1280, 16, 16, 5)
+BDS_TPLAN(2048, 16, 16, 8)
+BDS_TPLAN(3072, 16, 16, 4, 3)
+BDS_TPLAN(4096, 16, 16, 16)
+#undef BDS_TPLAN
+
+}  // namespace bds
