@@ -254,6 +254,10 @@ struct AcqState {
     std::vector<int> h_rowarg;
     std::map<int, PrnResult> last;
     int group = 4;
+    bool half = false;         // spectra + inter-pass buffer stored as fp16 complex (specialised plans only)
+    double sum_abs_ext = 0;    // sum |x| over the periodically extended block: bound of |X[k]|
+    double sum_sq_ext = 0;     // sum x^2 over it: X_rms^2 (Parseval)
+    float sX = 1.f, sC = 1.f, sB = 1.f;  // power-of-two storage scales
 };
 
 void acq_state_free(AcqState *a) {
@@ -337,6 +341,10 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
     a.ncomp = ncomp;
     if ((rc = plan_build(ctx, a.plan, a.n_ext))) return rc;
     if (const char *g = std::getenv("BDS_ACQ_GROUP")) a.group = std::max(1, std::min(64, atoi(g)));
+    a.half = a.plan.fast;
+    if (const char *h = std::getenv("BDS_ACQ_FP16")) a.half = a.plan.fast && atoi(h) != 0;
+    // code spectrum: |fft(code)| <= X; stored value conj(C)/L * sC, kept below 2^15
+    a.sC = a.half ? (float)std::exp2(std::floor(std::log2(32768.0 * (double)a.plan.L / (double)a.X))) : 1.f;
     // primary codes of every PRN, both components
     if (!a.d_prim) BDS_HIP(ctx, hipMalloc((void **)&a.d_prim, (size_t)BDS_MAX_PRN * 2 * 10230));
     std::vector<int8_t> prim((size_t)BDS_MAX_PRN * 2 * 10230);
@@ -362,6 +370,7 @@ static int set_lds_limits(bds_ctx *ctx) {
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_fwd<SignalLoader>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_fwd<CodeLoader>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_fwd_st<__half2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_inv<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_inv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_inv_max<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
@@ -378,44 +387,49 @@ static int forward(bds_ctx *ctx, AcqState &a, Loader ld, int nb, float2 *dst, lo
     dim3 g1(pl.ntiles, nb), g2(pl.L1, nb);
     hipLaunchKernelGGL(k_cols_fwd<Loader>, g1, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.twl, pl.L2,
                        pl.logT, pl.Spad, ld, a.d_Bw, pl.L);
-    hipLaunchKernelGGL(k_rows_fwd, g2, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, (const float2 *)a.d_Bw,
-                       pl.L, dst, dst_stride, conj_flag, scale);
+    if (a.half)  // dst counts in stored elements (fp16 complex)
+        hipLaunchKernelGGL(k_rows_fwd_st<__half2>, g2, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2,
+                           (const float2 *)a.d_Bw, pl.L, (__half2 *)dst, dst_stride, conj_flag, scale);
+    else
+        hipLaunchKernelGGL(k_rows_fwd, g2, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, (const float2 *)a.d_Bw,
+                           pl.L, dst, dst_stride, conj_flag, scale);
     BDS_HIP(ctx, hipGetLastError());
     return BDS_OK;
 }
 
 // ---- specialised search kernels: dispatch on the compile-time lengths ------------------------
-template <int S, int NC>
-static void launch_rows_t(bds_ctx *ctx, const Plan2D &pl, const float2 *Xs, int G, int bin0, const float2 *Cs, float2 *Bw) {
+template <int S, int NC, class ST>
+static void launch_rows_t(bds_ctx *ctx, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
+                          float out_scale) {
     static bool attr = false;
     const size_t lds = sizeof(float2) * tspan<S>();
-    if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_inv_t<S, NC, float2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
-    hipLaunchKernelGGL((k_rows_inv_t<S, NC, float2>), dim3(pl.L1 * G), dim3(rows_threads<S>()), lds, (hipStream_t)ctx->stream,
-                       (const float2 *)pl.d_tw2, pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, 1.0f);
+    if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_inv_t<S, NC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    hipLaunchKernelGGL((k_rows_inv_t<S, NC, ST>), dim3(pl.L1 * G), dim3(rows_threads<S>()), lds, (hipStream_t)ctx->stream,
+                       (const float2 *)pl.d_tw2, pl.twl, (const ST *)Xs, pl.L, pl.L1, G, bin0, (const ST *)Cs, (ST *)Bw, out_scale);
 }
-template <int S, int NC>
-static void launch_cols_t(bds_ctx *ctx, const Plan2D &pl, int G, const float2 *Bw, float w0, float w1, int lo1, int hi1,
+template <int S, int NC, class ST>
+static void launch_cols_t(bds_ctx *ctx, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
                           int lo2, int hi2, Rec *recs) {
     static bool attr = false;
     const size_t lds = sizeof(float2) * kFastT * tspan<S>();
-    if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_t<S, NC, float2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
-    hipLaunchKernelGGL((k_cols_inv_max_t<S, NC, float2>), dim3(pl.ntiles, G), dim3(cols_threads<S>()), lds, (hipStream_t)ctx->stream,
-                       (const float2 *)pl.d_tw1, pl.L2, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
+    if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_t<S, NC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    hipLaunchKernelGGL((k_cols_inv_max_t<S, NC, ST>), dim3(pl.ntiles, G), dim3(cols_threads<S>()), lds, (hipStream_t)ctx->stream,
+                       (const float2 *)pl.d_tw1, pl.L2, (const ST *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
 }
-template <int NC>
-static void launch_fast(bds_ctx *ctx, const Plan2D &pl, const float2 *Xs, int G, int bin0, const float2 *Cs, float2 *Bw,
-                        float w0, float w1, int lo1, int hi1, int lo2, int hi2, Rec *recs) {
+template <int NC, class ST>
+static void launch_fast(bds_ctx *ctx, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
+                        float out_scale, float w0, float w1, int lo1, int hi1, int lo2, int hi2, Rec *recs) {
     switch (pl.L2) {
-        case 1280: launch_rows_t<1280, NC>(ctx, pl, Xs, G, bin0, Cs, Bw); break;
-        case 2048: launch_rows_t<2048, NC>(ctx, pl, Xs, G, bin0, Cs, Bw); break;
-        case 3072: launch_rows_t<3072, NC>(ctx, pl, Xs, G, bin0, Cs, Bw); break;
-        default: launch_rows_t<4096, NC>(ctx, pl, Xs, G, bin0, Cs, Bw); break;
+        case 1280: launch_rows_t<1280, NC, ST>(ctx, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
+        case 2048: launch_rows_t<2048, NC, ST>(ctx, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
+        case 3072: launch_rows_t<3072, NC, ST>(ctx, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
+        default: launch_rows_t<4096, NC, ST>(ctx, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
     }
     switch (pl.L1) {
-        case 256: launch_cols_t<256, NC>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        case 512: launch_cols_t<512, NC>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        case 768: launch_cols_t<768, NC>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        default: launch_cols_t<1024, NC>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        case 256: launch_cols_t<256, NC, ST>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        case 512: launch_cols_t<512, NC, ST>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        case 768: launch_cols_t<768, NC, ST>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        default: launch_cols_t<1024, NC, ST>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
     }
 }
 
@@ -445,6 +459,12 @@ extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s, const int8_t *s
     a.h_prefix[0] = 0;
     for (size_t i = 0; i < n_samples; ++i) a.h_prefix[i + 1] = a.h_prefix[i] + samples[i];
     a.n_samples = (long)n_samples;
+    a.sum_abs_ext = a.sum_sq_ext = 0;
+    for (long i = 0; i < a.n_ext; ++i) {
+        const double v = (double)samples[i < a.N ? i : i - a.N];
+        a.sum_abs_ext += std::fabs(v);
+        a.sum_sq_ext += v * v;
+    }
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
     return BDS_OK;
 }
@@ -482,8 +502,10 @@ extern "C" int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s) {
         CodeLoader ld{a.tab, (prn - 1) * 2};
         // components of one PRN are adjacent code slots: batch index = component
         (void)chunk;
-        if ((rc = forward(ctx, a, ld, a.ncomp, a.d_Cs + (size_t)slot * a.ncomp * pl.L, pl.L, 1, (float)(1.0 / (double)pl.L))))
-            return rc;
+        // half storage: the same byte buffer holds 4-byte elements, so offsets count in those
+        float2 *cs_dst = a.half ? (float2 *)((__half2 *)a.d_Cs + (size_t)slot * a.ncomp * pl.L)
+                                : a.d_Cs + (size_t)slot * a.ncomp * pl.L;
+        if ((rc = forward(ctx, a, ld, a.ncomp, cs_dst, pl.L, 1, (float)((double)a.sC / (double)pl.L)))) return rc;
         a.cs_slot[prn] = slot;
     }
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
@@ -587,13 +609,24 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     }
     BDS_HIP(ctx, hipEventRecord(ev0, st(ctx)));
 
+    // ---- storage scales (fp16 mode): powers of two from exact sums of the block ----------
+    a.sX = a.sB = 1.f;
+    if (a.half) {
+        // |X[k]| <= sum|x|  -> keep the stored spectrum below 2^15
+        a.sX = (float)std::exp2(std::floor(std::log2(32768.0 / std::max(1.0, a.sum_abs_ext))));
+        // inter-pass values: rms = X_rms * C_rms / L * sqrt(L2) (Parseval); allow 64 x rms
+        const double b_rms = std::sqrt(a.sum_sq_ext) * std::sqrt((double)a.X) / (double)pl.L * std::sqrt((double)pl.L2);
+        a.sB = (float)std::exp2(std::floor(std::log2(32768.0 / (64.0 * std::max(1e-30, b_rms) * a.sX * a.sC))));
+    }
+
     // ---- forward transforms, once per Doppler bin -------------------------------------
     {
         const int chunk = (int)bw_batches(a);
         for (int b0 = 0; b0 < D; b0 += chunk) {
             const int nb = std::min(chunk, D - b0);
             SignalLoader ld{a.d_sig, a.N, a.n_ext, f0, s->acqStep, 1.0 / a.fs, b0};
-            if ((rc = forward(ctx, a, ld, nb, a.d_Xs + (size_t)b0 * pl.L, pl.L, 0, 1.0f))) return rc;
+            float2 *xs_dst = a.half ? (float2 *)((__half2 *)a.d_Xs + (size_t)b0 * pl.L) : a.d_Xs + (size_t)b0 * pl.L;
+            if ((rc = forward(ctx, a, ld, nb, xs_dst, pl.L, 0, a.sX))) return rc;
         }
     }
     BDS_HIP(ctx, hipEventRecord(ev1, st(ctx)));
@@ -604,17 +637,28 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
         w0 = (float)(std::sqrt(11.0) / std::sqrt(40.0));
         w1 = (float)(std::sqrt(29.0) / std::sqrt(40.0));
     }
+    {   // undo the storage scales in the final magnitude weights
+        const float inv = 1.0f / (a.sX * a.sC * a.sB);
+        w0 *= inv;
+        w1 *= inv;
+    }
     const long n_pairs_total = (long)P * ((D + G - 1) / G);
     const long sample_every = std::max<long>(1, n_pairs_total / kSamples);
     long pair_idx = 0;
     auto launch_cells = [&](int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2) {
         const float2 *Cs = a.d_Cs + (size_t)a.cs_slot[prn] * ncomp * pl.L;
         dim3 gr(pl.L1, nb), gc(pl.ntiles, nb);
-        if (pl.fast) {
+        if (pl.fast && a.half) {
+            const void *Ch = (const __half2 *)a.d_Cs + (size_t)a.cs_slot[prn] * ncomp * pl.L;
             if (ncomp == 2)
-                launch_fast<2>(ctx, pl, a.d_Xs, nb, b0, Cs, a.d_Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
+                launch_fast<2, __half2>(ctx, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, recs);
             else
-                launch_fast<1>(ctx, pl, a.d_Xs, nb, b0, Cs, a.d_Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
+                launch_fast<1, __half2>(ctx, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, recs);
+        } else if (pl.fast) {
+            if (ncomp == 2)
+                launch_fast<2, float2>(ctx, pl, a.d_Xs, nb, b0, Cs, a.d_Bw, 1.0f, w0, w1, lo1, hi1, lo2, hi2, recs);
+            else
+                launch_fast<1, float2>(ctx, pl, a.d_Xs, nb, b0, Cs, a.d_Bw, 1.0f, w0, w1, lo1, hi1, lo2, hi2, recs);
         } else if (ncomp == 2) {
             hipLaunchKernelGGL(k_rows_inv<2>, gr, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, pl.twl,
                                (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
@@ -649,9 +693,24 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
     a.run_prns = prns;
     a.last.clear();
+    if (a.half) {
+        bool bad = false;
+        for (float v : a.h_rowmax) bad = bad || !std::isfinite(v);
+        if (bad) {  // an fp16 value overflowed: redo the whole search with fp32 storage
+            a.half = false;
+            a.sC = 1.f;
+            a.cs_slot.clear();
+            setenv("BDS_ACQ_FP16", "0", 1);
+            for (hipEvent_t e : {ev0, ev1, ev2, ev3}) (void)hipEventDestroy(e);
+            for (int i = 0; i < kSamples; ++i) (void)hipEventDestroy(sa[i]), (void)hipEventDestroy(sb[i]);
+            if ((rc = bds_acq_prepare(ctx, s))) return rc;
+            return bds_acq_run(ctx, s, prn_list, n_prn, max_prn, carrFreq, codePhase, peakMetric, detected);
+        }
+    }
 
     // ---- f64 refinement of the sieve's candidates ---------------------------------------
-    const double kDelta = 2e-5;
+    // sieve tolerance: fp32 storage errs by ~1e-7 of the output RMS, fp16 storage by ~3e-4
+    const double kDelta = a.half ? 2e-3 : 2e-5;
     auto bin_freq = [&](int b) { return f0 + s->acqStep * (double)b; };
     std::vector<std::vector<Cell>> cells(P);
     std::vector<CorrJob> jobs;
@@ -896,6 +955,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     t.n_bins = D;
     t.n_prn = P;
     t.n_comp = ncomp;
+    t.half_storage = a.half ? 1 : 0;  // storage of the spectra / inter-pass buffer: 1 = fp16 complex
     for (hipEvent_t e : {ev0, ev1, ev2, ev3}) (void)hipEventDestroy(e);
     for (int i = 0; i < kSamples; ++i) (void)hipEventDestroy(sa[i]), (void)hipEventDestroy(sb[i]);
     return BDS_OK;

@@ -27,6 +27,28 @@ template <int S>
 __host__ __device__ constexpr int cols_threads() { return S / 2; }  // T = 8 columns, 16 points per thread
 constexpr int kFastT = 8;
 
+// ---- forward row pass with a typed store (k_rows_fwd of bds_acq_kernels.h, run-time plan) --------
+template <class ST>
+__global__ __launch_bounds__(1024) void k_rows_fwd_st(Plan1D p, const float2 *__restrict__ in, long in_stride,
+                                                      ST *__restrict__ out, long out_stride, int conj_flag,
+                                                      float scale) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int row = blockIdx.x, batch = blockIdx.y;
+    const int S = p.S;
+    const float2 *src = in + (long)batch * in_stride + (long)row * S;
+    for (int e = tid; e < S; e += nthr) lds[lds_phys(e)] = src[e];
+    __syncthreads();
+    fft_lds<-1>(lds, p, S, 1, tid, nthr);
+    ST *dst = out + (long)batch * out_stride + (long)row * S;
+    for (int e = tid; e < S; e += nthr) {
+        float2 v = lds[lds_phys(e)];
+        v.x *= scale;
+        v.y *= conj_flag ? -scale : scale;
+        st_c(dst, e, v);
+    }
+}
+
 // ---- inverse row pass ------------------------------------------------------------------------
 // 1-D grid of L1*G workgroups.  Workgroups that handle the same spectrum row k1 for the G
 // Doppler bins of a launch are consecutive on ONE XCD (hardware places workgroup b on XCD b % 8),

@@ -334,11 +334,22 @@ __global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig
                                                   double2 *__restrict__ out) {
     const CorrJob jb = jobs[blockIdx.x];
     double sr = 0.0, si = 0.0;
-    for (long n = threadIdx.x; n < jb.len; n += blockDim.x) {
+    // carrier by rotation: exact sincospi every 16th sample of a thread (and at the circular
+    // wrap, where the time index jumps), a constant-angle complex rotation in between
+    const double dcyc = jb.freq * ((double)blockDim.x * inv_fs);
+    double wr, wi;
+    sincospi(2.0 * (dcyc - floor(dcyc)), &wi, &wr);
+    double cr = 1.0, ci = 0.0;
+    int it = 0;
+    for (long n = threadIdx.x; n < jb.len; n += blockDim.x, ++it) {
         long a = jb.start + n;
         long t = n;
+        bool resync = (it & 15) == 0;
         if (jb.circ) {
-            if (a >= n_circ) a -= n_circ;
+            if (a >= n_circ) {
+                resync = resync || (a - (long)blockDim.x < n_circ);
+                a -= n_circ;
+            }
             t = a;
         }
         float cv;
@@ -346,16 +357,20 @@ __global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig
             cv = tab.value(jb.slot, n);
         } else {
             const long k = jb.code_k0 + n + 1;
-            const long ci = (long)floor((tab.ts * (double)k) / tab.tc);
-            cv = (float)tab.prim[(long)jb.slot * tab.code_len + (ci % tab.code_len)];
+            const long ci2 = (long)floor((tab.ts * (double)k) / tab.tc);
+            cv = (float)tab.prim[(long)jb.slot * tab.code_len + (ci2 % tab.code_len)];
         }
         const double x = ((double)sig[a] - jb.mean) * (double)cv;
-        const double cyc = jb.freq * ((double)t * inv_fs);
-        const double fr = cyc - floor(cyc);
-        double s, c;
-        sincospi(2.0 * fr, &s, &c);
-        sr += x * c;
-        si += x * s;
+        if (resync) {
+            const double cyc = jb.freq * ((double)t * inv_fs);
+            sincospi(2.0 * (cyc - floor(cyc)), &ci, &cr);
+        } else {
+            const double nr = cr * wr - ci * wi;
+            ci = cr * wi + ci * wr;
+            cr = nr;
+        }
+        sr += x * cr;
+        si += x * ci;
     }
     __shared__ double s_r[256], s_i[256];
     s_r[threadIdx.x] = sr;

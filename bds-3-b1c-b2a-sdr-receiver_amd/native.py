@@ -67,7 +67,7 @@ class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("forward_ms", C.c_double), ("search_ms", C.c_double),
                 ("refine_ms", C.c_double), ("cell_pair_ms", C.c_double), ("cells_per_pair", C.c_double),
                 ("n_pairs", C.c_int64), ("fft_len", C.c_int64), ("n_circ", C.c_int64),
-                ("n_bins", C.c_int32), ("n_prn", C.c_int32), ("n_comp", C.c_int32), ("reserved0", C.c_int32)]
+                ("n_bins", C.c_int32), ("n_prn", C.c_int32), ("n_comp", C.c_int32), ("half_storage", C.c_int32)]
 
 
 EXPORTS = [

@@ -6,7 +6,10 @@ PKG="$ROOT/bds-3-b1c-b2a-sdr-receiver_amd"
 SRC="$PKG/csrc"
 OUT="$PKG/libbds_mi355x.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off
+# -ffp-contract=off everywhere except the search (bds_acq.hip): the tracking NCO index
+# arithmetic must round exactly like the reference's a + k*d (two roundings), while the
+# fp32 transform butterflies want FMA contraction.
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden
        -Wall -Wno-unused-result -I"$ROOT/include" -I"$SRC")
 mkdir -p "$PKG/build"
 objs=()
@@ -16,9 +19,11 @@ for f in bds_codes.cpp bds_api.hip bds_acq.hip bds_track.hip; do
     if [ ! -f "$o" ] || [ -n "$(find "$SRC/$f" "$SRC"/*.h "$ROOT/include"/*.h -newer "$o" 2>/dev/null)" ]; then
         echo "hipcc $f"
         if [[ "$f" == *.cpp ]]; then
-            "$HIPCC" "${FLAGS[@]}" -x c++ -c "$SRC/$f" -o "$o"
+            "$HIPCC" "${FLAGS[@]}" -ffp-contract=off -x c++ -c "$SRC/$f" -o "$o"
         else
-            "$HIPCC" "${FLAGS[@]}" -c "$SRC/$f" -o "$o" ${BDS_HIPCC_EXTRA:-}
+            contract=off
+            [ "$f" = bds_acq.hip ] && contract=fast
+            "$HIPCC" "${FLAGS[@]}" -ffp-contract=$contract -c "$SRC/$f" -o "$o" ${BDS_HIPCC_EXTRA:-}
         fi
     fi
     objs+=("$o")

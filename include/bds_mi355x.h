@@ -129,7 +129,8 @@ typedef struct bds_timing {
     int64_t n_pairs;        /* launch pairs in the call                             */
     int64_t fft_len;        /* padded transform length L                            */
     int64_t n_circ;         /* N: the reference's circular correlation length       */
-    int32_t n_bins, n_prn, n_comp, reserved0;
+    int32_t n_bins, n_prn, n_comp;
+    int32_t half_storage;   /* 1: spectra + inter-pass buffer held as fp16 complex (fp32 arithmetic) */
 } bds_timing;
 
 typedef struct bds_ctx bds_ctx;

@@ -26,8 +26,9 @@ def _compare(s, x, ctx, oracle_fn):
     rm, ra = ctx.acq_grid(len(sats), nb)
     pk, dn, fb = ctx.acq_peaks(max(sats))
     for i, p in enumerate(sats):
-        np.testing.assert_allclose(rm[i], diag[p]["row_max"], rtol=2e-5)
-        assert np.mean(ra[i] == diag[p]["row_arg"]) > 0.9
+        # the search grid is a sieve: fp32 storage ~1e-7, fp16 storage ~3e-4 of the output RMS
+        np.testing.assert_allclose(rm[i], diag[p]["row_max"], rtol=2e-3 if ctx.timing()["half_storage"] else 2e-5)
+        assert np.mean(ra[i] == diag[p]["row_arg"]) > (0.5 if ctx.timing()["half_storage"] else 0.9)
         assert fb[p - 1] == diag[p]["fbin"]
         np.testing.assert_allclose(pk[p - 1], diag[p]["peak"], rtol=1e-9)
     return ref, got
@@ -66,3 +67,25 @@ def test_prn_shards_sum_to_the_full_result(ctx):
     b = bds_amd.acquisition(x, s, prn_list=[9, 33], verbose=False)
     for f in ("carrFreq", "codePhase", "peakMetric"):
         np.testing.assert_array_equal(getattr(a, f) + getattr(b, f), getattr(full, f))
+
+
+def test_fp32_storage_and_generic_kernels_agree(ctx, monkeypatch):
+    """The specialised fp16-storage path, the specialised fp32-storage path and the run-time generic
+    kernels must return the same acqResults (the f64 refinement decides in all of them)."""
+    s, x, _ = medium_b2a()
+    base = bds_amd.acquisition(x, s, verbose=False)
+    for env in ({"BDS_ACQ_FP16": "0"}, {"BDS_ACQ_GENERIC": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c2 = bds_amd.native.Context(0)
+        try:
+            c2.acq_load(s, x)
+            c2.acq_prepare(s)
+            carr, cph, pm, det = c2.acq_run(s)
+        finally:
+            c2.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        np.testing.assert_array_equal(carr, base.carrFreq)
+        np.testing.assert_array_equal(cph, base.codePhase)
+        np.testing.assert_allclose(pm, base.peakMetric, rtol=1e-9)
