@@ -402,7 +402,7 @@ template <int S, int NC, class ST>
 static void launch_rows_t(bds_ctx *ctx, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
                           float out_scale) {
     static bool attr = false;
-    const size_t lds = sizeof(float2) * tspan<S>();
+    const size_t lds = sizeof(float2) * (tspan<S>() + lds_span(twiddle_entries<S>()));
     if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_inv_t<S, NC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
     hipLaunchKernelGGL((k_rows_inv_t<S, NC, ST>), dim3(pl.L1 * G), dim3(rows_threads<S>()), lds, (hipStream_t)ctx->stream,
                        (const float2 *)pl.d_tw2, pl.twl, (const ST *)Xs, pl.L, pl.L1, G, bin0, (const ST *)Cs, (ST *)Bw, out_scale);
@@ -411,7 +411,7 @@ template <int S, int NC, class ST>
 static void launch_cols_t(bds_ctx *ctx, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
                           int lo2, int hi2, Rec *recs) {
     static bool attr = false;
-    const size_t lds = sizeof(float2) * kFastT * tspan<S>();
+    const size_t lds = sizeof(float2) * (kFastT * tspan<S>() + lds_span(twiddle_entries<S>()));
     if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_t<S, NC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
     hipLaunchKernelGGL((k_cols_inv_max_t<S, NC, ST>), dim3(pl.ntiles, G), dim3(cols_threads<S>()), lds, (hipStream_t)ctx->stream,
                        (const float2 *)pl.d_tw1, pl.L2, (const ST *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);

@@ -49,54 +49,113 @@ __global__ __launch_bounds__(1024) void k_rows_fwd_st(Plan1D p, const float2 *__
     }
 }
 
+// 16-byte-per-lane global access: four consecutive complex elements
+struct C4 {
+    float2 v[4];
+};
+__device__ __forceinline__ C4 ld4(const float2 *p, long i) {
+    const float4 *q = reinterpret_cast<const float4 *>(p + i);
+    const float4 a = q[0], b = q[1];
+    C4 r;
+    r.v[0] = make_float2(a.x, a.y);
+    r.v[1] = make_float2(a.z, a.w);
+    r.v[2] = make_float2(b.x, b.y);
+    r.v[3] = make_float2(b.z, b.w);
+    return r;
+}
+__device__ __forceinline__ C4 ld4(const __half2 *p, long i) {
+    union {
+        uint4 u;
+        __half2 h[4];
+    } t;
+    t.u = *reinterpret_cast<const uint4 *>(p + i);
+    C4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.v[k] = __half22float2(t.h[k]);
+    return r;
+}
+__device__ __forceinline__ void st4(float2 *p, long i, const C4 &c) {
+    float4 *q = reinterpret_cast<float4 *>(p + i);
+    q[0] = make_float4(c.v[0].x, c.v[0].y, c.v[1].x, c.v[1].y);
+    q[1] = make_float4(c.v[2].x, c.v[2].y, c.v[3].x, c.v[3].y);
+}
+__device__ __forceinline__ void st4(__half2 *p, long i, const C4 &c) {
+    union {
+        uint4 u;
+        __half2 h[4];
+    } t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t.h[k] = __float22half2_rn(c.v[k]);
+    *reinterpret_cast<uint4 *>(p + i) = t.u;
+}
+
 // ---- inverse row pass ------------------------------------------------------------------------
 // 1-D grid of L1*G workgroups.  Workgroups that handle the same spectrum row k1 for the G
 // Doppler bins of a launch are consecutive on ONE XCD (hardware places workgroup b on XCD b % 8),
 // so the code-spectrum rows are fetched from HBM once and re-used out of that XCD's L2.
+// Every lane moves 16 bytes per global access (4 consecutive elements: e = 4*(tid + i*NT) + u).
 template <int S, int NCOMP, class ST>
 __global__ __launch_bounds__(rows_threads<S>(), 3) void k_rows_inv_t(const float2 *__restrict__ tw, TwiddleL twl,
-                                                                const ST *__restrict__ Xs, long L, int L1, int G,
-                                                                int bin0, const ST *__restrict__ Cs,
-                                                                ST *__restrict__ Bw, float out_scale) {
+                                                                   const ST *__restrict__ Xs, long L, int L1, int G,
+                                                                   int bin0, const ST *__restrict__ Cs,
+                                                                   ST *__restrict__ Bw, float out_scale) {
     constexpr int NT = rows_threads<S>();
-    constexpr int PE = (S + NT - 1) / NT;
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];  // tspan<S>() elements
-    __shared__ float2 s_step[PE];
+    constexpr int NG = S / 4;                  // groups of 4 elements in a row
+    constexpr int PG = (NG + NT - 1) / NT;     // groups per thread
+    constexpr bool FULL = (NG % NT) == 0;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];  // tspan<S>() data + twiddle table
+    __shared__ float2 s_step[PG + 4];  // [0..PG): W^(k1*4*NT*i)   [PG..PG+4): W^(k1*u)
+    float2 *tw_lds = lds + tspan<S>();
     const int tid = threadIdx.x;
+    load_twiddles<S, NT>(tw_lds, tw, tid);
     const int xcd = blockIdx.x & 7, m = blockIdx.x >> 3;
     const int g = m % G, k1 = (m / G) * 8 + xcd;
     if (k1 >= L1) return;
-    if (tid < PE) {
-        const long mm = (long)k1 * ((long)tid * NT);
+    if (tid < PG + 4) {
+        const long mm = tid < PG ? (long)k1 * (4L * NT * tid) : (long)k1 * (tid - PG);
         s_step[tid] = mm < L ? twl.get<+1>((uint32_t)mm) : make_float2(1.f, 0.f);
     }
-    const float2 wbase = tid < S ? twl.get<+1>((uint32_t)k1 * (uint32_t)tid) : make_float2(1.f, 0.f);
+    const float2 wbase = 4 * tid < S ? twl.get<+1>((uint32_t)k1 * (uint32_t)(4 * tid)) : make_float2(1.f, 0.f);
     const ST *xr = Xs + (long)(bin0 + g) * L + (long)k1 * S;
-    float2 xv[PE];
+    C4 xv[PG];
 #pragma unroll
-    for (int i = 0; i < PE; ++i) {
-        const int e = tid + i * NT;
-        if (S % NT == 0 || e < S) xv[i] = ld_c(xr, e);
+    for (int i = 0; i < PG; ++i) {
+        const int gi = tid + i * NT;
+        if (FULL || gi < NG) xv[i] = ld4(xr, 4 * gi);
     }
 #pragma unroll
     for (int comp = 0; comp < NCOMP; ++comp) {
         const ST *cr = Cs + (long)comp * L + (long)k1 * S;
 #pragma unroll
-        for (int i = 0; i < PE; ++i) {
-            const int e = tid + i * NT;
-            if (S % NT == 0 || e < S) lds[e + (e >> 4)] = cmul(xv[i], ld_c(cr, e));
+        for (int i = 0; i < PG; ++i) {
+            const int gi = tid + i * NT;
+            if (FULL || gi < NG) {
+                const C4 c = ld4(cr, 4 * gi);
+                float2 *d = lds + 4 * gi + ((4 * gi) >> 4);  // the 4 elements share one 16-group
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] = cmul(xv[i].v[u], c.v[u]);
+            }
         }
         __syncthreads();
-        TPlan<S>::template run<1, NT, +1>(lds, tw, tid);
+        TPlan<S>::template run<1, NT, +1>(lds, tw_lds, tid);
         ST *dst = Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S;
+        float2 wu[4];
 #pragma unroll
-        for (int i = 0; i < PE; ++i) {
-            const int e = tid + i * NT;
-            if (S % NT == 0 || e < S) {
-                float2 y = cmul(lds[e + (e >> 4)], cmul(wbase, s_step[i]));
-                y.x *= out_scale;
-                y.y *= out_scale;
-                st_c(dst, e, y);
+        for (int u = 0; u < 4; ++u) {
+            wu[u] = cmul(wbase, s_step[PG + u]);
+            wu[u].x *= out_scale;
+            wu[u].y *= out_scale;
+        }
+#pragma unroll
+        for (int i = 0; i < PG; ++i) {
+            const int gi = tid + i * NT;
+            if (FULL || gi < NG) {
+                const float2 *sr = lds + 4 * gi + ((4 * gi) >> 4);
+                const float2 wi = s_step[i];
+                C4 o;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o.v[u] = cmul(sr[u], cmul(wu[u], wi));
+                st4(dst, 4 * gi, o);
             }
         }
         __syncthreads();
@@ -104,66 +163,64 @@ __global__ __launch_bounds__(rows_threads<S>(), 3) void k_rows_inv_t(const float
 }
 
 // ---- inverse column pass + |.| combine + maximum -----------------------------------------------
-// grid (tiles, cells), T = 8 columns per workgroup.  The second component's tile is fetched into
+// grid (tiles, cells), T = 8 columns per workgroup: a row of the tile is two 4-column groups, one
+// 16-byte (fp16) or 32-byte (fp32) access per lane.  The second component's tile is fetched into
 // registers while the first one is being transformed.
 template <int S, int NCOMP, class ST>
-__global__ __launch_bounds__(cols_threads<S>(), (2 * cols_threads<S>() + 255) / 256) void k_cols_inv_max_t(const float2 *__restrict__ tw, int L2,
-                                                                     const ST *__restrict__ Bw, long L, float w0,
-                                                                     float w1, int lo1, int hi1, int lo2, int hi2,
-                                                                     Rec *__restrict__ recs, int rec_stride) {
+__global__ __launch_bounds__(cols_threads<S>(), (2 * cols_threads<S>() + 255) / 256) void k_cols_inv_max_t(
+    const float2 *__restrict__ tw, int L2, const ST *__restrict__ Bw, long L, float w0, float w1, int lo1, int hi1,
+    int lo2, int hi2, Rec *__restrict__ recs, int rec_stride) {
     constexpr int NT = cols_threads<S>();
     constexpr int T = kFastT;
     constexpr int SP = tspan<S>();
-    constexpr int NI = 8;  // (row, column-pair) items per thread: S*4 / NT
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];  // T * SP elements
+    constexpr int NI = 4;  // (row, 4-column group) items per thread: S*2 / NT
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];  // T * SP data + twiddle table
+    float2 *tw_lds = lds + T * SP;
+    load_twiddles<S, NT>(tw_lds, tw, threadIdx.x);
     __shared__ float s_v[NT / 64];
     __shared__ int s_l[NT / 64];
     const int tid = threadIdx.x;
     const int tile = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int g = blockIdx.y;
     const int c0 = tile * T;
-    float2 pre[NI][2];
+    const bool full_tile = c0 + T <= L2;  // L2 % 8 == 0 for every specialised length
+    C4 pre[NI];
     auto fetch = [&](int comp) {
         const ST *src = Bw + ((long)g * NCOMP + comp) * L;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int it = tid + i * NT;
-            const int r = it >> 2, cp = (it & 3) * 2;
-            const long o = (long)r * L2 + c0 + cp;
-            if (c0 + cp + 1 < L2) {
-                pre[i][0] = ld_c(src, o);
-                pre[i][1] = ld_c(src, o + 1);
-            } else {
-                pre[i][0] = c0 + cp < L2 ? ld_c(src, o) : make_float2(0.f, 0.f);
-                pre[i][1] = make_float2(0.f, 0.f);
-            }
+            const int r = it >> 1, cq = (it & 1) * 4;
+            if (full_tile) pre[i] = ld4(src, (long)r * L2 + c0 + cq);
         }
     };
     fetch(0);
-    float mag[NI][2];
+    float mag[NI][4];
 #pragma unroll
     for (int comp = 0; comp < NCOMP; ++comp) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int it = tid + i * NT;
-            const int r = it >> 2, cp = (it & 3) * 2;
+            const int r = it >> 1, cq = (it & 1) * 4;
             const int pr = r + (r >> 4);
-            lds[cp * SP + pr] = pre[i][0];
-            lds[(cp + 1) * SP + pr] = pre[i][1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lds[(cq + u) * SP + pr] = pre[i].v[u];
         }
         __syncthreads();
         if (comp + 1 < NCOMP) fetch(comp + 1);  // in flight during the transform
-        TPlan<S>::template run<T, NT, +1>(lds, tw, tid);
+        TPlan<S>::template run<T, NT, +1>(lds, tw_lds, tid);
         const float w = comp == 0 ? w0 : w1;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int it = tid + i * NT;
-            const int r = it >> 2, cp = (it & 3) * 2;
+            const int r = it >> 1, cq = (it & 1) * 4;
             const int pr = r + (r >> 4);
-            const float2 a = lds[cp * SP + pr], b = lds[(cp + 1) * SP + pr];
-            const float ma = w * sqrtf(a.x * a.x + a.y * a.y), mb = w * sqrtf(b.x * b.x + b.y * b.y);
-            mag[i][0] = comp == 0 ? ma : mag[i][0] + ma;
-            mag[i][1] = comp == 0 ? mb : mag[i][1] + mb;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float2 a = lds[(cq + u) * SP + pr];
+                const float ma = w * sqrtf(a.x * a.x + a.y * a.y);
+                mag[i][u] = comp == 0 ? ma : mag[i][u] + ma;
+            }
         }
         __syncthreads();
     }
@@ -172,13 +229,12 @@ __global__ __launch_bounds__(cols_threads<S>(), (2 * cols_threads<S>() + 255) / 
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int it = tid + i * NT;
-        const int r = it >> 2, cp = (it & 3) * 2;
+        const int r = it >> 1, cq = (it & 1) * 4;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int col = c0 + cp + h;
-            const long lag = (long)r * L2 + col;
-            const bool in = col < L2 && ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2));
-            if (in) rec_better(bv, bl, mag[i][h], (int)lag);
+        for (int u = 0; u < 4; ++u) {
+            const long lag = (long)r * L2 + c0 + cq + u;
+            const bool in = full_tile && ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2));
+            if (in) rec_better(bv, bl, mag[i][u], (int)lag);
         }
     }
     for (int off = 32; off > 0; off >>= 1) {

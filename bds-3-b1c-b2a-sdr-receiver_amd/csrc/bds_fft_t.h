@@ -60,10 +60,10 @@ __device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *_
                 const int kt = kidx[i] * TWS;
                 if constexpr (R == 16 || R == 8) {
                     float2 w[R];
-                    w[1] = tw[kt];
-                    w[2] = tw[2 * kt];
-                    w[4] = tw[4 * kt];
-                    if constexpr (R == 16) w[8] = tw[8 * kt];
+                    w[1] = tw[lds_phys(kt)];  // twiddle table is LDS resident, padded like the data
+                    w[2] = tw[lds_phys(2 * kt)];
+                    w[4] = tw[lds_phys(4 * kt)];
+                    if constexpr (R == 16) w[8] = tw[lds_phys(8 * kt)];
                     if (DIR > 0) {
                         w[1].y = -w[1].y;
                         w[2].y = -w[2].y;
@@ -83,7 +83,7 @@ __device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *_
                 } else {
 #pragma unroll
                     for (int q = 1; q < R; ++q) {
-                        float2 w = tw[q * kt];
+                        float2 w = tw[lds_phys(q * kt)];
                         if (DIR > 0) w.y = -w.y;
                         v[i][q] = cmul(v[i][q], w);
                     }
@@ -102,6 +102,16 @@ template <int S, int T, int NT, int DIR, int NS, int R, int... REST>
 __device__ __forceinline__ void tfft_run(float2 *__restrict__ buf, const float2 *__restrict__ tw, int tid) {
     tstage<S, T, NT, DIR, NS, R>(buf, tw, tid);
     if constexpr (sizeof...(REST) > 0) tfft_run<S, T, NT, DIR, NS * R, REST...>(buf, tw, tid);
+}
+
+// Entries of the W_S table a length-S plan can touch: all-16/8 plans only reach the first half.
+template <int S>
+__host__ __device__ constexpr int twiddle_entries() { return (S == 256 || S == 2048 || S == 4096) ? S / 2 : S; }
+
+// Cooperative copy of the twiddle table into LDS (visible after the caller's next barrier).
+template <int S, int NT>
+__device__ __forceinline__ void load_twiddles(float2 *__restrict__ tw_lds, const float2 *__restrict__ tw, int tid) {
+    for (int i = tid; i < twiddle_entries<S>(); i += NT) tw_lds[lds_phys(i)] = tw[i];
 }
 
 // Radix lists of the supported lengths (must equal factor_radices() on the host: 16s first).
