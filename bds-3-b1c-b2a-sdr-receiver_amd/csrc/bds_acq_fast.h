@@ -89,83 +89,75 @@ __device__ __forceinline__ void st4(__half2 *p, long i, const C4 &c) {
     *reinterpret_cast<uint4 *>(p + i) = t.u;
 }
 
+template <int S>
+struct PlanInfo {
+    static constexpr int kN = sizeof(TPlan<S>::kRadix) / sizeof(int);
+    static constexpr int kLast = TPlan<S>::kRadix[kN - 1];  // radix of the last stage
+    static constexpr int kNsLast = S / kLast;               // its NS (= its butterfly count per transform)
+};
+
 // ---- inverse row pass ------------------------------------------------------------------------
 // 1-D grid of L1*G workgroups.  Workgroups that handle the same spectrum row k1 for the G
 // Doppler bins of a launch are consecutive on ONE XCD (hardware places workgroup b on XCD b % 8),
 // so the code-spectrum rows are fetched from HBM once and re-used out of that XCD's L2.
-// Every lane moves 16 bytes per global access (4 consecutive elements: e = 4*(tid + i*NT) + u).
+// The first radix-16 stage takes its inputs (spectrum product) straight from global memory and
+// the last stage stores its twiddled outputs straight back: per component the LDS sees two
+// stage hand-offs instead of four, and four barriers instead of eight.
 template <int S, int NCOMP, class ST>
 __global__ __launch_bounds__(rows_threads<S>(), 3) void k_rows_inv_t(const float2 *__restrict__ tw, TwiddleL twl,
                                                                    const ST *__restrict__ Xs, long L, int L1, int G,
                                                                    int bin0, const ST *__restrict__ Cs,
                                                                    ST *__restrict__ Bw, float out_scale) {
     constexpr int NT = rows_threads<S>();
-    constexpr int NG = S / 4;                  // groups of 4 elements in a row
-    constexpr int PG = (NG + NT - 1) / NT;     // groups per thread
-    constexpr bool FULL = (NG % NT) == 0;
+    constexpr int NB1 = S / 16;                       // first-stage butterflies
+    constexpr int MB1 = (NB1 + NT - 1) / NT;
+    constexpr int RL = PlanInfo<S>::kLast, NSL = PlanInfo<S>::kNsLast;
+    constexpr int MBL = (NSL + NT - 1) / NT;          // last-stage butterflies per thread
     extern __shared__ __attribute__((aligned(16))) float2 lds[];  // tspan<S>() data + twiddle table
-    __shared__ float2 s_step[PG + 4];  // [0..PG): W^(k1*4*NT*i)   [PG..PG+4): W^(k1*u)
+    __shared__ float2 s_a[MBL], s_b[RL];  // W^(k1*NT*i), W^(k1*NSL*q)
     float2 *tw_lds = lds + tspan<S>();
     const int tid = threadIdx.x;
     load_twiddles<S, NT>(tw_lds, tw, tid);
     const int xcd = blockIdx.x & 7, m = blockIdx.x >> 3;
     const int g = m % G, k1 = (m / G) * 8 + xcd;
     if (k1 >= L1) return;
-    if (tid < PG + 4) {
-        const long mm = tid < PG ? (long)k1 * (4L * NT * tid) : (long)k1 * (tid - PG);
-        s_step[tid] = mm < L ? twl.get<+1>((uint32_t)mm) : make_float2(1.f, 0.f);
-    }
-    const float2 wbase = 4 * tid < S ? twl.get<+1>((uint32_t)k1 * (uint32_t)(4 * tid)) : make_float2(1.f, 0.f);
+    if (tid < MBL) s_a[tid] = twl.get<+1>((uint32_t)((long)k1 * NT * tid));
+    if (tid >= 64 && tid < 64 + RL) s_b[tid - 64] = twl.get<+1>((uint32_t)((long)k1 * NSL * (tid - 64)));
+    const float2 wbase = twl.get<+1>((uint32_t)k1 * (uint32_t)tid);  // tid < NT <= S
     const ST *xr = Xs + (long)(bin0 + g) * L + (long)k1 * S;
-    C4 xv[PG];
+    float2 xv[MB1][16];
 #pragma unroll
-    for (int i = 0; i < PG; ++i) {
-        const int gi = tid + i * NT;
-        if (FULL || gi < NG) xv[i] = ld4(xr, 4 * gi);
+    for (int i = 0; i < MB1; ++i) {
+        const int bb = tid + i * NT;
+        if (NB1 % NT == 0 || bb < NB1) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xv[i][q] = ld_c(xr, bb + q * NB1);
+        }
+    }
+    __syncthreads();  // twiddle tables + s_a/s_b visible
+    float2 wi[MBL];
+#pragma unroll
+    for (int i = 0; i < MBL; ++i) {
+        wi[i] = cmul(wbase, s_a[i]);
+        wi[i].x *= out_scale;
+        wi[i].y *= out_scale;
     }
 #pragma unroll
     for (int comp = 0; comp < NCOMP; ++comp) {
         const ST *cr = Cs + (long)comp * L + (long)k1 * S;
-#pragma unroll
-        for (int i = 0; i < PG; ++i) {
-            const int gi = tid + i * NT;
-            if (FULL || gi < NG) {
-                const C4 c = ld4(cr, 4 * gi);
-                float2 *d = lds + 4 * gi + ((4 * gi) >> 4);  // the 4 elements share one 16-group
-#pragma unroll
-                for (int u = 0; u < 4; ++u) d[u] = cmul(xv[i].v[u], c.v[u]);
-            }
-        }
-        __syncthreads();
-        TPlan<S>::template run<1, NT, +1>(lds, tw_lds, tid);
         ST *dst = Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S;
-        float2 wu[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            wu[u] = cmul(wbase, s_step[PG + u]);
-            wu[u].x *= out_scale;
-            wu[u].y *= out_scale;
-        }
-#pragma unroll
-        for (int i = 0; i < PG; ++i) {
-            const int gi = tid + i * NT;
-            if (FULL || gi < NG) {
-                const float2 *sr = lds + 4 * gi + ((4 * gi) >> 4);
-                const float2 wi = s_step[i];
-                C4 o;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) o.v[u] = cmul(sr[u], cmul(wu[u], wi));
-                st4(dst, 4 * gi, o);
-            }
-        }
-        __syncthreads();
+        auto src = [&](int i, int q, int, int e) { return cmul(xv[i][q], ld_c(cr, e)); };
+        auto out = [&](int i, int q, int, int e, float2 v) { st_c(dst, e, cmul(v, cmul(wi[i], s_b[q]))); };
+        TPlan<S>::template run<1, NT, +1>(lds, tw_lds, tid, src, out);
+        if (comp + 1 < NCOMP) __syncthreads();  // last-stage reads done before the next first stage writes
     }
 }
 
 // ---- inverse column pass + |.| combine + maximum -----------------------------------------------
 // grid (tiles, cells), T = 8 columns per workgroup: a row of the tile is two 4-column groups, one
 // 16-byte (fp16) or 32-byte (fp32) access per lane.  The second component's tile is fetched into
-// registers while the first one is being transformed.
+// registers while the first one is being transformed; the last stage turns its outputs into
+// magnitudes in registers (no LDS round trip for the result).
 template <int S, int NCOMP, class ST>
 __global__ __launch_bounds__(cols_threads<S>(), (2 * cols_threads<S>() + 255) / 256) void k_cols_inv_max_t(
     const float2 *__restrict__ tw, int L2, const ST *__restrict__ Bw, long L, float w0, float w1, int lo1, int hi1,
@@ -174,6 +166,8 @@ __global__ __launch_bounds__(cols_threads<S>(), (2 * cols_threads<S>() + 255) / 
     constexpr int T = kFastT;
     constexpr int SP = tspan<S>();
     constexpr int NI = 4;  // (row, 4-column group) items per thread: S*2 / NT
+    constexpr int RL = PlanInfo<S>::kLast, NSL = PlanInfo<S>::kNsLast;
+    constexpr int TOTL = NSL * T, MBL = (TOTL + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];  // T * SP data + twiddle table
     float2 *tw_lds = lds + T * SP;
     load_twiddles<S, NT>(tw_lds, tw, threadIdx.x);
@@ -195,7 +189,7 @@ __global__ __launch_bounds__(cols_threads<S>(), (2 * cols_threads<S>() + 255) / 
         }
     };
     fetch(0);
-    float mag[NI][4];
+    float mag[MBL][RL];
 #pragma unroll
     for (int comp = 0; comp < NCOMP; ++comp) {
 #pragma unroll
@@ -208,33 +202,27 @@ __global__ __launch_bounds__(cols_threads<S>(), (2 * cols_threads<S>() + 255) / 
         }
         __syncthreads();
         if (comp + 1 < NCOMP) fetch(comp + 1);  // in flight during the transform
-        TPlan<S>::template run<T, NT, +1>(lds, tw_lds, tid);
         const float w = comp == 0 ? w0 : w1;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int it = tid + i * NT;
-            const int r = it >> 1, cq = (it & 1) * 4;
-            const int pr = r + (r >> 4);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float2 a = lds[(cq + u) * SP + pr];
-                const float ma = w * sqrtf(a.x * a.x + a.y * a.y);
-                mag[i][u] = comp == 0 ? ma : mag[i][u] + ma;
-            }
-        }
-        __syncthreads();
+        auto out = [&](int i, int q, int, int, float2 v) {
+            const float a = w * sqrtf(v.x * v.x + v.y * v.y);
+            mag[i][q] = comp == 0 ? a : mag[i][q] + a;
+        };
+        TPlan<S>::template run<T, NT, +1>(lds, tw_lds, tid, LdsIO{}, out);
+        if (comp + 1 < NCOMP) __syncthreads();  // last-stage reads done before the tile is overwritten
     }
     float bv = -1.f;
     int bl = -1;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int it = tid + i * NT;
-        const int r = it >> 1, cq = (it & 1) * 4;
+    for (int i = 0; i < MBL; ++i) {
+        const int b = tid + i * NT;
+        if (TOTL % NT == 0 || b < TOTL) {
+            const int j = b / NSL, bb = b - j * NSL;  // last stage: hi = 0, k = bb
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long lag = (long)r * L2 + c0 + cq + u;
-            const bool in = full_tile && ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2));
-            if (in) rec_better(bv, bl, mag[i][u], (int)lag);
+            for (int q = 0; q < RL; ++q) {
+                const long lag = (long)(bb + q * NSL) * L2 + c0 + j;
+                const bool in = full_tile && ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2));
+                if (in) rec_better(bv, bl, mag[i][q], (int)lag);
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) {

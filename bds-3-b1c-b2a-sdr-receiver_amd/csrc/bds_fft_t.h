@@ -10,6 +10,8 @@
 // gather and the scatter of a butterfly are "base + q * constant".
 #pragma once
 
+#include <type_traits>
+
 #include "bds_fft.h"
 
 namespace bds {
@@ -17,8 +19,16 @@ namespace bds {
 template <int S>
 __host__ __device__ constexpr int tspan() { return lds_span(S) + 4; }  // per-transform LDS stride (elements)
 
-template <int S, int T, int NT, int DIR, int NS, int R>
-__device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *__restrict__ tw, int tid) {
+// Tag: the stage reads its inputs from / writes its outputs to the LDS transform buffer.
+struct LdsIO {};
+
+// One radix-R stage.  Src / Dst are LdsIO or functors that replace the LDS side:
+//   src(i, q, j, e)  -> float2 : input element e (logical index) of transform j (i = butterfly slot, q = input)
+//   dst(i, q, j, e, v)         : output element e of transform j (i = butterfly slot, q = output)
+// A functor side needs no barrier of its own; the caller orders it against other LDS traffic.
+template <int S, int T, int NT, int DIR, int NS, int R, class Src, class Dst>
+__device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *__restrict__ tw, int tid, Src src,
+                                       Dst dst) {
     constexpr int NB = S / R;
     constexpr int TOTAL = NB * T;
     constexpr int MB = (TOTAL + NT - 1) / NT;
@@ -27,31 +37,38 @@ __device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *_
     constexpr int RSTR = NB + NB / 16;  // physical stride between the R inputs of a butterfly
     constexpr int WSTR = NS + NS / 16;  // physical stride between its outputs (NS >= 16)
     constexpr int TWS = S / (NS * R);   // stride into the W_S table
+    constexpr bool SRC_LDS = std::is_same<Src, LdsIO>::value;
+    constexpr bool DST_LDS = std::is_same<Dst, LdsIO>::value;
     static_assert(NB % 16 == 0, "S/R must be a multiple of 16");
     static_assert(NS == 1 || NS % 16 == 0, "later stages need NS % 16 == 0");
     static_assert(NS > 1 || R == 16, "the first stage must be radix 16");
     float2 v[MB][R];
-    int wofs[MB], kidx[MB];
+    int jj[MB], j0v[MB], kidx[MB];
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
         const int b = tid + i * NT;
         if (FULL || b < TOTAL) {
             const int j = b / NB, bb = b - j * NB;
-            const float2 *src = buf + j * SP + bb + (bb >> 4);
+            if constexpr (SRC_LDS) {
+                const float2 *sp = buf + j * SP + bb + (bb >> 4);
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[i][q] = src[q * RSTR];
+                for (int q = 0; q < R; ++q) v[i][q] = sp[q * RSTR];
+            } else {
+#pragma unroll
+                for (int q = 0; q < R; ++q) v[i][q] = src(i, q, j, bb + q * NB);
+            }
+            jj[i] = j;
             if (NS == 1) {
-                wofs[i] = j * SP + bb * 17;  // phys(16*bb + q) = 17*bb + q
+                j0v[i] = bb * R;
                 kidx[i] = 0;
             } else {
                 const int hi = bb / NS, k = bb - hi * NS;
-                const int j0 = hi * (NS * R) + k;
-                wofs[i] = j * SP + j0 + (j0 >> 4);
+                j0v[i] = hi * (NS * R) + k;
                 kidx[i] = k;
             }
         }
     }
-    __syncthreads();
+    if constexpr (SRC_LDS && DST_LDS) __syncthreads();  // every read of this stage precedes its writes
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
         const int b = tid + i * NT;
@@ -90,18 +107,30 @@ __device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *_
                 }
             }
             Butterfly<R, DIR>::run(v[i]);
-            float2 *dst = buf + wofs[i];
+            if constexpr (DST_LDS) {
+                // phys(j0 + q*NS): NS == 1 -> 17*bb + q ; NS % 16 == 0 -> phys(j0) + q*WSTR
+                float2 *dp = buf + jj[i] * SP + j0v[i] + (j0v[i] >> 4);
 #pragma unroll
-            for (int q = 0; q < R; ++q) dst[NS == 1 ? q : q * WSTR] = v[i][q];
+                for (int q = 0; q < R; ++q) dp[NS == 1 ? q : q * WSTR] = v[i][q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < R; ++q) dst(i, q, jj[i], j0v[i] + q * NS, v[i][q]);
+            }
         }
     }
-    __syncthreads();
+    if constexpr (DST_LDS) __syncthreads();
 }
 
-template <int S, int T, int NT, int DIR, int NS, int R, int... REST>
-__device__ __forceinline__ void tfft_run(float2 *__restrict__ buf, const float2 *__restrict__ tw, int tid) {
-    tstage<S, T, NT, DIR, NS, R>(buf, tw, tid);
-    if constexpr (sizeof...(REST) > 0) tfft_run<S, T, NT, DIR, NS * R, REST...>(buf, tw, tid);
+// All stages of a plan; the first stage takes Src, the last one Dst, everything between is LDS.
+template <int S, int T, int NT, int DIR, int NS, class Src, class Dst, int R, int... REST>
+__device__ __forceinline__ void tfft_run(float2 *__restrict__ buf, const float2 *__restrict__ tw, int tid, Src src,
+                                         Dst dst) {
+    if constexpr (sizeof...(REST) == 0) {
+        tstage<S, T, NT, DIR, NS, R>(buf, tw, tid, src, dst);
+    } else {
+        tstage<S, T, NT, DIR, NS, R>(buf, tw, tid, src, LdsIO{});
+        tfft_run<S, T, NT, DIR, NS * R, LdsIO, Dst, REST...>(buf, tw, tid, LdsIO{}, dst);
+    }
 }
 
 // Entries of the W_S table a length-S plan can touch: all-16/8 plans only reach the first half.
@@ -120,10 +149,12 @@ struct TPlan;
 #define BDS_TPLAN(S_, ...)                                                                         \
     template <>                                                                                    \
     struct TPlan<S_> {                                                                             \
-        template <int T, int NT, int DIR>                                                          \
-        __device__ __forceinline__ static void run(float2 *buf, const float2 *tw, int tid) {       \
-            tfft_run<S_, T, NT, DIR, 1, __VA_ARGS__>(buf, tw, tid);                                \
+        template <int T, int NT, int DIR, class Src, class Dst>                                    \
+        __device__ __forceinline__ static void run(float2 *buf, const float2 *tw, int tid, Src src, \
+                                                   Dst dst) {                                      \
+            tfft_run<S_, T, NT, DIR, 1, Src, Dst, __VA_ARGS__>(buf, tw, tid, src, dst);            \
         }                                                                                          \
+        static constexpr int kRadix[] = {__VA_ARGS__};                                             \
     };
 BDS_TPLAN(256, 16, 16)
 BDS_TPLAN(512, 16, 16, 2)

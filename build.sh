@@ -22,7 +22,9 @@ for f in bds_codes.cpp bds_api.hip bds_acq.hip bds_track.hip; do
             "$HIPCC" "${FLAGS[@]}" -ffp-contract=off -x c++ -c "$SRC/$f" -o "$o"
         else
             contract=off
-            [ "$f" = bds_acq.hip ] && contract=fast
+            # the search: FMA contraction on; SLP packing off (v_pk_* f32 runs at the scalar rate on
+            # gfx950 and costs register shuffles: measured -4.6 % on the cell pair)
+            [ "$f" = bds_acq.hip ] && contract="fast -fno-slp-vectorize"
             "$HIPCC" "${FLAGS[@]}" -ffp-contract=$contract -c "$SRC/$f" -o "$o" ${BDS_HIPCC_EXTRA:-}
         fi
     fi
