@@ -177,7 +177,10 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
     while (logT > 0 && (1 << logT) > pl.L2) --logT;
     if (const char *e = std::getenv("BDS_ACQ_LOGT")) logT = std::max(0, std::min(logT, atoi(e)));  // tuning
     const bool want_fast = fast_cols(pl.L1) && fast_rows(pl.L2) && !std::getenv("BDS_ACQ_GENERIC");
-    if (want_fast) logT = 3;  // the specialised column kernel is built for T = 8
+    if (want_fast) {  // the specialised column kernel is built for T = 8 (default) and T = 4
+        const char *e = std::getenv("BDS_ACQ_LOGT");
+        logT = (e && atoi(e) == 3) ? 3 : 2;  // 4 columns per workgroup: four workgroups per CU (measured best)
+    }
     pl.logT = logT;
     pl.Spad = lds_span(pl.L1) + 4;  // +4: successive columns start 8 dwords apart in the bank row
     pl.ntiles = (pl.L2 + (1 << logT) - 1) >> logT;
@@ -187,7 +190,7 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
         return fail(ctx, BDS_ERR_UNSUPPORTED, "transform %d x %d exceeds the per-workgroup budget", pl.L1, pl.L2);
     pl.lds_cols = sizeof(float2) * (size_t)pl.Spad * (size_t)(1 << logT);
     pl.lds_rows = sizeof(float2) * (size_t)lds_span(pl.L2);
-    pl.fast = fast_cols(pl.L1) && fast_rows(pl.L2) && logT == 3 && !std::getenv("BDS_ACQ_GENERIC");
+    pl.fast = want_fast;
     if (std::getenv("BDS_VERBOSE")) {
         fprintf(stderr, "[bds] search kernels: %s\n", pl.fast ? "specialised" : "generic");
         fprintf(stderr, "[bds] plan: need %ld -> L %ld = %d (cols:", need, pl.L, pl.L1);
@@ -253,7 +256,7 @@ struct AcqState {
     std::vector<float> h_rowmax;
     std::vector<int> h_rowarg;
     std::map<int, PrnResult> last;
-    int group = 4;
+    int group = 8;             // (PRN, bin) cells per launch pair
     bool half = false;         // spectra + inter-pass buffer stored as fp16 complex (specialised plans only)
     double sum_abs_ext = 0;    // sum |x| over the periodically extended block: bound of |X[k]|
     double sum_sq_ext = 0;     // sum x^2 over it: X_rms^2 (Parseval)
@@ -399,41 +402,59 @@ static int forward(bds_ctx *ctx, AcqState &a, Loader ld, int nb, float2 *dst, lo
 
 // ---- specialised search kernels: dispatch on the compile-time lengths ------------------------
 template <int S, int NC, class ST>
-static void launch_rows_t(bds_ctx *ctx, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
+static void launch_rows_t(hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
                           float out_scale) {
     static bool attr = false;
     const size_t lds = sizeof(float2) * (tspan<S>() + lds_span(twiddle_entries<S>()));
     if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_inv_t<S, NC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
-    hipLaunchKernelGGL((k_rows_inv_t<S, NC, ST>), dim3(pl.L1 * G), dim3(rows_threads<S>()), lds, (hipStream_t)ctx->stream,
+    hipLaunchKernelGGL((k_rows_inv_t<S, NC, ST>), dim3(pl.L1 * G), dim3(rows_threads<S>()), lds, sr,
                        (const float2 *)pl.d_tw2, pl.twl, (const ST *)Xs, pl.L, pl.L1, G, bin0, (const ST *)Cs, (ST *)Bw, out_scale);
 }
-template <int S, int NC, class ST>
-static void launch_cols_t(bds_ctx *ctx, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
-                          int lo2, int hi2, Rec *recs) {
+template <int S, int T, int NC, class ST>
+static void launch_cols_tt(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
+                           int lo2, int hi2, Rec *recs) {
     static bool attr = false;
-    const size_t lds = sizeof(float2) * (kFastT * tspan<S>() + lds_span(twiddle_entries<S>()));
-    if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_t<S, NC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
-    hipLaunchKernelGGL((k_cols_inv_max_t<S, NC, ST>), dim3(pl.ntiles, G), dim3(cols_threads<S>()), lds, (hipStream_t)ctx->stream,
+    const size_t lds = sizeof(float2) * (T * tspan<S>() + lds_span(twiddle_entries<S>()));
+    if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_t<S, T, NC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    hipLaunchKernelGGL((k_cols_inv_max_t<S, T, NC, ST>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc,
                        (const float2 *)pl.d_tw1, pl.L2, (const ST *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
 }
+template <int S, int NC, class ST>
+static void launch_cols_t(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
+                          int lo2, int hi2, Rec *recs) {
+    if (pl.logT == 2)
+        launch_cols_tt<S, 4, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
+    else
+        launch_cols_tt<S, 8, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
+}
+// One group of cells: row pass on stream sr, column pass on stream sc (sr == sc: plain ordering;
+// otherwise ev_rows / ev_cols chain them so the column pass of group k overlaps the row pass of
+// group k+1, which works in the other half of the inter-pass buffer).
 template <int NC, class ST>
-static void launch_fast(bds_ctx *ctx, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
-                        float out_scale, float w0, float w1, int lo1, int hi1, int lo2, int hi2, Rec *recs) {
+static void launch_fast(hipStream_t sr, hipStream_t sc, hipEvent_t ev_rows, hipEvent_t ev_cols, const Plan2D &pl,
+                        const void *Xs, int G, int bin0, const void *Cs, void *Bw, float out_scale, float w0, float w1,
+                        int lo1, int hi1, int lo2, int hi2, Rec *recs) {
     switch (pl.L2) {
-        case 1280: launch_rows_t<1280, NC, ST>(ctx, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
-        case 2048: launch_rows_t<2048, NC, ST>(ctx, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
-        case 3072: launch_rows_t<3072, NC, ST>(ctx, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
-        default: launch_rows_t<4096, NC, ST>(ctx, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
+        case 1280: launch_rows_t<1280, NC, ST>(sr, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
+        case 2048: launch_rows_t<2048, NC, ST>(sr, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
+        case 3072: launch_rows_t<3072, NC, ST>(sr, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
+        default: launch_rows_t<4096, NC, ST>(sr, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
+    }
+    if (sr != sc) {
+        (void)hipEventRecord(ev_rows, sr);
+        (void)hipStreamWaitEvent(sc, ev_rows, 0);
     }
     switch (pl.L1) {
-        case 256: launch_cols_t<256, NC, ST>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        case 512: launch_cols_t<512, NC, ST>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        case 768: launch_cols_t<768, NC, ST>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        default: launch_cols_t<1024, NC, ST>(ctx, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        case 256: launch_cols_t<256, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        case 512: launch_cols_t<512, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        case 768: launch_cols_t<768, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        default: launch_cols_t<1024, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
     }
+    if (sr != sc) (void)hipEventRecord(ev_cols, sc);
 }
 
-static size_t bw_batches(const AcqState &a) { return (size_t)std::max(a.group * a.ncomp, 8); }
+// inter-pass work buffer: two halves of `group` cells each (float2-sized elements)
+static size_t bw_batches(const AcqState &a) { return (size_t)std::max(2 * a.group * a.ncomp, 8); }
 
 }  // namespace bds
 
@@ -645,20 +666,36 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     const long n_pairs_total = (long)P * ((D + G - 1) / G);
     const long sample_every = std::max<long>(1, n_pairs_total / kSamples);
     long pair_idx = 0;
-    auto launch_cells = [&](int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2) {
+    hipEvent_t ev_rows[2], ev_cols[2];
+    for (int i = 0; i < 2; ++i) {
+        BDS_HIP(ctx, hipEventCreateWithFlags(&ev_rows[i], hipEventDisableTiming));
+        BDS_HIP(ctx, hipEventCreateWithFlags(&ev_cols[i], hipEventDisableTiming));
+    }
+    const hipStream_t s_main = st(ctx), s_cols = (hipStream_t)ctx->stream2;
+    // Running the column pass of group k beside the row pass of group k+1 on a second stream was
+    // measured neutral (both kernels already fill the wave slots), so it stays opt-in.
+    const bool overlap = pl.fast && std::getenv("BDS_ACQ_OVERLAP");
+    long group_idx = 0;
+    // buf < 0: both passes on the main stream; buf = 0/1: half of the inter-pass buffer, passes overlapped
+    auto launch_cells = [&](int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2, int buf) {
         const float2 *Cs = a.d_Cs + (size_t)a.cs_slot[prn] * ncomp * pl.L;
         dim3 gr(pl.L1, nb), gc(pl.ntiles, nb);
+        const hipStream_t sc = buf >= 0 ? s_cols : s_main;
+        const int hb = buf >= 0 ? buf : 0;
+        const size_t half_elems = (size_t)G * ncomp * pl.L;  // elements (of the storage type) per half
         if (pl.fast && a.half) {
             const void *Ch = (const __half2 *)a.d_Cs + (size_t)a.cs_slot[prn] * ncomp * pl.L;
+            void *Bh = (__half2 *)a.d_Bw + (size_t)hb * half_elems;
             if (ncomp == 2)
-                launch_fast<2, __half2>(ctx, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, recs);
+                launch_fast<2, __half2>(s_main, sc, ev_rows[hb], ev_cols[hb], pl, a.d_Xs, nb, b0, Ch, Bh, a.sB, w0, w1, lo1, hi1, lo2, hi2, recs);
             else
-                launch_fast<1, __half2>(ctx, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, recs);
+                launch_fast<1, __half2>(s_main, sc, ev_rows[hb], ev_cols[hb], pl, a.d_Xs, nb, b0, Ch, Bh, a.sB, w0, w1, lo1, hi1, lo2, hi2, recs);
         } else if (pl.fast) {
+            void *Bf = a.d_Bw + (size_t)hb * half_elems;
             if (ncomp == 2)
-                launch_fast<2, float2>(ctx, pl, a.d_Xs, nb, b0, Cs, a.d_Bw, 1.0f, w0, w1, lo1, hi1, lo2, hi2, recs);
+                launch_fast<2, float2>(s_main, sc, ev_rows[hb], ev_cols[hb], pl, a.d_Xs, nb, b0, Cs, Bf, 1.0f, w0, w1, lo1, hi1, lo2, hi2, recs);
             else
-                launch_fast<1, float2>(ctx, pl, a.d_Xs, nb, b0, Cs, a.d_Bw, 1.0f, w0, w1, lo1, hi1, lo2, hi2, recs);
+                launch_fast<1, float2>(s_main, sc, ev_rows[hb], ev_cols[hb], pl, a.d_Xs, nb, b0, Cs, Bf, 1.0f, w0, w1, lo1, hi1, lo2, hi2, recs);
         } else if (ncomp == 2) {
             hipLaunchKernelGGL(k_rows_inv<2>, gr, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, pl.twl,
                                (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
@@ -672,14 +709,19 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
         }
     };
     for (int pi = 0; pi < P; ++pi) {
-        for (int b0 = 0; b0 < D; b0 += G, ++pair_idx) {
+        for (int b0 = 0; b0 < D; b0 += G, ++pair_idx, ++group_idx) {
             const int nb = std::min(G, D - b0);
-            const bool sample = nb == G && (pair_idx % sample_every) == 0 && nsamp < kSamples;
+            const int buf = overlap ? (int)(group_idx & 1) : -1;
+            // the row pass of group k re-uses the buffer half the column pass of group k-2 read
+            if (overlap && group_idx >= 2) BDS_HIP(ctx, hipStreamWaitEvent(s_main, ev_cols[buf], 0));
+            const bool sample = !overlap && nb == G && (pair_idx % sample_every) == 0 && nsamp < kSamples;
             if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], st(ctx)));
-            launch_cells(prns[pi], b0, nb, a.d_recs + ((size_t)pi * D + b0) * pl.ntiles, 0, (int)a.N - 1, 1, 0);
+            launch_cells(prns[pi], b0, nb, a.d_recs + ((size_t)pi * D + b0) * pl.ntiles, 0, (int)a.N - 1, 1, 0, buf);
             if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], st(ctx)));
         }
     }
+    if (overlap)  // join: everything after this is ordered on the main stream again
+        for (int i = 0; i < 2 && i < group_idx; ++i) BDS_HIP(ctx, hipStreamWaitEvent(s_main, ev_cols[i], 0));
     BDS_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)(P * D)), dim3(256), 0, st(ctx), (const Rec *)a.d_recs,
                        pl.ntiles, pl.ntiles, a.d_rowmax, a.d_rowarg);
@@ -701,7 +743,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
             a.sC = 1.f;
             a.cs_slot.clear();
             setenv("BDS_ACQ_FP16", "0", 1);
-            for (hipEvent_t e : {ev0, ev1, ev2, ev3}) (void)hipEventDestroy(e);
+            for (hipEvent_t e : {ev0, ev1, ev2, ev3, ev_rows[0], ev_rows[1], ev_cols[0], ev_cols[1]}) (void)hipEventDestroy(e);
             for (int i = 0; i < kSamples; ++i) (void)hipEventDestroy(sa[i]), (void)hipEventDestroy(sb[i]);
             if ((rc = bds_acq_prepare(ctx, s))) return rc;
             return bds_acq_run(ctx, s, prn_list, n_prn, max_prn, carrFreq, codePhase, peakMetric, detected);
@@ -796,7 +838,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
             if (hi1 < lo1 && hi2 < lo2)
                 return fail(ctx, BDS_ERR_ARG, "PRN %d: empty second-peak range (acquisition.m:248 would fail)", prns[pi]);
             launch_cells(prns[pi], res[pi].fbin - 1, 1, a.d_recs + (size_t)pi * pl.ntiles, (int)rng[pi][0],
-                         (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3]);
+                         (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3], -1);
         }
         BDS_HIP(ctx, hipGetLastError());
         std::vector<Rec> r2((size_t)P * pl.ntiles);
@@ -947,7 +989,8 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
         BDS_HIP(ctx, hipEventElapsedTime(&ms, sa[i], sb[i]));
         acc += ms;
     }
-    t.cell_pair_ms = nsamp ? acc / nsamp : 0;
+    // overlapped passes: the average launch-pair duration is the search time over the pair count
+    t.cell_pair_ms = nsamp ? acc / nsamp : (n_pairs_total ? t.search_ms / (double)n_pairs_total : 0);
     t.cells_per_pair = G;
     t.n_pairs = n_pairs_total;
     t.fft_len = pl.L;
@@ -956,7 +999,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     t.n_prn = P;
     t.n_comp = ncomp;
     t.half_storage = a.half ? 1 : 0;  // storage of the spectra / inter-pass buffer: 1 = fp16 complex
-    for (hipEvent_t e : {ev0, ev1, ev2, ev3}) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev0, ev1, ev2, ev3, ev_rows[0], ev_rows[1], ev_cols[0], ev_cols[1]}) (void)hipEventDestroy(e);
     for (int i = 0; i < kSamples; ++i) (void)hipEventDestroy(sa[i]), (void)hipEventDestroy(sb[i]);
     return BDS_OK;
 }

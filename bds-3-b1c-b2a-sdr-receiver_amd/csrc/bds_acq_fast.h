@@ -23,9 +23,8 @@ __device__ __forceinline__ void st_c(__half2 *p, long i, float2 v) { p[i] = __fl
 
 template <int S>
 __host__ __device__ constexpr int rows_threads() { return S / 16 < 64 ? 64 : ((S / 16 + 63) / 64) * 64; }
-template <int S>
-__host__ __device__ constexpr int cols_threads() { return S / 2; }  // T = 8 columns, 16 points per thread
-constexpr int kFastT = 8;
+template <int S, int T>
+__host__ __device__ constexpr int cols_threads() { return S * T / 16; }  // 16 points per thread
 
 // ---- forward row pass with a typed store (k_rows_fwd of bds_acq_kernels.h, run-time plan) --------
 template <class ST>
@@ -158,14 +157,15 @@ __global__ __launch_bounds__(rows_threads<S>(), 3) void k_rows_inv_t(const float
 // 16-byte (fp16) or 32-byte (fp32) access per lane.  The second component's tile is fetched into
 // registers while the first one is being transformed; the last stage turns its outputs into
 // magnitudes in registers (no LDS round trip for the result).
-template <int S, int NCOMP, class ST>
-__global__ __launch_bounds__(cols_threads<S>(), (2 * cols_threads<S>() + 255) / 256) void k_cols_inv_max_t(
+template <int S, int T, int NCOMP, class ST>
+__global__ __launch_bounds__((cols_threads<S, T>()), 3) void k_cols_inv_max_t(
     const float2 *__restrict__ tw, int L2, const ST *__restrict__ Bw, long L, float w0, float w1, int lo1, int hi1,
     int lo2, int hi2, Rec *__restrict__ recs, int rec_stride) {
-    constexpr int NT = cols_threads<S>();
-    constexpr int T = kFastT;
+    constexpr int NT = cols_threads<S, T>();
     constexpr int SP = tspan<S>();
-    constexpr int NI = 4;  // (row, 4-column group) items per thread: S*2 / NT
+    constexpr int QG = T / 4;  // 4-column groups per tile row
+    constexpr int NI = 4;      // (row, 4-column group) items per thread: S*QG / NT
+    static_assert(T == 4 || T == 8, "tile width");
     constexpr int RL = PlanInfo<S>::kLast, NSL = PlanInfo<S>::kNsLast;
     constexpr int TOTL = NSL * T, MBL = (TOTL + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];  // T * SP data + twiddle table
@@ -178,13 +178,15 @@ __global__ __launch_bounds__(cols_threads<S>(), (2 * cols_threads<S>() + 255) / 
     const int g = blockIdx.y;
     const int c0 = tile * T;
     const bool full_tile = c0 + T <= L2;  // L2 % 8 == 0 for every specialised length
+    // lags >= hi_all are never searched: skip their magnitudes (the padded transform is ~1.6 N long)
+    const int hi_all = hi1 > hi2 ? hi1 : hi2;
     C4 pre[NI];
     auto fetch = [&](int comp) {
         const ST *src = Bw + ((long)g * NCOMP + comp) * L;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int it = tid + i * NT;
-            const int r = it >> 1, cq = (it & 1) * 4;
+            const int r = it / QG, cq = (it % QG) * 4;
             if (full_tile) pre[i] = ld4(src, (long)r * L2 + c0 + cq);
         }
     };
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(cols_threads<S>(), (2 * cols_threads<S>() + 255) / 
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int it = tid + i * NT;
-            const int r = it >> 1, cq = (it & 1) * 4;
+            const int r = it / QG, cq = (it % QG) * 4;
             const int pr = r + (r >> 4);
 #pragma unroll
             for (int u = 0; u < 4; ++u) lds[(cq + u) * SP + pr] = pre[i].v[u];
@@ -203,9 +205,11 @@ __global__ __launch_bounds__(cols_threads<S>(), (2 * cols_threads<S>() + 255) / 
         __syncthreads();
         if (comp + 1 < NCOMP) fetch(comp + 1);  // in flight during the transform
         const float w = comp == 0 ? w0 : w1;
-        auto out = [&](int i, int q, int, int, float2 v) {
-            const float a = w * sqrtf(v.x * v.x + v.y * v.y);
-            mag[i][q] = comp == 0 ? a : mag[i][q] + a;
+        auto out = [&](int i, int q, int, int e, float2 v) {
+            if ((long)e * L2 + c0 <= hi_all) {  // wave-uniform for the tail rows
+                const float a = w * sqrtf(v.x * v.x + v.y * v.y);
+                mag[i][q] = comp == 0 ? a : mag[i][q] + a;
+            }
         };
         TPlan<S>::template run<T, NT, +1>(lds, tw_lds, tid, LdsIO{}, out);
         if (comp + 1 < NCOMP) __syncthreads();  // last-stage reads done before the tile is overwritten

@@ -52,6 +52,14 @@ extern "C" bds_ctx *bds_create(int device_id) {
         return nullptr;
     }
     ctx->stream = (void *)s;
+    hipStream_t s2;
+    if ((e = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)) != hipSuccess) {
+        bds::fail(nullptr, BDS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        (void)hipStreamDestroy(s);
+        delete ctx;
+        return nullptr;
+    }
+    ctx->stream2 = (void *)s2;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
         ctx->devname = prop.name;
@@ -65,8 +73,10 @@ extern "C" void bds_destroy(bds_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize((hipStream_t)ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize((hipStream_t)ctx->stream2);
     bds::acq_state_free(ctx->acq);
     bds::track_state_free(ctx->trk);
+    if (ctx->stream2) (void)hipStreamDestroy((hipStream_t)ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy((hipStream_t)ctx->stream);
     delete ctx;
 }

@@ -31,7 +31,8 @@ void track_state_free(TrackState *);
 
 struct bds_ctx {
     int device = 0;
-    void *stream = nullptr;  // hipStream_t
+    void *stream = nullptr;   // hipStream_t: everything is ordered on this stream ...
+    void *stream2 = nullptr;  // ... except the search's column pass, which overlaps the next row pass
     std::string err;
     std::string devname;
     bds::AcqState *acq = nullptr;

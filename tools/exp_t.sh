@@ -1,0 +1,5 @@
+for lt in 3 2; do for g in 2 4 8; do echo "== LOGT=$lt GROUP=$g"; BDS_ACQ_LOGT=$lt BDS_ACQ_GROUP=$g timeout 300 python bench.py --workload b1c --steps 1 --warmup 1 --no-cpu-baseline --prns 8 2>&1 | grep -E "^\{" | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('   search', round(d['stage_ms']['search_ms'],1), 'us/cell', round(d['stage_ms']['search_ms']*1e3/(8*201),1), 'det', d['config']['satellites_detected'])
+"; done; done
