@@ -1,0 +1,92 @@
+"""BASELINE.json full-size acquisition configs on the GPU (configs[1] B2a and configs[2] B1C, 63 PRNs,
+fs = 99.375 MS/s): size-independent properties + oracle spot checks on a handful of cells (the full
+float64 oracle would need ~1 h for the B1C grid)."""
+import numpy as np
+import pytest
+
+import bds_amd
+from oracle import acquisition as oacq
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_injected(s, sats, res, spc, thr, ftol):
+    injected = {sat.prn: sat for sat in sats}
+    detected = set(int(p) for p in np.nonzero(res.carrFreq)[0] + 1)
+    assert detected == set(injected)
+    for prn, sat in injected.items():
+        assert abs(res.carrFreq[prn - 1] - (s.IF + sat.doppler)) <= ftol  # estimator noise at 45 dB-Hz, not parity
+        d = ((res.codePhase[prn - 1] - 1) - sat.delay) % spc
+        assert min(d, spc - d) <= 6.0  # code-delay estimate, noise limited (a half-chip is 48.6 samples)
+        assert res.peakMetric[prn - 1] > thr
+    for prn in s.acqSatelliteList:
+        if prn not in injected:
+            assert 0 < res.peakMetric[prn - 1] <= thr and res.codePhase[prn - 1] == 0
+
+
+def test_b2a_full_grid(ctx):
+    s, x, sats, _ = bench.build_workload("b2a")
+    res = bds_amd.acquisition(x, s, verbose=False)
+    _check_injected(s, sats, res, 99375, s.acqThreshold, 100.0)
+    # oracle on three PRNs (two present, one absent), whole Doppler grid
+    sub = s.copy(acqSatelliteList=[4, 19, 33])
+    ref = oacq.acquisition_b2a(x.astype(np.float64), sub)
+    for p in (4, 19, 33):
+        assert res.codePhase[p - 1] == ref.codePhase[p - 1] and res.carrFreq[p - 1] == ref.carrFreq[p - 1]
+        np.testing.assert_allclose(res.peakMetric[p - 1], ref.peakMetric[p - 1], rtol=1e-6)
+
+
+def test_b1c_full_grid(ctx):
+    s, x, sats, _ = bench.build_workload("b1c")
+    res = bds_amd.acquisition(x, s, verbose=False)
+    _check_injected(s, sats, res, 993750, s.acqThreshold, 50.0)
+    tm = ctx.timing()
+    assert tm["n_bins"] == 201 and tm["n_prn"] == 63 and tm["n_circ"] == 1987500
+    rm, ra = ctx.acq_grid(63, 201)
+    pk, dn, fb = ctx.acq_peaks(63)
+    tol = 2e-3 if tm["half_storage"] else 2e-5
+    xf = x.astype(np.float64)
+    # oracle rows of the winning bin and its neighbours for one present and one absent PRN
+    for prn in (sats[0].prn, 2):
+        b = int(fb[prn - 1]) - 1
+        bins = [bb for bb in (b - 1, b, b + 1) if 0 <= bb < 201]
+        best = -1.0
+        for bb, row in oacq.b1c_coarse_rows(xf, s, prn, bins):
+            np.testing.assert_allclose(rm[prn - 1, bb], row.max(), rtol=tol)
+            best = max(best, row.max())
+            if bb == b:
+                assert int(np.argmax(row)) + 1 == int(ra[prn - 1, bb]) or tm["half_storage"]
+        np.testing.assert_allclose(pk[prn - 1], best, rtol=1e-9)  # f64 refinement == oracle peak
+        sig_power = np.sqrt(np.var(xf[:993750], ddof=1) * 993750)
+        np.testing.assert_allclose(res.peakMetric[prn - 1], best / sig_power, rtol=1e-9)
+    # sharding invariance at full size: two halves sum to the full result
+    a = bds_amd.acquisition(x, s, prn_list=list(range(1, 64, 2)), verbose=False)
+    b2 = bds_amd.acquisition(x, s, prn_list=list(range(2, 64, 2)), verbose=False)
+    for f in ("carrFreq", "codePhase", "peakMetric"):
+        np.testing.assert_array_equal(getattr(a, f) + getattr(b2, f), getattr(res, f))
+
+
+def test_argument_errors_are_reported(ctx):
+    s = bds_amd.init_settings_b2a(acqSatelliteList=[5])
+    x = np.zeros(1000, dtype=np.int8)
+    with pytest.raises(bds_amd.native.BdsError, match="acquisition needs at least"):
+        bds_amd.acquisition(x, s, verbose=False)
+    x = np.zeros(17 * 99375, dtype=np.int8)
+    with pytest.raises(bds_amd.native.BdsError, match="resampling"):
+        bds_amd.acquisition(x, s.copy(resamplingflag=1, resamplingThreshold=1e6), verbose=False)
+    with pytest.raises(bds_amd.native.BdsError, match="out of 1..63"):
+        bds_amd.acquisition(x, s.copy(acqSatelliteList=[64]), verbose=False)
+    with pytest.raises(bds_amd.native.BdsError, match="fileType 2"):
+        bds_amd.acquisition(x.astype(np.complex128), s, verbose=False)
+    with pytest.raises(bds_amd.native.BdsError, match="acqStep"):
+        bds_amd.acquisition(x, s.copy(acqStep=0), verbose=False)
+
+
+def test_all_zero_block_is_not_a_detection(ctx):
+    """Degenerate input: every correlation is 0, the B2a ratio is 0/0 -> NaN, NaN > threshold is false."""
+    s = bds_amd.init_settings_b2a(samplingFreq=25e6, IF=6.5e6, acqSatelliteList=[5, 9], acqSearchBand=800)
+    x = np.zeros(8 * 25000, dtype=np.int8)
+    r = bds_amd.acquisition(x, s, verbose=False)
+    assert not np.any(r.carrFreq) and not np.any(r.codePhase)
