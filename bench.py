@@ -166,6 +166,16 @@ def main():
     achieved = bytes_per_pair / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
     b_alg = 9 * n_circ * n_bins + 8 * (1 + ncomp) * n_circ * p_total * n_bins
 
+    # HBM traffic per launch pair: measured separately with rocprofv3 --pmc (FETCH_SIZE x2 gfx950
+    # correction + WRITE_SIZE, tools/pmc_run.sh) and committed under profiles/; null if no
+    # measurement exists for this workload / cells-per-pair.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if int(tj.get("cells_per_pair", -1)) == int(cells_per_pair):
+            traffic = tj["bytes_per_pair"] / 1e9  # GB per launch pair
+
     detected = sorted(int(p) for p in np.nonzero(res[0])[0] + 1)
     out = {
         "metric": "IF Msamples/s through acquisition (all PRNs x Doppler bins)",
@@ -188,9 +198,10 @@ def main():
         "whole_job_frac_of_hbm_peak": b_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         "stage_ms": {k: float(np.mean([t[k] for t in tim])) for k in ("total_ms", "forward_ms", "search_ms", "refine_ms")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_rows_inv + k_cols_inv_max launch pair (one pair = %d cells)" % int(cells_per_pair),
-                     "pair_ms": pair_ms},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_unit": "GB per launch pair (PMC)", "algorithmic_GB_per_pair": bytes_per_pair / 1e9,
+                     "kernel": "k_rows_inv_t + k_cols_inv_max_t launch pair (one pair = %d (PRN, bin) cells)" % int(cells_per_pair),
+                     "pair_ms": pair_ms, "storage": "fp16 complex" if tm.get("half_storage") else "fp32 complex"},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
