@@ -46,6 +46,8 @@ struct Plan2D {
     size_t lds_cols = 0, lds_rows = 0;
     bool fast = false;  // both lengths have compile-time specialised search kernels (bds_acq_fast.h)
     float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_hi = nullptr, *d_lo = nullptr;
+    h2 *d_htab1 = nullptr, *d_htab2 = nullptr;  // fp16 stage-twiddle tables of the column / row transform
+    double hscale1 = 1, hscale2 = 1;            // product of the stage scales folded into them
 };
 
 static bool is_5smooth(long v) {
@@ -151,6 +153,36 @@ static int threads_for(const Plan1D &p, int T) {
 static void plan_free(Plan2D &pl) {
     for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo})
         if (*p) (void)hipFree(*p), *p = nullptr;
+    for (h2 **p : {&pl.d_htab1, &pl.d_htab2})
+        if (*p) (void)hipFree(*p), *p = nullptr;
+}
+
+// fp16 stage tables of an inverse transform (bds_fft_t.h: [k][R] per stage after the first,
+// entry = stage_scale(R) * exp(+2 pi j q k / (NS R)))
+static int upload_half_tables(bds_ctx *ctx, const Plan1D &p, h2 **dptr, double *total_scale) {
+    std::vector<h2> h;
+    int ns = 1;
+    *total_scale = 1;
+    for (int s = 0; s < p.nstage; ++s) {
+        const int R = p.radix[s];
+        if (ns > 1) {
+            const double sc = stage_scale(R);
+            *total_scale *= sc;
+            for (int k = 0; k < ns; ++k)
+                for (int q = 0; q < R; ++q) {
+                    const double a = 2.0 * kPi * (double)((long)q * k) / (double)((long)ns * R);
+                    h2 v;
+                    v.x = (_Float16)(sc * std::cos(a));
+                    v.y = (_Float16)(sc * std::sin(a));
+                    h.push_back(v);
+                }
+        }
+        ns *= R;
+    }
+    if (h.empty()) h.push_back(h2{(_Float16)1, (_Float16)0});
+    BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(h2) * h.size()));
+    BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(h2) * h.size(), hipMemcpyHostToDevice));
+    return BDS_OK;
 }
 
 static int upload_twiddles(bds_ctx *ctx, int n, long denom, long step, float2 **dptr) {
@@ -205,6 +237,10 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
     const int nhi = (int)((pl.L + (1L << kTwLoBits) - 1) >> kTwLoBits);
     if ((rc = upload_twiddles(ctx, nhi, pl.L, 1L << kTwLoBits, &pl.d_hi))) return rc;
     if ((rc = upload_twiddles(ctx, 1 << kTwLoBits, pl.L, 1, &pl.d_lo))) return rc;
+    if (pl.fast) {
+        if ((rc = upload_half_tables(ctx, pl.p1, &pl.d_htab1, &pl.hscale1))) return rc;
+        if ((rc = upload_half_tables(ctx, pl.p2, &pl.d_htab2, &pl.hscale2))) return rc;
+    }
     pl.p1.tw = pl.d_tw1;
     pl.p2.tw = pl.d_tw2;
     pl.twl.hi = pl.d_hi;
@@ -258,6 +294,8 @@ struct AcqState {
     std::map<int, PrnResult> last;
     int group = 8;             // (PRN, bin) cells per launch pair
     bool half = false;         // spectra + inter-pass buffer stored as fp16 complex (specialised plans only)
+    bool hmath = false;        // ... and the search arithmetic itself in packed fp16 (k_*_h kernels)
+    float in_scale = 1.f;      // power of two applied to the spectrum row on load (fp16 arithmetic)
     double sum_abs_ext = 0;    // sum |x| over the periodically extended block: bound of |X[k]|
     double sum_sq_ext = 0;     // sum x^2 over it: X_rms^2 (Parseval)
     float sX = 1.f, sC = 1.f, sB = 1.f;  // power-of-two storage scales
@@ -346,6 +384,8 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
     if (const char *g = std::getenv("BDS_ACQ_GROUP")) a.group = std::max(1, std::min(64, atoi(g)));
     a.half = a.plan.fast;
     if (const char *h = std::getenv("BDS_ACQ_FP16")) a.half = a.plan.fast && atoi(h) != 0;
+    a.hmath = a.half;
+    if (const char *h = std::getenv("BDS_ACQ_HMATH")) a.hmath = a.half && atoi(h) != 0;
     // code spectrum: |fft(code)| <= X; stored value conj(C)/L * sC, kept below 2^15
     a.sC = a.half ? (float)std::exp2(std::floor(std::log2(32768.0 * (double)a.plan.L / (double)a.X))) : 1.f;
     // primary codes of every PRN, both components
@@ -451,6 +491,50 @@ static void launch_fast(hipStream_t sr, hipStream_t sc, hipEvent_t ev_rows, hipE
         default: launch_cols_t<1024, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
     }
     if (sr != sc) (void)hipEventRecord(ev_cols, sc);
+}
+
+// ---- fp16-arithmetic search kernels ---------------------------------------------------------------
+template <int S, int NC>
+static void launch_rows_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
+                          float in_scale) {
+    static bool attr = false;
+    const size_t lds = sizeof(h2) * (((tspan<S>() + 3) & ~3) + half_table_entries<S>());
+    if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_inv_h<S, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    hipLaunchKernelGGL((k_rows_inv_h<S, NC>), dim3(pl.L1 * G), dim3(rows_threads<S>()), lds, sr, (const h2 *)pl.d_htab2, pl.twl,
+                       (const __half2 *)Xs, pl.L, pl.L1, G, bin0, (const __half2 *)Cs, (__half2 *)Bw, in_scale);
+}
+template <int S, int T, int NC>
+static void launch_cols_hh(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
+                           int lo2, int hi2, Rec *recs) {
+    static bool attr = false;
+    const size_t lds = sizeof(h2) * (((T * tspan<S>() + 3) & ~3) + half_table_entries<S>());
+    if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_h<S, T, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    hipLaunchKernelGGL((k_cols_inv_max_h<S, T, NC>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, (const h2 *)pl.d_htab1,
+                       pl.L2, (const __half2 *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
+}
+template <int S, int NC>
+static void launch_cols_h(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
+                          int lo2, int hi2, Rec *recs) {
+    if (pl.logT == 2)
+        launch_cols_hh<S, 4, NC>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
+    else
+        launch_cols_hh<S, 8, NC>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
+}
+template <int NC>
+static void launch_fast_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
+                          float in_scale, float w0, float w1, int lo1, int hi1, int lo2, int hi2, Rec *recs) {
+    switch (pl.L2) {
+        case 1280: launch_rows_h<1280, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale); break;
+        case 2048: launch_rows_h<2048, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale); break;
+        case 3072: launch_rows_h<3072, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale); break;
+        default: launch_rows_h<4096, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale); break;
+    }
+    switch (pl.L1) {
+        case 256: launch_cols_h<256, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        case 512: launch_cols_h<512, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        case 768: launch_cols_h<768, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        default: launch_cols_h<1024, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+    }
 }
 
 // inter-pass work buffer: two halves of `group` cells each (float2-sized elements)
@@ -638,6 +722,13 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
         // inter-pass values: rms = X_rms * C_rms / L * sqrt(L2) (Parseval); allow 64 x rms
         const double b_rms = std::sqrt(a.sum_sq_ext) * std::sqrt((double)a.X) / (double)pl.L * std::sqrt((double)pl.L2);
         a.sB = (float)std::exp2(std::floor(std::log2(32768.0 / (64.0 * std::max(1e-30, b_rms) * a.sX * a.sC))));
+        if (a.hmath) {
+            // fp16 arithmetic: bring the spectrum product to unit RMS after the first radix-16 stage
+            // (x4 on noise-like data); later stages are rescaled inside their twiddle tables
+            const double p_rms = std::sqrt(a.sum_sq_ext) * a.sX * std::sqrt((double)a.X) * a.sC / (double)pl.L;
+            a.in_scale = (float)std::exp2(std::round(std::log2(1.0 / (4.0 * std::max(1e-30, p_rms)))));
+            a.sB = (float)(a.in_scale * pl.hscale2 * pl.hscale1);  // total scale the kernels apply themselves
+        }
     }
 
     // ---- forward transforms, once per Doppler bin -------------------------------------
@@ -683,7 +774,14 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
         const hipStream_t sc = buf >= 0 ? s_cols : s_main;
         const int hb = buf >= 0 ? buf : 0;
         const size_t half_elems = (size_t)G * ncomp * pl.L;  // elements (of the storage type) per half
-        if (pl.fast && a.half) {
+        if (pl.fast && a.half && a.hmath) {
+            const void *Ch = (const __half2 *)a.d_Cs + (size_t)a.cs_slot[prn] * ncomp * pl.L;
+            void *Bh = (__half2 *)a.d_Bw + (size_t)hb * half_elems;
+            if (ncomp == 2)
+                launch_fast_h<2>(s_main, pl, a.d_Xs, nb, b0, Ch, Bh, a.in_scale, w0, w1, lo1, hi1, lo2, hi2, recs);
+            else
+                launch_fast_h<1>(s_main, pl, a.d_Xs, nb, b0, Ch, Bh, a.in_scale, w0, w1, lo1, hi1, lo2, hi2, recs);
+        } else if (pl.fast && a.half) {
             const void *Ch = (const __half2 *)a.d_Cs + (size_t)a.cs_slot[prn] * ncomp * pl.L;
             void *Bh = (__half2 *)a.d_Bw + (size_t)hb * half_elems;
             if (ncomp == 2)
@@ -739,7 +837,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
         bool bad = false;
         for (float v : a.h_rowmax) bad = bad || !std::isfinite(v);
         if (bad) {  // an fp16 value overflowed: redo the whole search with fp32 storage
-            a.half = false;
+            a.half = a.hmath = false;
             a.sC = 1.f;
             a.cs_slot.clear();
             setenv("BDS_ACQ_FP16", "0", 1);
@@ -752,7 +850,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
 
     // ---- f64 refinement of the sieve's candidates ---------------------------------------
     // sieve tolerance: fp32 storage errs by ~1e-7 of the output RMS, fp16 storage by ~3e-4
-    const double kDelta = a.half ? 2e-3 : 2e-5;
+    const double kDelta = a.hmath ? 1e-2 : a.half ? 2e-3 : 2e-5;
     auto bin_freq = [&](int b) { return f0 + s->acqStep * (double)b; };
     std::vector<std::vector<Cell>> cells(P);
     std::vector<CorrJob> jobs;
@@ -998,7 +1096,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     t.n_bins = D;
     t.n_prn = P;
     t.n_comp = ncomp;
-    t.half_storage = a.half ? 1 : 0;  // storage of the spectra / inter-pass buffer: 1 = fp16 complex
+    t.half_storage = a.hmath ? 2 : a.half ? 1 : 0;  // 0 fp32; 1 fp16 storage, fp32 arithmetic; 2 fp16 storage and arithmetic  // storage of the spectra / inter-pass buffer: 1 = fp16 complex
     for (hipEvent_t e : {ev0, ev1, ev2, ev3, ev_rows[0], ev_rows[1], ev_cols[0], ev_cols[1]}) (void)hipEventDestroy(e);
     for (int i = 0; i < kSamples; ++i) (void)hipEventDestroy(sa[i]), (void)hipEventDestroy(sb[i]);
     return BDS_OK;

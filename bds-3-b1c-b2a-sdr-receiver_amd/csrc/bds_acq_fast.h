@@ -250,4 +250,166 @@ __global__ __launch_bounds__((cols_threads<S, T>()), 3) void k_cols_inv_max_t(
     }
 }
 
+// =================================================================================================
+// fp16-arithmetic sieve (packed v_pk_*_f16): same kernels with complex type h2 everywhere --
+// registers, LDS, stage twiddles (per-stage [k][R] tables, pre-scaled so values stay near unit RMS).
+// Half the VALU instructions and half the LDS bytes of the fp32 kernels; error ~2e-3 of the output
+// RMS, covered by the wider refinement tolerance (the f64 refinement still makes every decision).
+// =================================================================================================
+__device__ __forceinline__ h2 ld_h(const __half2 *p, long i) {
+    return *reinterpret_cast<const h2 *>(p + i);
+}
+template <int S, int NT>
+__device__ __forceinline__ void load_half_table(h2 *__restrict__ dst, const h2 *__restrict__ src, int tid) {
+    for (int i = tid; i < half_table_entries<S>(); i += NT) dst[i] = src[i];
+}
+
+template <int S, int NCOMP>
+__global__ __launch_bounds__(rows_threads<S>(), 4) void k_rows_inv_h(const h2 *__restrict__ htab, TwiddleL twl,
+                                                                   const __half2 *__restrict__ Xs, long L, int L1,
+                                                                   int G, int bin0, const __half2 *__restrict__ Cs,
+                                                                   __half2 *__restrict__ Bw, float in_scale) {
+    constexpr int NT = rows_threads<S>();
+    constexpr int NB1 = S / 16;
+    constexpr int MB1 = (NB1 + NT - 1) / NT;
+    constexpr int RL = PlanInfo<S>::kLast, NSL = PlanInfo<S>::kNsLast;
+    constexpr int MBL = (NSL + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) h2 ldsh[];  // tspan<S>() data + stage tables
+    __shared__ float2 s_a[MBL], s_b[RL];
+    h2 *tab = ldsh + ((tspan<S>() + 3) & ~3);
+    const int tid = threadIdx.x;
+    load_half_table<S, NT>(tab, htab, tid);
+    const int xcd = blockIdx.x & 7, m = blockIdx.x >> 3;
+    const int g = m % G, k1 = (m / G) * 8 + xcd;
+    if (k1 >= L1) return;
+    if (tid < MBL) s_a[tid] = twl.get<+1>((uint32_t)((long)k1 * NT * tid));
+    if (tid >= 64 && tid < 64 + RL) s_b[tid - 64] = twl.get<+1>((uint32_t)((long)k1 * NSL * (tid - 64)));
+    const float2 wbase = twl.get<+1>((uint32_t)k1 * (uint32_t)tid);
+    const __half2 *xr = Xs + (long)(bin0 + g) * L + (long)k1 * S;
+    const h2 sc = {(_Float16)in_scale, (_Float16)in_scale};
+    h2 xv[MB1][16];
+#pragma unroll
+    for (int i = 0; i < MB1; ++i) {
+        const int bb = tid + i * NT;
+        if (NB1 % NT == 0 || bb < NB1) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xv[i][q] = ld_h(xr, bb + q * NB1) * sc;
+        }
+    }
+    __syncthreads();
+    float2 wi[MBL];
+#pragma unroll
+    for (int i = 0; i < MBL; ++i) wi[i] = cmul(wbase, s_a[i]);
+#pragma unroll
+    for (int comp = 0; comp < NCOMP; ++comp) {
+        const __half2 *cr = Cs + (long)comp * L + (long)k1 * S;
+        __half2 *dst = Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S;
+        auto src = [&](int i, int q, int, int e) { return cmul(xv[i][q], ld_h(cr, e)); };
+        auto out = [&](int i, int q, int, int e, h2 v) {
+            const float2 y = cmul(make_float2((float)v.x, (float)v.y), cmul(wi[i], s_b[q]));
+            st_c(dst, e, y);
+        };
+        TPlan<S>::template run<1, NT, +1>(ldsh, (const h2 *)tab, tid, src, out);
+        if (comp + 1 < NCOMP) __syncthreads();
+    }
+}
+
+template <int S, int T, int NCOMP>
+__global__ __launch_bounds__((cols_threads<S, T>()), 4) void k_cols_inv_max_h(
+    const h2 *__restrict__ htab, int L2, const __half2 *__restrict__ Bw, long L, float w0, float w1, int lo1, int hi1,
+    int lo2, int hi2, Rec *__restrict__ recs, int rec_stride) {
+    constexpr int NT = cols_threads<S, T>();
+    constexpr int SP = tspan<S>();
+    constexpr int QG = T / 4;
+    constexpr int NI = 4;
+    constexpr int RL = PlanInfo<S>::kLast, NSL = PlanInfo<S>::kNsLast;
+    constexpr int TOTL = NSL * T, MBL = (TOTL + NT - 1) / NT;
+    static_assert(T == 4 || T == 8, "tile width");
+    extern __shared__ __attribute__((aligned(16))) h2 ldsh[];  // T * SP data + stage tables
+    h2 *tab = ldsh + ((T * SP + 3) & ~3);
+    const int tid = threadIdx.x;
+    load_half_table<S, NT>(tab, htab, tid);
+    __shared__ float s_v[NT / 64];
+    __shared__ int s_l[NT / 64];
+    const int tile = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int g = blockIdx.y;
+    const int c0 = tile * T;
+    const bool full_tile = c0 + T <= L2;
+    const int hi_all = hi1 > hi2 ? hi1 : hi2;
+    uint4 pre[NI];
+    auto fetch = [&](int comp) {
+        const __half2 *src = Bw + ((long)g * NCOMP + comp) * L;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int it = tid + i * NT;
+            const int r = it / QG, cq = (it % QG) * 4;
+            if (full_tile) pre[i] = *reinterpret_cast<const uint4 *>(src + (long)r * L2 + c0 + cq);
+        }
+    };
+    fetch(0);
+    float mag[MBL][RL];
+#pragma unroll
+    for (int comp = 0; comp < NCOMP; ++comp) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int it = tid + i * NT;
+            const int r = it / QG, cq = (it % QG) * 4;
+            const int pr = r + (r >> 4);
+            union {
+                uint4 u;
+                h2 h[4];
+            } t;
+            t.u = pre[i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ldsh[(cq + u) * SP + pr] = t.h[u];
+        }
+        __syncthreads();
+        if (comp + 1 < NCOMP) fetch(comp + 1);
+        const float w = comp == 0 ? w0 : w1;
+        auto out = [&](int i, int q, int, int e, h2 v) {
+            if ((long)e * L2 + c0 <= hi_all) {
+                const float x = (float)v.x, y = (float)v.y;
+                const float a = w * sqrtf(x * x + y * y);
+                mag[i][q] = comp == 0 ? a : mag[i][q] + a;
+            }
+        };
+        TPlan<S>::template run<T, NT, +1>(ldsh, (const h2 *)tab, tid, LdsIO{}, out);
+        if (comp + 1 < NCOMP) __syncthreads();
+    }
+    float bv = -1.f;
+    int bl = -1;
+#pragma unroll
+    for (int i = 0; i < MBL; ++i) {
+        const int b = tid + i * NT;
+        if (TOTL % NT == 0 || b < TOTL) {
+            const int j = b / NSL, bb = b - j * NSL;
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                const long lag = (long)(bb + q * NSL) * L2 + c0 + j;
+                const bool in = full_tile && ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2));
+                if (in) rec_better(bv, bl, mag[i][q], (int)lag);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(bv, off, 64);
+        const int ol = __shfl_down(bl, off, 64);
+        rec_better(bv, bl, ov, ol);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) {
+        s_v[wave] = bv;
+        s_l[wave] = bl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w2 = 1; w2 < NT / 64; ++w2) rec_better(bv, bl, s_v[w2], s_l[w2]);
+        Rec rr;
+        rr.v = bv;
+        rr.lag = bl;
+        recs[(long)g * rec_stride + tile] = rr;
+    }
+}
+
 }  // namespace bds

@@ -65,15 +65,51 @@ struct TwiddleL {
     }
 };
 
+// ---- complex arithmetic on two storage/compute types ------------------------------------------
+//   float2 : fp32 complex
+//   h2     : fp16 complex, one packed VGPR; +,-,* and fma map to v_pk_*_f16 (two lanes of a
+//            complex value per instruction) -- used by the reduced-precision sieve only
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
 // multiply by -j*DIR ... i.e. exp(-j pi/2) for the forward transform, +j for the inverse
 template <int DIR>
 __device__ __forceinline__ float2 rot90(float2 a) {
     return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+// multiply by the forward constant (cr - j ci) (DIR < 0) or its conjugate (DIR > 0)
+template <int DIR>
+__device__ __forceinline__ float2 mulc(float2 a, float cr, float ci) {
+    return DIR < 0 ? make_float2(a.x * cr + a.y * ci, a.y * cr - a.x * ci)
+                   : make_float2(a.x * cr - a.y * ci, a.y * cr + a.x * ci);
+}
+
+__device__ __forceinline__ h2 hswap(h2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ h2 cmul(h2 a, h2 b) {
+    const h2 bx = {b.x, b.x}, by = {-b.y, b.y};
+    return __builtin_elementwise_fma(hswap(a), by, a * bx);
+}
+__device__ __forceinline__ h2 cadd(h2 a, h2 b) { return a + b; }
+__device__ __forceinline__ h2 csub(h2 a, h2 b) { return a - b; }
+__device__ __forceinline__ h2 cscale(h2 a, float s) {
+    const h2 ss = {(_Float16)s, (_Float16)s};
+    return a * ss;
+}
+template <int DIR>
+__device__ __forceinline__ h2 rot90(h2 a) {
+    const h2 sg = DIR < 0 ? h2{(_Float16)1, (_Float16)-1} : h2{(_Float16)-1, (_Float16)1};
+    return hswap(a) * sg;
+}
+template <int DIR>
+__device__ __forceinline__ h2 mulc(h2 a, float cr, float ci) {
+    const h2 c1 = {(_Float16)cr, (_Float16)cr};
+    const h2 c2 = DIR < 0 ? h2{(_Float16)ci, (_Float16)-ci} : h2{(_Float16)-ci, (_Float16)ci};
+    return __builtin_elementwise_fma(hswap(a), c2, a * c1);
 }
 
 template <int R, int DIR>
@@ -81,8 +117,9 @@ struct Butterfly;
 
 template <int DIR>
 struct Butterfly<2, DIR> {
-    __device__ __forceinline__ static void run(float2 *v) {
-        const float2 a = v[0], b = v[1];
+    template <class C>
+    __device__ __forceinline__ static void run(C *v) {
+        const C a = v[0], b = v[1];
         v[0] = cadd(a, b);
         v[1] = csub(a, b);
     }
@@ -90,13 +127,13 @@ struct Butterfly<2, DIR> {
 
 template <int DIR>
 struct Butterfly<3, DIR> {
-    __device__ __forceinline__ static void run(float2 *v) {
-        // X1,2 = a - (b+c)/2 -+ j*DIR... with s = sin(2pi/3)
+    template <class C>
+    __device__ __forceinline__ static void run(C *v) {
+        // X1,2 = a - (b+c)/2 -+ j s (b-c), s = sin(2pi/3)
         const float s = 0.86602540378443864676f;
-        const float2 a = v[0], t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
-        const float2 m = make_float2(a.x - 0.5f * t.x, a.y - 0.5f * t.y);
-        // forward: X1 = m - j s d ; inverse: X1 = m + j s d
-        const float2 jd = DIR < 0 ? make_float2(s * d.y, -s * d.x) : make_float2(-s * d.y, s * d.x);
+        const C a = v[0], t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+        const C m = csub(a, cscale(t, 0.5f));
+        const C jd = rot90<DIR>(cscale(d, s));  // forward: -j s d
         v[0] = cadd(a, t);
         v[1] = cadd(m, jd);
         v[2] = csub(m, jd);
@@ -105,9 +142,10 @@ struct Butterfly<3, DIR> {
 
 template <int DIR>
 struct Butterfly<4, DIR> {
-    __device__ __forceinline__ static void run(float2 *v) {
-        const float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]);
-        const float2 c = cadd(v[1], v[3]), d = rot90<DIR>(csub(v[1], v[3]));
+    template <class C>
+    __device__ __forceinline__ static void run(C *v) {
+        const C a = cadd(v[0], v[2]), b = csub(v[0], v[2]);
+        const C c = cadd(v[1], v[3]), d = rot90<DIR>(csub(v[1], v[3]));
         v[0] = cadd(a, c);
         v[1] = cadd(b, d);
         v[2] = csub(a, c);
@@ -117,22 +155,21 @@ struct Butterfly<4, DIR> {
 
 template <int DIR>
 struct Butterfly<5, DIR> {
-    __device__ __forceinline__ static void run(float2 *v) {
+    template <class C>
+    __device__ __forceinline__ static void run(C *v) {
         const float c1 = 0.30901699437494742410f;   // cos(2pi/5)
         const float c2 = -0.80901699437494742410f;  // cos(4pi/5)
         const float s1 = 0.95105651629515357212f;   // sin(2pi/5)
         const float s2 = 0.58778525229247312917f;   // sin(4pi/5)
-        const float2 a = v[0];
-        const float2 p1 = cadd(v[1], v[4]), m1 = csub(v[1], v[4]);
-        const float2 p2 = cadd(v[2], v[3]), m2 = csub(v[2], v[3]);
-        const float2 r1 = make_float2(a.x + c1 * p1.x + c2 * p2.x, a.y + c1 * p1.y + c2 * p2.y);
-        const float2 r2 = make_float2(a.x + c2 * p1.x + c1 * p2.x, a.y + c2 * p1.y + c1 * p2.y);
-        // q1 = s1 m1 + s2 m2 ; q2 = s2 m1 - s1 m2 ; forward: X1 = r1 - j q1, X2 = r2 - j q2
-        const float2 q1 = make_float2(s1 * m1.x + s2 * m2.x, s1 * m1.y + s2 * m2.y);
-        const float2 q2 = make_float2(s2 * m1.x - s1 * m2.x, s2 * m1.y - s1 * m2.y);
-        const float2 jq1 = DIR < 0 ? make_float2(q1.y, -q1.x) : make_float2(-q1.y, q1.x);
-        const float2 jq2 = DIR < 0 ? make_float2(q2.y, -q2.x) : make_float2(-q2.y, q2.x);
-        v[0] = make_float2(a.x + p1.x + p2.x, a.y + p1.y + p2.y);
+        const C a = v[0];
+        const C p1 = cadd(v[1], v[4]), m1 = csub(v[1], v[4]);
+        const C p2 = cadd(v[2], v[3]), m2 = csub(v[2], v[3]);
+        const C r1 = cadd(a, cadd(cscale(p1, c1), cscale(p2, c2)));
+        const C r2 = cadd(a, cadd(cscale(p1, c2), cscale(p2, c1)));
+        // forward: X1 = r1 - j q1, X2 = r2 - j q2 ; q1 = s1 m1 + s2 m2 ; q2 = s2 m1 - s1 m2
+        const C jq1 = rot90<DIR>(cadd(cscale(m1, s1), cscale(m2, s2)));
+        const C jq2 = rot90<DIR>(csub(cscale(m1, s2), cscale(m2, s1)));
+        v[0] = cadd(a, cadd(p1, p2));
         v[1] = cadd(r1, jq1);
         v[4] = csub(r1, jq1);
         v[2] = cadd(r2, jq2);
@@ -140,20 +177,14 @@ struct Butterfly<5, DIR> {
     }
 };
 
-// multiply by the forward constant (cr - j ci) (DIR < 0) or its conjugate (DIR > 0)
-template <int DIR>
-__device__ __forceinline__ float2 mulc(float2 a, float cr, float ci) {
-    return DIR < 0 ? make_float2(a.x * cr + a.y * ci, a.y * cr - a.x * ci)
-                   : make_float2(a.x * cr - a.y * ci, a.y * cr + a.x * ci);
-}
-
 template <int DIR>
 struct Butterfly<8, DIR> {
     // n = 2 n1 + n2, k = k1 + 4 k2:  X[k1 + 4 k2] = sum_n2 W2^(n2 k2) W8^(n2 k1) sum_n1 x[2 n1 + n2] W4^(n1 k1)
-    __device__ __forceinline__ static void run(float2 *v) {
+    template <class C>
+    __device__ __forceinline__ static void run(C *v) {
         const float h = 0.70710678118654752440f;
-        float2 a0[4] = {v[0], v[2], v[4], v[6]};
-        float2 a1[4] = {v[1], v[3], v[5], v[7]};
+        C a0[4] = {v[0], v[2], v[4], v[6]};
+        C a1[4] = {v[1], v[3], v[5], v[7]};
         Butterfly<4, DIR>::run(a0);
         Butterfly<4, DIR>::run(a1);
         a1[1] = mulc<DIR>(a1[1], h, h);    // W8^1
@@ -170,11 +201,12 @@ struct Butterfly<8, DIR> {
 template <int DIR>
 struct Butterfly<16, DIR> {
     // n = 4 n1 + n2, k = k1 + 4 k2:  X[k1 + 4 k2] = sum_n2 W4^(n2 k2) W16^(n2 k1) sum_n1 x[4 n1 + n2] W4^(n1 k1)
-    __device__ __forceinline__ static void run(float2 *v) {
+    template <class C>
+    __device__ __forceinline__ static void run(C *v) {
         const float h = 0.70710678118654752440f;
         const float c = 0.92387953251128675613f;  // cos(pi/8)
         const float s = 0.38268343236508977173f;  // sin(pi/8)
-        float2 a[4][4];
+        C a[4][4];
 #pragma unroll
         for (int n2 = 0; n2 < 4; ++n2) {
             a[n2][0] = v[n2];
@@ -195,7 +227,7 @@ struct Butterfly<16, DIR> {
         a[3][3] = mulc<DIR>(a[3][3], -c, -s);  // W16^9 = -W16^1
 #pragma unroll
         for (int k1 = 0; k1 < 4; ++k1) {
-            float2 u[4] = {a[0][k1], a[1][k1], a[2][k1], a[3][k1]};
+            C u[4] = {a[0][k1], a[1][k1], a[2][k1], a[3][k1]};
             Butterfly<4, DIR>::run(u);
             v[k1] = u[0];
             v[k1 + 4] = u[1];

@@ -22,13 +22,20 @@ __host__ __device__ constexpr int tspan() { return lds_span(S) + 4; }  // per-tr
 // Tag: the stage reads its inputs from / writes its outputs to the LDS transform buffer.
 struct LdsIO {};
 
-// One radix-R stage.  Src / Dst are LdsIO or functors that replace the LDS side:
-//   src(i, q, j, e)  -> float2 : input element e (logical index) of transform j (i = butterfly slot, q = input)
-//   dst(i, q, j, e, v)         : output element e of transform j (i = butterfly slot, q = output)
+// scale folded into the fp16 stage-twiddle tables so that values neither grow nor vanish:
+// a radix-R stage multiplies the RMS of noise-like data by sqrt(R)
+__host__ __device__ constexpr float stage_scale(int R) { return R == 16 ? 0.25f : (R == 8 || R == 4) ? 0.5f : 1.0f; }
+
+// One radix-R stage on complex type C (float2: fp32; h2: packed fp16).  Src / Dst are LdsIO or
+// functors that replace the LDS side:
+//   src(i, q, j, e)  -> C : input element e (logical index) of transform j (i = butterfly slot, q = input)
+//   dst(i, q, j, e, v)    : output element e of transform j (i = butterfly slot, q = output)
 // A functor side needs no barrier of its own; the caller orders it against other LDS traffic.
-template <int S, int T, int NT, int DIR, int NS, int R, class Src, class Dst>
-__device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *__restrict__ tw, int tid, Src src,
-                                       Dst dst) {
+// Twiddles: fp32 -- tw is the LDS copy of the W_S table (physical layout), the power-of-two
+// multiples are fetched and the rest built as products; fp16 -- tw is the LDS copy of the
+// per-stage tables [k][R] at offset TWOFF, already in the transform direction and pre-scaled.
+template <class C, int S, int T, int NT, int DIR, int NS, int R, int TWOFF, class Src, class Dst>
+__device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict__ tw, int tid, Src src, Dst dst) {
     constexpr int NB = S / R;
     constexpr int TOTAL = NB * T;
     constexpr int MB = (TOTAL + NT - 1) / NT;
@@ -39,10 +46,11 @@ __device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *_
     constexpr int TWS = S / (NS * R);   // stride into the W_S table
     constexpr bool SRC_LDS = std::is_same<Src, LdsIO>::value;
     constexpr bool DST_LDS = std::is_same<Dst, LdsIO>::value;
+    constexpr bool HALF = std::is_same<C, h2>::value;
     static_assert(NB % 16 == 0, "S/R must be a multiple of 16");
     static_assert(NS == 1 || NS % 16 == 0, "later stages need NS % 16 == 0");
     static_assert(NS > 1 || R == 16, "the first stage must be radix 16");
-    float2 v[MB][R];
+    C v[MB][R];
     int jj[MB], j0v[MB], kidx[MB];
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
@@ -50,7 +58,7 @@ __device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *_
         if (FULL || b < TOTAL) {
             const int j = b / NB, bb = b - j * NB;
             if constexpr (SRC_LDS) {
-                const float2 *sp = buf + j * SP + bb + (bb >> 4);
+                const C *sp = buf + j * SP + bb + (bb >> 4);
 #pragma unroll
                 for (int q = 0; q < R; ++q) v[i][q] = sp[q * RSTR];
             } else {
@@ -74,42 +82,49 @@ __device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *_
         const int b = tid + i * NT;
         if (FULL || b < TOTAL) {
             if (NS > 1) {
-                const int kt = kidx[i] * TWS;
-                if constexpr (R == 16 || R == 8) {
-                    float2 w[R];
-                    w[1] = tw[lds_phys(kt)];  // twiddle table is LDS resident, padded like the data
-                    w[2] = tw[lds_phys(2 * kt)];
-                    w[4] = tw[lds_phys(4 * kt)];
-                    if constexpr (R == 16) w[8] = tw[lds_phys(8 * kt)];
-                    if (DIR > 0) {
-                        w[1].y = -w[1].y;
-                        w[2].y = -w[2].y;
-                        w[4].y = -w[4].y;
-                        if constexpr (R == 16) w[8].y = -w[8].y;
-                    }
-                    w[3] = cmul(w[1], w[2]);
-                    w[5] = cmul(w[1], w[4]);
-                    w[6] = cmul(w[2], w[4]);
-                    w[7] = cmul(w[3], w[4]);
-                    if constexpr (R == 16) {
+                if constexpr (HALF) {
+                    const C *tk = tw + TWOFF + kidx[i] * R;
 #pragma unroll
-                        for (int q = 1; q < 8; ++q) w[8 + q] = cmul(w[q], w[8]);
-                    }
-#pragma unroll
-                    for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], w[q]);
+                    for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], tk[q]);
+                    v[i][0] = cscale(v[i][0], stage_scale(R));
                 } else {
+                    const int kt = kidx[i] * TWS;
+                    if constexpr (R == 16 || R == 8) {
+                        C w[R];
+                        w[1] = tw[lds_phys(kt)];  // twiddle table is LDS resident, padded like the data
+                        w[2] = tw[lds_phys(2 * kt)];
+                        w[4] = tw[lds_phys(4 * kt)];
+                        if constexpr (R == 16) w[8] = tw[lds_phys(8 * kt)];
+                        if (DIR > 0) {
+                            w[1].y = -w[1].y;
+                            w[2].y = -w[2].y;
+                            w[4].y = -w[4].y;
+                            if constexpr (R == 16) w[8].y = -w[8].y;
+                        }
+                        w[3] = cmul(w[1], w[2]);
+                        w[5] = cmul(w[1], w[4]);
+                        w[6] = cmul(w[2], w[4]);
+                        w[7] = cmul(w[3], w[4]);
+                        if constexpr (R == 16) {
 #pragma unroll
-                    for (int q = 1; q < R; ++q) {
-                        float2 w = tw[lds_phys(q * kt)];
-                        if (DIR > 0) w.y = -w.y;
-                        v[i][q] = cmul(v[i][q], w);
+                            for (int q = 1; q < 8; ++q) w[8 + q] = cmul(w[q], w[8]);
+                        }
+#pragma unroll
+                        for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], w[q]);
+                    } else {
+#pragma unroll
+                        for (int q = 1; q < R; ++q) {
+                            C w = tw[lds_phys(q * kt)];
+                            if (DIR > 0) w.y = -w.y;
+                            v[i][q] = cmul(v[i][q], w);
+                        }
                     }
                 }
             }
             Butterfly<R, DIR>::run(v[i]);
             if constexpr (DST_LDS) {
                 // phys(j0 + q*NS): NS == 1 -> 17*bb + q ; NS % 16 == 0 -> phys(j0) + q*WSTR
-                float2 *dp = buf + jj[i] * SP + j0v[i] + (j0v[i] >> 4);
+                C *dp = buf + jj[i] * SP + j0v[i] + (j0v[i] >> 4);
 #pragma unroll
                 for (int q = 0; q < R; ++q) dp[NS == 1 ? q : q * WSTR] = v[i][q];
             } else {
@@ -122,14 +137,13 @@ __device__ __forceinline__ void tstage(float2 *__restrict__ buf, const float2 *_
 }
 
 // All stages of a plan; the first stage takes Src, the last one Dst, everything between is LDS.
-template <int S, int T, int NT, int DIR, int NS, class Src, class Dst, int R, int... REST>
-__device__ __forceinline__ void tfft_run(float2 *__restrict__ buf, const float2 *__restrict__ tw, int tid, Src src,
-                                         Dst dst) {
+template <class C, int S, int T, int NT, int DIR, int NS, int TWOFF, class Src, class Dst, int R, int... REST>
+__device__ __forceinline__ void tfft_run(C *__restrict__ buf, const C *__restrict__ tw, int tid, Src src, Dst dst) {
     if constexpr (sizeof...(REST) == 0) {
-        tstage<S, T, NT, DIR, NS, R>(buf, tw, tid, src, dst);
+        tstage<C, S, T, NT, DIR, NS, R, TWOFF>(buf, tw, tid, src, dst);
     } else {
-        tstage<S, T, NT, DIR, NS, R>(buf, tw, tid, src, LdsIO{});
-        tfft_run<S, T, NT, DIR, NS * R, LdsIO, Dst, REST...>(buf, tw, tid, LdsIO{}, dst);
+        tstage<C, S, T, NT, DIR, NS, R, TWOFF>(buf, tw, tid, src, LdsIO{});
+        tfft_run<C, S, T, NT, DIR, NS * R, TWOFF + (NS > 1 ? NS * R : 0), LdsIO, Dst, REST...>(buf, tw, tid, LdsIO{}, dst);
     }
 }
 
@@ -143,16 +157,20 @@ __device__ __forceinline__ void load_twiddles(float2 *__restrict__ tw_lds, const
     for (int i = tid; i < twiddle_entries<S>(); i += NT) tw_lds[lds_phys(i)] = tw[i];
 }
 
+// fp16 stage-twiddle tables: for every stage after the first, [k][R] entries
+// stage_scale(R) * exp(+2 pi j q k / (NS R)) (inverse direction), concatenated in stage order.
+template <int S>
+__host__ __device__ constexpr int half_table_entries();
+
 // Radix lists of the supported lengths (must equal factor_radices() on the host: 16s first).
 template <int S>
 struct TPlan;
 #define BDS_TPLAN(S_, ...)                                                                         \
     template <>                                                                                    \
     struct TPlan<S_> {                                                                             \
-        template <int T, int NT, int DIR, class Src, class Dst>                                    \
-        __device__ __forceinline__ static void run(float2 *buf, const float2 *tw, int tid, Src src, \
-                                                   Dst dst) {                                      \
-            tfft_run<S_, T, NT, DIR, 1, Src, Dst, __VA_ARGS__>(buf, tw, tid, src, dst);            \
+        template <int T, int NT, int DIR, class C, class Src, class Dst>                           \
+        __device__ __forceinline__ static void run(C *buf, const C *tw, int tid, Src src, Dst dst) { \
+            tfft_run<C, S_, T, NT, DIR, 1, 0, Src, Dst, __VA_ARGS__>(buf, tw, tid, src, dst);      \
         }                                                                                          \
         static constexpr int kRadix[] = {__VA_ARGS__};                                             \
     };
@@ -165,5 +183,15 @@ BDS_TPLAN(2048, 16, 16, 8)
 BDS_TPLAN(3072, 16, 16, 4, 3)
 BDS_TPLAN(4096, 16, 16, 16)
 #undef BDS_TPLAN
+
+template <int S>
+__host__ __device__ constexpr int half_table_entries() {
+    int ns = 1, n = 0;
+    for (int r : TPlan<S>::kRadix) {
+        if (ns > 1) n += ns * r;
+        ns *= r;
+    }
+    return n;
+}
 
 }  // namespace bds

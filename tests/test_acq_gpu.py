@@ -27,8 +27,8 @@ def _compare(s, x, ctx, oracle_fn):
     pk, dn, fb = ctx.acq_peaks(max(sats))
     for i, p in enumerate(sats):
         # the search grid is a sieve: fp32 storage ~1e-7, fp16 storage ~3e-4 of the output RMS
-        np.testing.assert_allclose(rm[i], diag[p]["row_max"], rtol=2e-3 if ctx.timing()["half_storage"] else 2e-5)
-        assert np.mean(ra[i] == diag[p]["row_arg"]) > (0.5 if ctx.timing()["half_storage"] else 0.9)
+        np.testing.assert_allclose(rm[i], diag[p]["row_max"], rtol={0: 2e-5, 1: 2e-3, 2: 3e-2}[ctx.timing()["half_storage"]])
+        assert np.mean(ra[i] == diag[p]["row_arg"]) > (0.3 if ctx.timing()["half_storage"] else 0.9)
         assert fb[p - 1] == diag[p]["fbin"]
         np.testing.assert_allclose(pk[p - 1], diag[p]["peak"], rtol=1e-9)
     return ref, got
@@ -74,7 +74,7 @@ def test_fp32_storage_and_generic_kernels_agree(ctx, monkeypatch):
     kernels must return the same acqResults (the f64 refinement decides in all of them)."""
     s, x, _ = medium_b2a()
     base = bds_amd.acquisition(x, s, verbose=False)
-    for env in ({"BDS_ACQ_FP16": "0"}, {"BDS_ACQ_GENERIC": "1"}):
+    for env in ({"BDS_ACQ_HMATH": "0"}, {"BDS_ACQ_FP16": "0"}, {"BDS_ACQ_GENERIC": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         c2 = bds_amd.native.Context(0)
