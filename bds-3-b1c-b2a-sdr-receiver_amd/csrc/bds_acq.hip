@@ -157,7 +157,7 @@ static void plan_free(Plan2D &pl) {
         if (*p) (void)hipFree(*p), *p = nullptr;
 }
 
-// fp16 stage tables of an inverse transform (bds_fft_t.h: [k][R] per stage after the first,
+// fp16 stage tables of an inverse transform (bds_fft_t.h: [q][k] per stage after the first,
 // entry = stage_scale(R) * exp(+2 pi j q k / (NS R)))
 static int upload_half_tables(bds_ctx *ctx, const Plan1D &p, h2 **dptr, double *total_scale) {
     std::vector<h2> h;
@@ -168,8 +168,8 @@ static int upload_half_tables(bds_ctx *ctx, const Plan1D &p, h2 **dptr, double *
         if (ns > 1) {
             const double sc = stage_scale(R);
             *total_scale *= sc;
-            for (int k = 0; k < ns; ++k)
-                for (int q = 0; q < R; ++q) {
+            for (int q = 0; q < R; ++q)
+                for (int k = 0; k < ns; ++k) {
                     const double a = 2.0 * kPi * (double)((long)q * k) / (double)((long)ns * R);
                     h2 v;
                     v.x = (_Float16)(sc * std::cos(a));

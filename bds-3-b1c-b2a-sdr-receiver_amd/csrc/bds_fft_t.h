@@ -33,7 +33,7 @@ __host__ __device__ constexpr float stage_scale(int R) { return R == 16 ? 0.25f 
 // A functor side needs no barrier of its own; the caller orders it against other LDS traffic.
 // Twiddles: fp32 -- tw is the LDS copy of the W_S table (physical layout), the power-of-two
 // multiples are fetched and the rest built as products; fp16 -- tw is the LDS copy of the
-// per-stage tables [k][R] at offset TWOFF, already in the transform direction and pre-scaled.
+// per-stage tables [R][NS] (q-major) at offset TWOFF, already in the transform direction and pre-scaled.
 template <class C, int S, int T, int NT, int DIR, int NS, int R, int TWOFF, class Src, class Dst>
 __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict__ tw, int tid, Src src, Dst dst) {
     constexpr int NB = S / R;
@@ -83,9 +83,9 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
         if (FULL || b < TOTAL) {
             if (NS > 1) {
                 if constexpr (HALF) {
-                    const C *tk = tw + TWOFF + kidx[i] * R;
+                    const C *tk = tw + TWOFF + kidx[i];  // table layout [q][k]: lanes (consecutive k) hit consecutive banks
 #pragma unroll
-                    for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], tk[q]);
+                    for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], tk[q * NS]);
                     v[i][0] = cscale(v[i][0], stage_scale(R));
                 } else {
                     const int kt = kidx[i] * TWS;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void load_twiddles(float2 *__restrict__ tw_lds, const
     for (int i = tid; i < twiddle_entries<S>(); i += NT) tw_lds[lds_phys(i)] = tw[i];
 }
 
-// fp16 stage-twiddle tables: for every stage after the first, [k][R] entries
+// fp16 stage-twiddle tables: for every stage after the first, [q][k] (q < R, k < NS) entries
 // stage_scale(R) * exp(+2 pi j q k / (NS R)) (inverse direction), concatenated in stage order.
 template <int S>
 __host__ __device__ constexpr int half_table_entries();
