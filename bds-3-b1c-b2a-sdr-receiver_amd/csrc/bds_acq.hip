@@ -292,7 +292,7 @@ struct AcqState {
     std::vector<float> h_rowmax;
     std::vector<int> h_rowarg;
     std::map<int, PrnResult> last;
-    int group = 8;             // (PRN, bin) cells per launch pair
+    int group = 16;            // (PRN, bin) cells per launch pair (measured: 1 -> 41, 4 -> 25, 8 -> 23.6, 16 -> 22.9 us/cell)
     bool half = false;         // spectra + inter-pass buffer stored as fp16 complex (specialised plans only)
     bool hmath = false;        // ... and the search arithmetic itself in packed fp16 (k_*_h kernels)
     float in_scale = 1.f;      // power of two applied to the spectrum row on load (fp16 arithmetic)

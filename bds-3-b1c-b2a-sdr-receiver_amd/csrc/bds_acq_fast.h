@@ -297,18 +297,24 @@ __global__ __launch_bounds__(rows_threads<S>(), 4) void k_rows_inv_h(const h2 *_
         }
     }
     __syncthreads();
-    float2 wi[MBL];
+    // inter-pass twiddle W_L^(-k1 e) of this thread's outputs: built in fp32 (base * step_i * step_q),
+    // rounded to fp16 once per row and shared by the components
+    h2 wo[MBL][RL];
 #pragma unroll
-    for (int i = 0; i < MBL; ++i) wi[i] = cmul(wbase, s_a[i]);
+    for (int i = 0; i < MBL; ++i) {
+        const float2 wi = cmul(wbase, s_a[i]);
+#pragma unroll
+        for (int q = 0; q < RL; ++q) {
+            const float2 w = cmul(wi, s_b[q]);
+            wo[i][q] = h2{(_Float16)w.x, (_Float16)w.y};
+        }
+    }
 #pragma unroll
     for (int comp = 0; comp < NCOMP; ++comp) {
         const __half2 *cr = Cs + (long)comp * L + (long)k1 * S;
-        __half2 *dst = Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S;
+        h2 *dst = reinterpret_cast<h2 *>(Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S);
         auto src = [&](int i, int q, int, int e) { return cmul(xv[i][q], ld_h(cr, e)); };
-        auto out = [&](int i, int q, int, int e, h2 v) {
-            const float2 y = cmul(make_float2((float)v.x, (float)v.y), cmul(wi[i], s_b[q]));
-            st_c(dst, e, y);
-        };
+        auto out = [&](int i, int q, int, int e, h2 v) { dst[e] = cmul(v, wo[i][q]); };
         TPlan<S>::template run<1, NT, +1>(ldsh, (const h2 *)tab, tid, src, out);
         if (comp + 1 < NCOMP) __syncthreads();
     }
@@ -336,6 +342,7 @@ __global__ __launch_bounds__((cols_threads<S, T>()), 4) void k_cols_inv_max_h(
     const int c0 = tile * T;
     const bool full_tile = c0 + T <= L2;
     const int hi_all = hi1 > hi2 ? hi1 : hi2;
+    const int e_max = hi_all >= c0 ? (hi_all - c0) / L2 : -1;  // last output row that can hold a searched lag
     uint4 pre[NI];
     auto fetch = [&](int comp) {
         const __half2 *src = Bw + ((long)g * NCOMP + comp) * L;
@@ -367,7 +374,7 @@ __global__ __launch_bounds__((cols_threads<S, T>()), 4) void k_cols_inv_max_h(
         if (comp + 1 < NCOMP) fetch(comp + 1);
         const float w = comp == 0 ? w0 : w1;
         auto out = [&](int i, int q, int, int e, h2 v) {
-            if ((long)e * L2 + c0 <= hi_all) {
+            if (e <= e_max) {  // rows beyond the searched lags (the padded transform is ~1.6 N long)
                 const float x = (float)v.x, y = (float)v.y;
                 const float a = w * sqrtf(x * x + y * y);
                 mag[i][q] = comp == 0 ? a : mag[i][q] + a;
@@ -385,9 +392,10 @@ __global__ __launch_bounds__((cols_threads<S, T>()), 4) void k_cols_inv_max_h(
             const int j = b / NSL, bb = b - j * NSL;
 #pragma unroll
             for (int q = 0; q < RL; ++q) {
-                const long lag = (long)(bb + q * NSL) * L2 + c0 + j;
-                const bool in = full_tile && ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2));
-                if (in) rec_better(bv, bl, mag[i][q], (int)lag);
+                const int e = bb + q * NSL;
+                const int lag = e * L2 + c0 + j;  // L < 2^31
+                const bool in = full_tile && e <= e_max && ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2));
+                if (in) rec_better(bv, bl, mag[i][q], lag);
             }
         }
     }
