@@ -283,6 +283,9 @@ struct AcqState {
     float *d_rowmax = nullptr;
     int *d_rowarg = nullptr;
     size_t rows_cap = 0;
+    int8_t *d_codes = nullptr;       // sampled codes [slot*2 + mode][code_stride] for the f64 sums
+    long code_stride = 0;
+    std::vector<char> code_have;     // which (slot, mode) tables exist
     CorrJob *d_jobs = nullptr;
     double2 *d_jobout = nullptr;
     size_t jobs_cap = 0;
@@ -305,7 +308,7 @@ void acq_state_free(AcqState *a) {
     if (!a) return;
     plan_free(a->plan);
     for (void *p : {(void *)a->d_sig, (void *)a->d_prim, (void *)a->d_Cs, (void *)a->d_Xs, (void *)a->d_Bw,
-                    (void *)a->d_recs, (void *)a->d_rowmax, (void *)a->d_rowarg, (void *)a->d_jobs,
+                    (void *)a->d_recs, (void *)a->d_rowmax, (void *)a->d_rowarg, (void *)a->d_jobs, (void *)a->d_codes,
                     (void *)a->d_jobout})
         if (p) (void)hipFree(p);
     delete a;
@@ -366,6 +369,7 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
                       a.cohT == s.acqCohT && a.pilotACQ == s.pilotACQflag && a.code_len == s.codeLength &&
                       a.plan.L > 0;
     if (same) return BDS_OK;
+    a.code_have.clear();  // sampled-code cache: same key
     a.cs_slot.clear();  // the spectra cache is keyed by everything above: drop it (slot size depends on L)
     if (a.d_Cs) (void)hipFree(a.d_Cs), a.d_Cs = nullptr;
     a.cs_cap_slots = 0;
@@ -625,11 +629,31 @@ struct Cell {
     bool operator<(const Cell &o) const { return std::tie(b, lag) < std::tie(o.b, o.lag); }
 };
 
-static int run_jobs(bds_ctx *ctx, AcqState &a, const CodeTable &tab, std::vector<CorrJob> &jobs,
+static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vector<CorrJob> &jobs,
                     std::vector<double2> &out) {
     out.resize(jobs.size());
     if (jobs.empty()) return BDS_OK;
     int rc;
+    // sampled codes the jobs refer to (built once per (slot, mode), cached in the context)
+    const long stride = a.signal == BDS_SIGNAL_B2A ? std::max<long>(a.spc, (long)s.fineNoncoh * a.spc) : a.spc;
+    const size_t ntab = (size_t)BDS_MAX_PRN * 2 * 2;
+    if (!a.d_codes || a.code_stride != stride || a.code_have.size() != ntab) {
+        if (a.d_codes) (void)hipFree(a.d_codes), a.d_codes = nullptr;
+        hipError_t e = hipMalloc((void **)&a.d_codes, ntab * (size_t)stride);
+        if (e != hipSuccess) return fail(ctx, BDS_ERR_NOMEM, "sampled-code cache: %s", hipGetErrorString(e));
+        a.code_stride = stride;
+        a.code_have.assign(ntab, 0);
+    }
+    CodeTable full = a.tab;
+    full.xlen = a.spc;  // whole table; the coarse jobs read its first X samples
+    for (const CorrJob &j : jobs) {
+        const size_t t = (size_t)j.slot * 2 + j.mode;
+        if (a.code_have[t]) continue;
+        const long len = j.mode ? stride : a.spc;
+        hipLaunchKernelGGL(k_make_code, dim3(256), dim3(256), 0, st(ctx), full, j.slot, j.mode, len,
+                           a.d_codes + t * (size_t)stride);
+        a.code_have[t] = 1;
+    }
     if (a.jobs_cap < jobs.size()) {
         if (a.d_jobs) (void)hipFree(a.d_jobs), a.d_jobs = nullptr;
         if (a.d_jobout) (void)hipFree(a.d_jobout), a.d_jobout = nullptr;
@@ -641,7 +665,7 @@ static int run_jobs(bds_ctx *ctx, AcqState &a, const CodeTable &tab, std::vector
     }
     BDS_HIP(ctx, hipMemcpyAsync(a.d_jobs, jobs.data(), sizeof(CorrJob) * jobs.size(), hipMemcpyHostToDevice, st(ctx)));
     hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size()), dim3(256), 0, st(ctx), (const int8_t *)a.d_sig, a.N,
-                       tab, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
+                       (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
     BDS_HIP(ctx, hipGetLastError());
     BDS_HIP(ctx, hipMemcpyAsync(out.data(), a.d_jobout, sizeof(double2) * jobs.size(), hipMemcpyDeviceToHost, st(ctx)));
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
@@ -826,10 +850,8 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     BDS_HIP(ctx, hipEventRecord(ev2, st(ctx)));
     a.h_rowmax.resize((size_t)P * D);
     a.h_rowarg.resize((size_t)P * D);
-    std::vector<Rec> h_recs((size_t)P * D * pl.ntiles);
     BDS_HIP(ctx, hipMemcpyAsync(a.h_rowmax.data(), a.d_rowmax, sizeof(float) * P * D, hipMemcpyDeviceToHost, st(ctx)));
     BDS_HIP(ctx, hipMemcpyAsync(a.h_rowarg.data(), a.d_rowarg, sizeof(int) * P * D, hipMemcpyDeviceToHost, st(ctx)));
-    BDS_HIP(ctx, hipMemcpyAsync(h_recs.data(), a.d_recs, sizeof(Rec) * h_recs.size(), hipMemcpyDeviceToHost, st(ctx)));
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
     a.run_prns = prns;
     a.last.clear();
@@ -854,14 +876,42 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     auto bin_freq = [&](int b) { return f0 + s->acqStep * (double)b; };
     std::vector<std::vector<Cell>> cells(P);
     std::vector<CorrJob> jobs;
+    // only the per-workgroup records of rows that reach the tolerance band travel to the host
+    // (the full record array is P*D*tiles*8 B: 104 MB at the B1C config)
+    std::vector<float> thr_of(P);
+    std::map<std::pair<int, int>, size_t> row_at;
+    std::vector<Rec> h_recs;
+    {
+        std::vector<std::pair<int, int>> rows;
+        for (int pi = 0; pi < P; ++pi) {
+            float M = -1.f;
+            for (int b = 0; b < D; ++b) M = std::max(M, a.h_rowmax[(size_t)pi * D + b]);
+            thr_of[pi] = (float)((1.0 - kDelta) * (double)M);
+            for (int b = 0; b < D; ++b)
+                if (!(a.h_rowmax[(size_t)pi * D + b] < thr_of[pi])) rows.push_back({pi, b});
+        }
+        const size_t all = (size_t)P * D * pl.ntiles;
+        if (all * sizeof(Rec) <= (16u << 20)) {  // small grid (B2a): one copy beats many row copies
+            h_recs.resize(all);
+            BDS_HIP(ctx, hipMemcpyAsync(h_recs.data(), a.d_recs, sizeof(Rec) * all, hipMemcpyDeviceToHost, st(ctx)));
+            for (auto &r : rows) row_at[r] = ((size_t)r.first * D + r.second) * pl.ntiles;
+        } else {
+            h_recs.resize(rows.size() * (size_t)pl.ntiles);
+            for (size_t r = 0; r < rows.size(); ++r) {
+                row_at[rows[r]] = r * (size_t)pl.ntiles;
+                BDS_HIP(ctx, hipMemcpyAsync(&h_recs[r * (size_t)pl.ntiles],
+                                            a.d_recs + ((size_t)rows[r].first * D + rows[r].second) * pl.ntiles,
+                                            sizeof(Rec) * pl.ntiles, hipMemcpyDeviceToHost, st(ctx)));
+            }
+        }
+        BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+    }
     for (int pi = 0; pi < P; ++pi) {
-        float M = -1.f;
-        for (int b = 0; b < D; ++b) M = std::max(M, a.h_rowmax[(size_t)pi * D + b]);
-        const float thr = (float)((1.0 - kDelta) * (double)M);
+        const float thr = thr_of[pi];
         std::set<Cell> cs;
         for (int b = 0; b < D; ++b) {
             if (a.h_rowmax[(size_t)pi * D + b] < thr) continue;
-            const Rec *rr = &h_recs[((size_t)pi * D + b) * pl.ntiles];
+            const Rec *rr = &h_recs[row_at[{pi, b}]];
             for (int t = 0; t < pl.ntiles; ++t) {
                 if (rr[t].lag < 0 || rr[t].v < thr) continue;
                 for (int db = -1; db <= 1; ++db)
@@ -887,7 +937,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
             }
     }
     std::vector<double2> jout;
-    if ((rc = run_jobs(ctx, a, a.tab, jobs, jout))) return rc;
+    if ((rc = run_jobs(ctx, a, *s, jobs, jout))) return rc;
     std::vector<PrnResult> res(P);
     {
         size_t k = 0;
@@ -971,7 +1021,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
                     jobs.push_back(j);
                 }
         }
-        if ((rc = run_jobs(ctx, a, a.tab, jobs, jout))) return rc;
+        if ((rc = run_jobs(ctx, a, *s, jobs, jout))) return rc;
         size_t k = 0;
         for (int pi = 0; pi < P; ++pi) {
             double second = -1;
@@ -985,8 +1035,6 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     std::vector<int> fine_of(P, -1);
     int nfine = 0;
     std::vector<std::vector<double>> fine_frq(P);
-    CodeTable tabf = a.tab;
-    tabf.xlen = a.spc;  // the fine search multiplies by the whole table (B1C/acquisition.m:257)
     for (int pi = 0; pi < P; ++pi) {
         PrnResult &r = res[pi];
         const double metric = r.peak / r.denom;  // :252 / B1C :235
@@ -1040,7 +1088,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
         }
         fine_of[pi] = 1;
     }
-    if ((rc = run_jobs(ctx, a, tabf, jobs, jout))) return rc;
+    if ((rc = run_jobs(ctx, a, *s, jobs, jout))) return rc;
     {
         size_t k = 0;
         for (int pi = 0; pi < P; ++pi) {

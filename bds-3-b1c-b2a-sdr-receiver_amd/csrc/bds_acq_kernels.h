@@ -317,6 +317,23 @@ __global__ void k_reduce_rows(const Rec *__restrict__ recs, int rec_stride, int 
 //   code mode 0: sampling table (CodeTable::value, n < spc)
 //   code mode 1: long code  prim[ floor(ts*(k)/tc) mod code_len ], k = code_k0 + n + 1
 //                (B2a/acquisition.m:279-284; always the plain primary code)
+// The sampled code of a (slot, mode) is materialised once as int8 (k_make_code, cached in the
+// context) so the f64 index arithmetic -- a multiply, a divide and a ceil/floor per sample,
+// rounded exactly like the reference -- is not redone for every frequency bin and candidate.
+__global__ __launch_bounds__(256) void k_make_code(CodeTable tab, int slot, int mode, long len,
+                                                   int8_t *__restrict__ out) {
+    for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < len; n += (long)gridDim.x * blockDim.x) {
+        float cv;
+        if (mode == 0) {
+            cv = tab.value(slot, n);
+        } else {
+            const long ci = (long)floor((tab.ts * (double)(n + 1)) / tab.tc);
+            cv = (float)tab.prim[(long)slot * tab.code_len + (ci % tab.code_len)];
+        }
+        out[n] = (int8_t)cv;
+    }
+}
+
 struct CorrJob {
     long start;     // first sample (0-based)
     long len;       // samples to sum
@@ -329,7 +346,8 @@ struct CorrJob {
     int pad;
 };
 
-__global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig, long n_circ, CodeTable tab,
+__global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig, long n_circ,
+                                                  const int8_t *__restrict__ codes, long code_stride,
                                                   double inv_fs, const CorrJob *__restrict__ jobs,
                                                   double2 *__restrict__ out) {
     const CorrJob jb = jobs[blockIdx.x];
@@ -341,6 +359,7 @@ __global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig
     sincospi(2.0 * (dcyc - floor(dcyc)), &wi, &wr);
     double cr = 1.0, ci = 0.0;
     int it = 0;
+    const long cbase = ((long)jb.slot * 2 + jb.mode) * code_stride + (jb.mode ? jb.code_k0 : 0);
     for (long n = threadIdx.x; n < jb.len; n += blockDim.x, ++it) {
         long a = jb.start + n;
         long t = n;
@@ -352,14 +371,7 @@ __global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig
             }
             t = a;
         }
-        float cv;
-        if (jb.mode == 0) {
-            cv = tab.value(jb.slot, n);
-        } else {
-            const long k = jb.code_k0 + n + 1;
-            const long ci2 = (long)floor((tab.ts * (double)k) / tab.tc);
-            cv = (float)tab.prim[(long)jb.slot * tab.code_len + (ci2 % tab.code_len)];
-        }
+        const int8_t cv = codes[cbase + n];
         const double x = ((double)sig[a] - jb.mean) * (double)cv;
         if (resync) {
             const double cyc = jb.freq * ((double)t * inv_fs);
