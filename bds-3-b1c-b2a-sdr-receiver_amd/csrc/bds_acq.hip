@@ -504,8 +504,8 @@ static void launch_rows_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int 
     static bool attr = false;
     const size_t lds = sizeof(h2) * (((tspan<S>() + 3) & ~3) + half_table_entries<S>());
     if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_inv_h<S, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
-    hipLaunchKernelGGL((k_rows_inv_h<S, NC>), dim3(pl.L1 * G), dim3(rows_threads<S>()), lds, sr, (const h2 *)pl.d_htab2, pl.twl,
-                       (const __half2 *)Xs, pl.L, pl.L1, G, bin0, (const __half2 *)Cs, (__half2 *)Bw, in_scale);
+    const RowsHArgs A{(const h2 *)pl.d_htab2, pl.twl, (const __half2 *)Xs, pl.L, pl.L1, G, bin0, (const __half2 *)Cs, (__half2 *)Bw, in_scale};
+    hipLaunchKernelGGL((k_rows_inv_h<S, NC>), dim3(pl.L1 * G), dim3(rows_threads<S>()), lds, sr, A);
 }
 template <int S, int T, int NC>
 static void launch_cols_hh(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
@@ -513,8 +513,8 @@ static void launch_cols_hh(hipStream_t sc, const Plan2D &pl, int G, const void *
     static bool attr = false;
     const size_t lds = sizeof(h2) * (((T * tspan<S>() + 3) & ~3) + half_table_entries<S>());
     if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_h<S, T, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
-    hipLaunchKernelGGL((k_cols_inv_max_h<S, T, NC>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, (const h2 *)pl.d_htab1,
-                       pl.L2, (const __half2 *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
+    const ColsHArgs A{(const h2 *)pl.d_htab1, pl.L2, (const __half2 *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles};
+    hipLaunchKernelGGL((k_cols_inv_max_h<S, T, NC>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
 }
 template <int S, int NC>
 static void launch_cols_h(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
@@ -539,6 +539,35 @@ static void launch_fast_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int 
         case 768: launch_cols_h<768, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
         default: launch_cols_h<1024, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
     }
+}
+
+// Fused row(k+1) + column(k) launch.  Instantiated for the plan pairs the cost model picks at the
+// BASELINE configs; other specialised pairs run the two kernels back to back.
+template <int S2, int S1, int T, int NC>
+static void launch_fused_tt(hipStream_t st_, const Plan2D &pl, const RowsHArgs &RA, const ColsHArgs &CA, int nr, int nc) {
+    static bool attr = false;
+    const size_t lr = sizeof(h2) * (((tspan<S2>() + 3) & ~3) + half_table_entries<S2>());
+    const size_t lc = sizeof(h2) * (((T * tspan<S1>() + 3) & ~3) + half_table_entries<S1>());
+    const size_t lds = std::max(lr, lc);
+    if (!attr) (void)hipFuncSetAttribute((const void *)k_search_fused_h<S2, S1, T, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    hipLaunchKernelGGL((k_search_fused_h<S2, S1, T, NC>), dim3(8u * (unsigned)(nr + nc)), dim3(rows_threads<S2>()), lds, st_, RA, CA,
+                       nr, nc, pl.ntiles);
+}
+// Measured on MI355X: the fused launch wins on the small B2a plan (4.7 vs 5.7 ms per search: half
+// the launches, and its grids are short) and is neutral-to-worse on the B1C plan (287 vs 275 ms:
+// the mixed grid runs at the row pass's LDS footprint, which costs the column pass occupancy), so
+// the large plan only fuses on request (BDS_ACQ_FUSE=1).
+static bool fused_available(const Plan2D &pl) {
+    if (pl.logT != 2) return false;
+    if (pl.L2 == 1280 && pl.L1 == 256) return true;
+    return pl.L2 == 4096 && pl.L1 == 768 && std::getenv("BDS_ACQ_FUSE") != nullptr;
+}
+template <int NC>
+static void launch_fused(hipStream_t st_, const Plan2D &pl, const RowsHArgs &RA, const ColsHArgs &CA, int nr, int nc) {
+    if (pl.L2 == 4096)
+        launch_fused_tt<4096, 768, 4, NC>(st_, pl, RA, CA, nr, nc);
+    else
+        launch_fused_tt<1280, 256, 4, NC>(st_, pl, RA, CA, nr, nc);
 }
 
 // inter-pass work buffer: two halves of `group` cells each (float2-sized elements)
@@ -830,6 +859,43 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
                                pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
         }
     };
+    const bool fused = pl.fast && a.half && a.hmath && fused_available(pl) && !std::getenv("BDS_ACQ_NOFUSE");
+    if (fused) {
+        // chain of fused launches: launch k carries the row pass of group k and the column pass of
+        // group k-1 (the two use different halves of the inter-pass buffer)
+        struct Grp {
+            int pi, b0, nb;
+        };
+        std::vector<Grp> grps;
+        for (int pi = 0; pi < P; ++pi)
+            for (int b0 = 0; b0 < D; b0 += G) grps.push_back({pi, b0, std::min(G, D - b0)});
+        const size_t half_elems = (size_t)G * ncomp * pl.L;
+        const int ng = (int)grps.size();
+        for (int k = 0; k <= ng; ++k) {
+            RowsHArgs RA{};
+            ColsHArgs CA{};
+            int nr = 0, nc = 0;
+            if (k < ng) {
+                const Grp &gr = grps[k];
+                RA = RowsHArgs{(const h2 *)pl.d_htab2, pl.twl, (const __half2 *)a.d_Xs, pl.L, pl.L1, gr.nb, gr.b0,
+                               (const __half2 *)a.d_Cs + (size_t)a.cs_slot[prns[gr.pi]] * ncomp * pl.L,
+                               (__half2 *)a.d_Bw + (size_t)(k & 1) * half_elems, a.in_scale};
+                nr = pl.L1 * gr.nb / 8;
+            }
+            if (k >= 1) {
+                const Grp &gc = grps[k - 1];
+                CA = ColsHArgs{(const h2 *)pl.d_htab1, pl.L2, (const __half2 *)a.d_Bw + (size_t)((k - 1) & 1) * half_elems,
+                               pl.L, w0, w1, 0, (int)a.N - 1, 1, 0,
+                               a.d_recs + ((size_t)gc.pi * D + gc.b0) * pl.ntiles, pl.ntiles};
+                nc = pl.ntiles * gc.nb / 8;
+            }
+            if (ncomp == 2)
+                launch_fused<2>(s_main, pl, RA, CA, nr, nc);
+            else
+                launch_fused<1>(s_main, pl, RA, CA, nr, nc);
+        }
+        pair_idx = ng;
+    } else
     for (int pi = 0; pi < P; ++pi) {
         for (int b0 = 0; b0 < D; b0 += G, ++pair_idx, ++group_idx) {
             const int nb = std::min(G, D - b0);

@@ -264,11 +264,28 @@ __device__ __forceinline__ void load_half_table(h2 *__restrict__ dst, const h2 *
     for (int i = tid; i < half_table_entries<S>(); i += NT) dst[i] = src[i];
 }
 
+struct RowsHArgs {
+    const h2 *htab;
+    TwiddleL twl;
+    const __half2 *Xs;
+    long L;
+    int L1, G, bin0;
+    const __half2 *Cs;
+    __half2 *Bw;
+    float in_scale;
+};
+
+// body of the fp16 row pass for virtual workgroup index vb (= 8*slot + xcd), thread tid < rows_threads<S>()
 template <int S, int NCOMP>
-__global__ __launch_bounds__(rows_threads<S>(), 4) void k_rows_inv_h(const h2 *__restrict__ htab, TwiddleL twl,
-                                                                   const __half2 *__restrict__ Xs, long L, int L1,
-                                                                   int G, int bin0, const __half2 *__restrict__ Cs,
-                                                                   __half2 *__restrict__ Bw, float in_scale) {
+__device__ __forceinline__ void rows_inv_h_body(const RowsHArgs &A, int vb, int tid) {
+    const h2 *__restrict__ htab = A.htab;
+    const TwiddleL twl = A.twl;
+    const __half2 *__restrict__ Xs = A.Xs;
+    const long L = A.L;
+    const int L1 = A.L1, G = A.G, bin0 = A.bin0;
+    const __half2 *__restrict__ Cs = A.Cs;
+    __half2 *__restrict__ Bw = A.Bw;
+    const float in_scale = A.in_scale;
     constexpr int NT = rows_threads<S>();
     constexpr int NB1 = S / 16;
     constexpr int MB1 = (NB1 + NT - 1) / NT;
@@ -277,9 +294,8 @@ __global__ __launch_bounds__(rows_threads<S>(), 4) void k_rows_inv_h(const h2 *_
     extern __shared__ __attribute__((aligned(16))) h2 ldsh[];  // tspan<S>() data + stage tables
     __shared__ float2 s_a[MBL], s_b[RL];
     h2 *tab = ldsh + ((tspan<S>() + 3) & ~3);
-    const int tid = threadIdx.x;
     load_half_table<S, NT>(tab, htab, tid);
-    const int xcd = blockIdx.x & 7, m = blockIdx.x >> 3;
+    const int xcd = vb & 7, m = vb >> 3;
     const int g = m % G, k1 = (m / G) * 8 + xcd;
     if (k1 >= L1) return;
     if (tid < MBL) s_a[tid] = twl.get<+1>((uint32_t)((long)k1 * NT * tid));
@@ -320,10 +336,28 @@ __global__ __launch_bounds__(rows_threads<S>(), 4) void k_rows_inv_h(const h2 *_
     }
 }
 
+struct ColsHArgs {
+    const h2 *htab;
+    int L2;
+    const __half2 *Bw;
+    long L;
+    float w0, w1;
+    int lo1, hi1, lo2, hi2;
+    Rec *recs;
+    int rec_stride;  // = tiles per cell
+};
+
+// body of the fp16 column pass for tile index tb (of ntb = tiles per cell) of cell g, thread tid < cols_threads<S,T>()
 template <int S, int T, int NCOMP>
-__global__ __launch_bounds__((cols_threads<S, T>()), 4) void k_cols_inv_max_h(
-    const h2 *__restrict__ htab, int L2, const __half2 *__restrict__ Bw, long L, float w0, float w1, int lo1, int hi1,
-    int lo2, int hi2, Rec *__restrict__ recs, int rec_stride) {
+__device__ __forceinline__ void cols_inv_max_h_body(const ColsHArgs &A, int tb, int ntb, int g, int tid) {
+    const h2 *__restrict__ htab = A.htab;
+    const int L2 = A.L2;
+    const __half2 *__restrict__ Bw = A.Bw;
+    const long L = A.L;
+    const float w0 = A.w0, w1 = A.w1;
+    const int lo1 = A.lo1, hi1 = A.hi1, lo2 = A.lo2, hi2 = A.hi2;
+    Rec *__restrict__ recs = A.recs;
+    const int rec_stride = A.rec_stride;
     constexpr int NT = cols_threads<S, T>();
     constexpr int SP = tspan<S>();
     constexpr int QG = T / 4;
@@ -333,12 +367,10 @@ __global__ __launch_bounds__((cols_threads<S, T>()), 4) void k_cols_inv_max_h(
     static_assert(T == 4 || T == 8, "tile width");
     extern __shared__ __attribute__((aligned(16))) h2 ldsh[];  // T * SP data + stage tables
     h2 *tab = ldsh + ((T * SP + 3) & ~3);
-    const int tid = threadIdx.x;
     load_half_table<S, NT>(tab, htab, tid);
     __shared__ float s_v[NT / 64];
     __shared__ int s_l[NT / 64];
-    const int tile = (int)xcd_remap(blockIdx.x, gridDim.x);
-    const int g = blockIdx.y;
+    const int tile = (int)xcd_remap((uint32_t)tb, (uint32_t)ntb);
     const int c0 = tile * T;
     const bool full_tile = c0 + T <= L2;
     const int hi_all = hi1 > hi2 ? hi1 : hi2;
@@ -417,6 +449,41 @@ __global__ __launch_bounds__((cols_threads<S, T>()), 4) void k_cols_inv_max_h(
         rr.v = bv;
         rr.lag = bl;
         recs[(long)g * rec_stride + tile] = rr;
+    }
+}
+
+template <int S, int NCOMP>
+__global__ __launch_bounds__(rows_threads<S>(), 4) void k_rows_inv_h(RowsHArgs A) {
+    rows_inv_h_body<S, NCOMP>(A, (int)blockIdx.x, (int)threadIdx.x);
+}
+
+template <int S, int T, int NCOMP>
+__global__ __launch_bounds__((cols_threads<S, T>()), 4) void k_cols_inv_max_h(ColsHArgs A) {
+    cols_inv_max_h_body<S, T, NCOMP>(A, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)threadIdx.x);
+}
+
+// ---- fused launch: row pass of cell group k+1 beside the column pass of group k -----------------
+// The row pass is HBM-bound (it writes the inter-pass buffer), the column pass VALU-bound; as
+// separate launches they run back to back.  Here one grid carries both kinds of workgroup,
+// interleaved in proportion (Bresenham over 8-wide "slots" so that workgroup b still lands on XCD
+// b % 8 with the slot's partners), and the CU's wave slots hold a mix of the two.  The two groups
+// use different halves of the inter-pass buffer.  nr / nc = row / column slots (workgroups / 8);
+// either may be 0 (first / last launch of the chain).
+template <int S2, int S1, int T, int NCOMP>
+__global__ __launch_bounds__(rows_threads<S2>(), 4) void k_search_fused_h(RowsHArgs RA, ColsHArgs CA, int nr, int nc,
+                                                                        int ntiles) {
+    static_assert(rows_threads<S2>() >= cols_threads<S1, T>(), "block size is the row pass's");
+    const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const long tot = (long)nr + nc;
+    const int sr = (int)(((long)slot * nr) / tot);          // row slots before this one
+    const bool is_row = (int)(((long)(slot + 1) * nr) / tot) > sr;
+    const int tid = threadIdx.x;
+    if (is_row) {
+        rows_inv_h_body<S2, NCOMP>(RA, sr * 8 + xcd, tid);
+    } else {
+        if (tid >= cols_threads<S1, T>()) return;  // surplus wave of the wider block
+        const int v = (slot - sr) * 8 + xcd;       // column workgroup index: cell-major
+        cols_inv_max_h_body<S1, T, NCOMP>(CA, v % ntiles, ntiles, v / ntiles, tid);
     }
 }
 
