@@ -312,6 +312,21 @@ __device__ __forceinline__ void rows_inv_h_body(const RowsHArgs &A, int vb, int 
             for (int q = 0; q < 16; ++q) xv[i][q] = ld_h(xr, bb + q * NB1) * sc;
         }
     }
+    // code-spectrum rows of every component: all global loads of the workgroup are in flight
+    // before the first transform starts
+    h2 cv[NCOMP][MB1][16];
+#pragma unroll
+    for (int comp = 0; comp < NCOMP; ++comp) {
+        const __half2 *cr = Cs + (long)comp * L + (long)k1 * S;
+#pragma unroll
+        for (int i = 0; i < MB1; ++i) {
+            const int bb = tid + i * NT;
+            if (NB1 % NT == 0 || bb < NB1) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) cv[comp][i][q] = ld_h(cr, bb + q * NB1);
+            }
+        }
+    }
     __syncthreads();
     // inter-pass twiddle W_L^(-k1 e) of this thread's outputs: built in fp32 (base * step_i * step_q),
     // rounded to fp16 once per row and shared by the components
@@ -327,9 +342,8 @@ __device__ __forceinline__ void rows_inv_h_body(const RowsHArgs &A, int vb, int 
     }
 #pragma unroll
     for (int comp = 0; comp < NCOMP; ++comp) {
-        const __half2 *cr = Cs + (long)comp * L + (long)k1 * S;
         h2 *dst = reinterpret_cast<h2 *>(Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S);
-        auto src = [&](int i, int q, int, int e) { return cmul(xv[i][q], ld_h(cr, e)); };
+        auto src = [&](int i, int q, int, int) { return cmul(xv[i][q], cv[comp][i][q]); };
         auto out = [&](int i, int q, int, int e, h2 v) { dst[e] = cmul(v, wo[i][q]); };
         TPlan<S>::template run<1, NT, +1>(ldsh, (const h2 *)tab, tid, src, out);
         if (comp + 1 < NCOMP) __syncthreads();
