@@ -188,7 +188,8 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32 search + f64 refinement",
+        "dtype": {0: "f32 search + f64 refinement", 1: "f32 search on f16-stored spectra + f64 refinement",
+                  2: "f16 search (packed v_pk_*_f16, f32 magnitudes) + f64 refinement"}[int(tm.get("half_storage", 0))],
         "data": "synthetic",
         "config": {"workload": label, "prns": p_total, "doppler_bins": n_bins, "n_circ": n_circ,
                    "fft_len": tm["fft_len"], "components": ncomp, "parallelism": f"prn-shard x{world}",
@@ -200,7 +201,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "GB per launch pair (PMC)", "algorithmic_GB_per_pair": bytes_per_pair / 1e9,
-                     "kernel": "k_rows_inv_t + k_cols_inv_max_t launch pair (one pair = %d (PRN, bin) cells)" % int(cells_per_pair),
+                     "kernel": "row-pass + column-pass launch pair (k_rows_inv_* + k_cols_inv_max_*; one pair = %d (PRN, bin) cells)" % int(cells_per_pair),
                      "pair_ms": pair_ms, "storage": "fp16 complex" if tm.get("half_storage") else "fp32 complex"},
     }
     if rank == 0:
