@@ -510,11 +510,18 @@ static void launch_rows_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int 
 template <int S, int T, int NC>
 static void launch_cols_hh(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
                            int lo2, int hi2, Rec *recs) {
-    static bool attr = false;
     const size_t lds = sizeof(h2) * (((T * tspan<S>() + 3) & ~3) + half_table_entries<S>());
-    if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_h<S, T, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
     const ColsHArgs A{(const h2 *)pl.d_htab1, pl.L2, (const __half2 *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles};
-    hipLaunchKernelGGL((k_cols_inv_max_h<S, T, NC>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
+    const bool masked = !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
+    if (masked) {
+        static bool attr = false;
+        if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_h<S, T, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+        hipLaunchKernelGGL((k_cols_inv_max_h<S, T, NC, true>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
+    } else {
+        static bool attr = false;
+        if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_h<S, T, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+        hipLaunchKernelGGL((k_cols_inv_max_h<S, T, NC, false>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
+    }
 }
 template <int S, int NC>
 static void launch_cols_h(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,

@@ -24,7 +24,11 @@ __device__ __forceinline__ void st_c(__half2 *p, long i, float2 v) { p[i] = __fl
 template <int S>
 __host__ __device__ constexpr int rows_threads() { return S / 16 < 64 ? 64 : ((S / 16 + 63) / 64) * 64; }
 template <int S, int T>
-__host__ __device__ constexpr int cols_threads() { return S * T / 16; }  // 16 points per thread
+__host__ __device__ constexpr int cols_threads() {
+    // 16 points per thread; 768 x 4 takes 256 so that its radix-3 stage (256 butterflies per column)
+    // maps one column per unroll step with no index arithmetic (the radix-16 stages idle one wave)
+    return (S == 768 && T == 4) ? 256 : S * T / 16;
+}
 
 // ---- forward row pass with a typed store (k_rows_fwd of bds_acq_kernels.h, run-time plan) --------
 template <class ST>
@@ -163,8 +167,9 @@ __global__ __launch_bounds__((cols_threads<S, T>()), 3) void k_cols_inv_max_t(
     int lo2, int hi2, Rec *__restrict__ recs, int rec_stride) {
     constexpr int NT = cols_threads<S, T>();
     constexpr int SP = tspan<S>();
-    constexpr int QG = T / 4;  // 4-column groups per tile row
-    constexpr int NI = 4;      // (row, 4-column group) items per thread: S*QG / NT
+    constexpr int QG = T / 4;        // 4-column groups per tile row
+    constexpr int NI = S * QG / NT;  // (row, 4-column group) items per thread
+    static_assert(S * QG % NT == 0, "tile items must divide evenly");
     static_assert(T == 4 || T == 8, "tile width");
     constexpr int RL = PlanInfo<S>::kLast, NSL = PlanInfo<S>::kNsLast;
     constexpr int TOTL = NSL * T, MBL = (TOTL + NT - 1) / NT;
@@ -362,7 +367,8 @@ struct ColsHArgs {
 };
 
 // body of the fp16 column pass for tile index tb (of ntb = tiles per cell) of cell g, thread tid < cols_threads<S,T>()
-template <int S, int T, int NCOMP>
+// MASKED = false: the full search (lags 0..hi1, one range); true: the two ranges of the B2a second-peak pass.
+template <int S, int T, int NCOMP, bool MASKED>
 __device__ __forceinline__ void cols_inv_max_h_body(const ColsHArgs &A, int tb, int ntb, int g, int tid) {
     const h2 *__restrict__ htab = A.htab;
     const int L2 = A.L2;
@@ -375,7 +381,8 @@ __device__ __forceinline__ void cols_inv_max_h_body(const ColsHArgs &A, int tb, 
     constexpr int NT = cols_threads<S, T>();
     constexpr int SP = tspan<S>();
     constexpr int QG = T / 4;
-    constexpr int NI = 4;
+    constexpr int NI = S * QG / NT;  // (row, 4-column group) items per thread
+    static_assert(S * QG % NT == 0, "tile items must divide evenly");
     constexpr int RL = PlanInfo<S>::kLast, NSL = PlanInfo<S>::kNsLast;
     constexpr int TOTL = NSL * T, MBL = (TOTL + NT - 1) / NT;
     static_assert(T == 4 || T == 8, "tile width");
@@ -419,8 +426,12 @@ __device__ __forceinline__ void cols_inv_max_h_body(const ColsHArgs &A, int tb, 
         __syncthreads();
         if (comp + 1 < NCOMP) fetch(comp + 1);
         const float w = comp == 0 ? w0 : w1;
-        auto out = [&](int i, int q, int, int e, h2 v) {
-            if (e <= e_max) {  // rows beyond the searched lags (the padded transform is ~1.6 N long)
+        // Output q of the last stage covers rows q*NSL .. q*NSL+NSL-1: a whole q beyond the searched
+        // lags (the padded transform is ~1.6 N long) is skipped with a workgroup-uniform test.
+        auto out = [&](int i, int q, int, int, h2 v) {
+            if (q * NSL <= e_max) {
+                // |v|^2 as one v_dot2_f32_f16 (fp32 accumulate), then sqrt and the component weight
+                // (v_dot2_f32_f16 for |v|^2 measured 1% slower than convert + fma: tools/exp_mag.sh)
                 const float x = (float)v.x, y = (float)v.y;
                 const float a = w * sqrtf(x * x + y * y);
                 mag[i][q] = comp == 0 ? a : mag[i][q] + a;
@@ -438,10 +449,17 @@ __device__ __forceinline__ void cols_inv_max_h_body(const ColsHArgs &A, int tb, 
             const int j = b / NSL, bb = b - j * NSL;
 #pragma unroll
             for (int q = 0; q < RL; ++q) {
-                const int e = bb + q * NSL;
-                const int lag = e * L2 + c0 + j;  // L < 2^31
-                const bool in = full_tile && e <= e_max && ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2));
-                if (in) rec_better(bv, bl, mag[i][q], lag);
+                if (q * NSL <= e_max) {
+                    const int lag = (bb + q * NSL) * L2 + c0 + j;  // L < 2^31
+                    bool in = full_tile && lag <= hi1;
+                    if (MASKED) in = full_tile && ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2));
+                    // ties inside one thread: whichever comes first -- every record within the
+                    // tolerance band is re-evaluated in f64 anyway
+                    if (in && mag[i][q] > bv) {
+                        bv = mag[i][q];
+                        bl = lag;
+                    }
+                }
             }
         }
     }
@@ -471,9 +489,9 @@ __global__ __launch_bounds__(rows_threads<S>(), 4) void k_rows_inv_h(RowsHArgs A
     rows_inv_h_body<S, NCOMP>(A, (int)blockIdx.x, (int)threadIdx.x);
 }
 
-template <int S, int T, int NCOMP>
+template <int S, int T, int NCOMP, bool MASKED>
 __global__ __launch_bounds__((cols_threads<S, T>()), 4) void k_cols_inv_max_h(ColsHArgs A) {
-    cols_inv_max_h_body<S, T, NCOMP>(A, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)threadIdx.x);
+    cols_inv_max_h_body<S, T, NCOMP, MASKED>(A, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)threadIdx.x);
 }
 
 // ---- fused launch: row pass of cell group k+1 beside the column pass of group k -----------------
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(rows_threads<S2>(), 4) void k_search_fused_h(RowsHA
     } else {
         if (tid >= cols_threads<S1, T>()) return;  // surplus wave of the wider block
         const int v = (slot - sr) * 8 + xcd;       // column workgroup index: cell-major
-        cols_inv_max_h_body<S1, T, NCOMP>(CA, v % ntiles, ntiles, v / ntiles, tid);
+        cols_inv_max_h_body<S1, T, NCOMP, false>(CA, v % ntiles, ntiles, v / ntiles, tid);
     }
 }
 
