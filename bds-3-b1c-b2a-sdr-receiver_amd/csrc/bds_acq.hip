@@ -270,6 +270,8 @@ struct AcqState {
     long n_samples = 0;
     std::vector<int8_t> h_sig;
     std::vector<int64_t> h_prefix;  // prefix sums of the samples (exact DC means)
+    std::vector<int64_t> h_prefix_q;  // ... of the Q samples (fileType 2)
+    bool cplx = false;              // longSignal = I + 1i*Q (postProcessing.m:92-96), stored as int8 pairs
     int8_t *d_prim = nullptr;       // [63][2][code_len]
     float2 *d_Cs = nullptr;         // [slots][ncomp][L]
     size_t cs_cap_slots = 0;
@@ -588,8 +590,8 @@ using namespace bds;
 extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s, const int8_t *samples, size_t n_samples,
                             int is_complex) {
     if (!ctx || !s || !samples) return BDS_ERR_ARG;
-    if (is_complex || s->fileType == 2)
-        return fail(ctx, BDS_ERR_UNSUPPORTED, "fileType 2 (interleaved I/Q) acquisition input is not built yet");
+    // n_samples counts complex samples when is_complex: `samples` then holds 2*n_samples int8 (I,Q pairs)
+    const bool cplx = is_complex != 0;
     int rc = acq_configure(ctx, *s);
     if (rc) return rc;
     AcqState &a = *ctx->acq;
@@ -597,17 +599,30 @@ extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s, const int8_t *s
         return fail(ctx, BDS_ERR_ARG, "longSignal has %zu samples; acquisition needs at least %ld (acquisition.m:140)",
                     n_samples, a.N);
     BDS_HIP(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure(ctx, &a.d_sig, &a.sig_cap, n_samples))) return rc;
-    BDS_HIP(ctx, hipMemcpyAsync(a.d_sig, samples, n_samples, hipMemcpyHostToDevice, st(ctx)));
-    a.h_sig.assign(samples, samples + n_samples);
+    const size_t nb = n_samples * (cplx ? 2 : 1);
+    if ((rc = ensure(ctx, &a.d_sig, &a.sig_cap, nb))) return rc;
+    BDS_HIP(ctx, hipMemcpyAsync(a.d_sig, samples, nb, hipMemcpyHostToDevice, st(ctx)));
+    a.cplx = cplx;
+    a.h_sig.assign(samples, samples + nb);
     a.h_prefix.resize(n_samples + 1);
     a.h_prefix[0] = 0;
-    for (size_t i = 0; i < n_samples; ++i) a.h_prefix[i + 1] = a.h_prefix[i] + samples[i];
+    a.h_prefix_q.clear();
+    if (cplx) {
+        a.h_prefix_q.resize(n_samples + 1);
+        a.h_prefix_q[0] = 0;
+        for (size_t i = 0; i < n_samples; ++i) {
+            a.h_prefix[i + 1] = a.h_prefix[i] + samples[2 * i];
+            a.h_prefix_q[i + 1] = a.h_prefix_q[i] + samples[2 * i + 1];
+        }
+    } else {
+        for (size_t i = 0; i < n_samples; ++i) a.h_prefix[i + 1] = a.h_prefix[i] + samples[i];
+    }
     a.n_samples = (long)n_samples;
     a.sum_abs_ext = a.sum_sq_ext = 0;
     for (long i = 0; i < a.n_ext; ++i) {
-        const double v = (double)samples[i < a.N ? i : i - a.N];
-        a.sum_abs_ext += std::fabs(v);
+        const long m = i < a.N ? i : i - a.N;
+        const double v = cplx ? std::hypot((double)samples[2 * m], (double)samples[2 * m + 1]) : std::fabs((double)samples[m]);
+        a.sum_abs_ext += v;
         a.sum_sq_ext += v * v;
     }
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
@@ -700,7 +715,7 @@ static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vecto
         a.jobs_cap = cap;
     }
     BDS_HIP(ctx, hipMemcpyAsync(a.d_jobs, jobs.data(), sizeof(CorrJob) * jobs.size(), hipMemcpyHostToDevice, st(ctx)));
-    hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size()), dim3(256), 0, st(ctx), (const int8_t *)a.d_sig, a.N,
+    hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size()), dim3(256), 0, st(ctx), (const int8_t *)a.d_sig, a.cplx ? 1 : 0, a.N,
                        (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
     BDS_HIP(ctx, hipGetLastError());
     BDS_HIP(ctx, hipMemcpyAsync(out.data(), a.d_jobout, sizeof(double2) * jobs.size(), hipMemcpyDeviceToHost, st(ctx)));
@@ -796,7 +811,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
         const int chunk = (int)bw_batches(a);
         for (int b0 = 0; b0 < D; b0 += chunk) {
             const int nb = std::min(chunk, D - b0);
-            SignalLoader ld{a.d_sig, a.N, a.n_ext, f0, s->acqStep, 1.0 / a.fs, b0};
+            SignalLoader ld{a.d_sig, a.N, a.n_ext, f0, s->acqStep, 1.0 / a.fs, b0, a.cplx ? 1 : 0};
             float2 *xs_dst = a.half ? (float2 *)((__half2 *)a.d_Xs + (size_t)b0 * pl.L) : a.d_Xs + (size_t)b0 * pl.L;
             if ((rc = forward(ctx, a, ld, nb, xs_dst, pl.L, 0, a.sX))) return rc;
         }
@@ -1032,11 +1047,18 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     // ---- detection metric -----------------------------------------------------------------
     if (a.signal == BDS_SIGNAL_B1C) {
         // sigPower = sqrt(var(sig(1:X)) * X), unbiased variance (B1C/acquisition.m:150)
+        // (complex input: var = sum |x - mean|^2 / (X-1), as MATLAB's var of a complex vector)
         const double mean = (double)(a.h_prefix[a.X] - a.h_prefix[0]) / (double)a.X;
+        const double mean_q = a.cplx ? (double)(a.h_prefix_q[a.X] - a.h_prefix_q[0]) / (double)a.X : 0.0;
         long double acc = 0;
         for (long i = 0; i < a.X; ++i) {
-            const double d = (double)a.h_sig[i] - mean;
-            acc += (long double)(d * d);
+            if (a.cplx) {
+                const double d = (double)a.h_sig[2 * i] - mean, dq = (double)a.h_sig[2 * i + 1] - mean_q;
+                acc += (long double)(d * d + dq * dq);
+            } else {
+                const double d = (double)a.h_sig[i] - mean;
+                acc += (long double)(d * d);
+            }
         }
         const double var = (double)(acc / (long double)(a.X - 1));
         const double sigPower = std::sqrt(var * (double)a.X);
@@ -1121,6 +1143,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
                 return fail(ctx, BDS_ERR_ARG, "PRN %d: fine-search block %ld..%ld outside longSignal (B1C/acquisition.m:253)",
                             prns[pi], r.codePhase, r.codePhase + a.spc - 1);
             const double mean = (double)(a.h_prefix[r.codePhase - 1 + a.spc] - a.h_prefix[r.codePhase - 1]) / (double)a.spc;  // :254
+            const double mean_q = a.cplx ? (double)(a.h_prefix_q[r.codePhase - 1 + a.spc] - a.h_prefix_q[r.codePhase - 1]) / (double)a.spc : 0.0;
             for (int kf = 0; kf < nfine; ++kf) {
                 const double f = fb - s->acqStep + 25.0 * kf;  // :282-283
                 fine_frq[pi].push_back(f);
@@ -1130,6 +1153,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
                     j.len = a.spc;
                     j.freq = f;
                     j.mean = mean;
+                    j.mean_q = mean_q;
                     j.slot = (prns[pi] - 1) * 2 + comp;
                     j.circ = 0;
                     j.mode = 0;

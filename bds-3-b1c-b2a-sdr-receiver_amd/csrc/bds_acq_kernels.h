@@ -29,10 +29,18 @@ struct SignalLoader {
     double f0, fstep; // bin frequency = f0 + fstep*batch  [Hz]
     double inv_fs;    // 1/fs
     int bin0;         // first bin of this launch
+    int cplx;         // sig holds (I,Q) int8 pairs: x = I + 1i*Q (fileType 2, postProcessing.m:92-96)
     __device__ __forceinline__ float2 operator()(int batch, long n) const {
         if (n >= n_ext) return make_float2(0.f, 0.f);
         const long m = n < n_circ ? n : n - n_circ;
-        const float x = (float)sig[m];
+        float x, xq = 0.f;
+        if (cplx) {
+            const char2 v = reinterpret_cast<const char2 *>(sig)[m];
+            x = (float)v.x;
+            xq = (float)v.y;
+        } else {
+            x = (float)sig[m];
+        }
         const double f = f0 + fstep * (double)(bin0 + batch);
         const double cyc = f * ((double)m * inv_fs);
         const double fr = cyc - floor(cyc);
@@ -41,7 +49,8 @@ struct SignalLoader {
         float s, c;
         sincospif(2.0f * hi, &s, &c);
         const float d = 6.28318530717958647692f * lo;  // first-order correction for the fp32 rounding of fr
-        return make_float2(x * (c - d * s), x * (s + d * c));
+        const float cc = c - d * s, ss = s + d * c;
+        return make_float2(x * cc - xq * ss, x * ss + xq * cc);
     }
 };
 
@@ -340,13 +349,14 @@ struct CorrJob {
     long code_k0;   // mode 1: offset of this segment inside the long code
     double freq;    // [Hz]
     double mean;    // subtracted from every sample (B1C/acquisition.m:254), else 0
+    double mean_q;  // ... from the Q part of a complex sample
     int slot;       // code slot (prn_idx*ncomp + comp)
     int circ;
     int mode;
     int pad;
 };
 
-__global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig, long n_circ,
+__global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig, int cplx, long n_circ,
                                                   const int8_t *__restrict__ codes, long code_stride,
                                                   double inv_fs, const CorrJob *__restrict__ jobs,
                                                   double2 *__restrict__ out) {
@@ -372,7 +382,14 @@ __global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig
             t = a;
         }
         const int8_t cv = codes[cbase + n];
-        const double x = ((double)sig[a] - jb.mean) * (double)cv;
+        double x, xq = 0.0;
+        if (cplx) {
+            const char2 v = reinterpret_cast<const char2 *>(sig)[a];
+            x = ((double)v.x - jb.mean) * (double)cv;
+            xq = ((double)v.y - jb.mean_q) * (double)cv;
+        } else {
+            x = ((double)sig[a] - jb.mean) * (double)cv;
+        }
         if (resync) {
             const double cyc = jb.freq * ((double)t * inv_fs);
             sincospi(2.0 * (cyc - floor(cyc)), &ci, &cr);
@@ -381,8 +398,8 @@ __global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig
             ci = cr * wi + ci * wr;
             cr = nr;
         }
-        sr += x * cr;
-        si += x * ci;
+        sr += x * cr - xq * ci;
+        si += x * ci + xq * cr;
     }
     __shared__ double s_r[256], s_i[256];
     s_r[threadIdx.x] = sr;

@@ -35,7 +35,7 @@ struct ChanState {
     double codeFreq, remCodePhase, carrFreq, carrFreqBasis, remCarrPhase;
     double oldCodeNco, oldCodeError, d2CarrError, dCarrError;
     double codeFreqBasis;  // channel.codeFreq (tracking.m:389)
-    long long pos;         // byte/sample offset of the next read (ftell, fileType 1)
+    long long pos;         // sample offset of the next read: ftell / dataAdaptCoeff (tracking.m:226)
     int prn;               // 0 = channel unused
     int active;            // 1 while the channel keeps tracking
     int completed;         // epochs finished
@@ -45,12 +45,14 @@ struct ChanState {
 struct TrkParams {
     int mode;        // BDS_TRACK_*
     int pilot;       // pilot correlators on
+    int cplx;        // fileType 2: the record is interleaved I/Q int8 pairs (tracking.m:132-136,242-246)
+    int pad;
     int code_len;    // 10230
     int n_epochs;
     double fs, inv_fs;
     double spacing;  // dllCorrelatorSpacing (earlyLateSpc)
     double tau1, tau2, pdi, pf1, pf2, pf3, factor;
-    long long n_bytes;
+    long long n_bytes;  // samples in the record: file bytes / dataAdaptCoeff
 };
 
 struct TrkOut {  // device arrays [n_ch][n_epochs]
@@ -115,7 +117,14 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
 #pragma unroll
     for (int i = 0; i < kNSums; ++i) acc[i] = 0.f;
     for (long k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
-        const float raw = (float)data[g.pos + k];
+        float raw, raw_q = 0.f;
+        if (p.cplx) {  // rawSignal = data(1:2:end) + 1i*data(2:2:end)  (tracking.m:242-246)
+            const char2 v = reinterpret_cast<const char2 *>(data)[g.pos + k];
+            raw = (float)v.x;
+            raw_q = (float)v.y;
+        } else {
+            raw = (float)data[g.pos + k];
+        }
         const double kd = (double)k;
         const double te = st_e + kd * inc, tl = st_l + kd * inc, tp = st_p + kd * inc;
         const long ie = (long)ceil(te) + 1, il = (long)ceil(tl) + 1, ip = (long)ceil(tp) + 1;
@@ -129,11 +138,11 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
         const float c2 = cs - d * sn, s2 = sn + d * cs;
         float ib, qb;
         if (MODE == BDS_TRACK_B2A) {  // exp(+j th): q = real, i = imag (tracking.m:309-314)
-            qb = raw * c2;
-            ib = raw * s2;
+            qb = raw * c2 - raw_q * s2;
+            ib = raw * s2 + raw_q * c2;
         } else {  // exp(-j th): i = real, q = imag (NB_tracking.m:320-325)
-            ib = raw * c2;
-            qb = -raw * s2;
+            ib = raw * c2 + raw_q * s2;
+            qb = raw_q * c2 - raw * s2;
         }
         const float ce = code_at<UNITS>(prim_d, p.code_len, ie);
         const float cp = code_at<UNITS>(prim_d, p.code_len, ip);
@@ -418,7 +427,7 @@ static int ensure_prim(bds_ctx *ctx, TrackState &t, int signal) {
 
 static int fill_params(bds_ctx *ctx, const bds_settings &s, TrkParams &p, int n_epochs, size_t n_bytes) {
     if (s.signal != BDS_SIGNAL_B1C && s.signal != BDS_SIGNAL_B2A) return fail(ctx, BDS_ERR_ARG, "settings.signal invalid");
-    if (s.fileType != 1) return fail(ctx, BDS_ERR_UNSUPPORTED, "fileType 2 (interleaved I/Q) tracking input is not built yet");
+    if (s.fileType != 1 && s.fileType != 2) return fail(ctx, BDS_ERR_ARG, "settings.fileType must be 1 (real) or 2 (I/Q)");
     if (s.codeLength != 10230 || !(s.samplingFreq > 0) || !(s.intTime > 0))
         return fail(ctx, BDS_ERR_ARG, "settings.codeLength/samplingFreq/intTime invalid");
     p.mode = track_mode(s);
@@ -432,7 +441,9 @@ static int fill_params(bds_ctx *ctx, const bds_settings &s, TrkParams &p, int n_
     bds_calc_loop_coef_carr(&s, &p.pf3, &p.pf2, &p.pf1);                                 // :116
     p.pdi = s.intTime;                                                                   // :107
     p.factor = p.mode == BDS_TRACK_WB ? bds_calc_weighing_factor(&s) : 0.0;              // WB_tracking.m:138
-    p.n_bytes = (long long)n_bytes;
+    p.cplx = s.fileType == 2;
+    p.pad = 0;
+    p.n_bytes = (long long)(n_bytes / (p.cplx ? 2 : 1));  // whole samples an fread can deliver
     return BDS_OK;
 }
 

@@ -45,8 +45,13 @@ def random_sats(rng, prns, spc, cn0_dbhz=45.0, max_doppler=4500.0):
 
 
 def make_if(settings, sats, n_samples, seed=3550, sigma=20.0, codegen=None, chunk=1 << 22,
-            out=None):
-    """Return int8[n_samples] of real IF samples (fileType 1)."""
+            out=None, iq_sign=0):
+    """Return int8[n_samples] of real IF samples (fileType 1), or -- iq_sign = +1 / -1 --
+    int8[2*n_samples] of interleaved I/Q pairs (fileType 2) holding the analytic signal
+    a(t) e^{+j th} (iq_sign +1) or its conjugate (iq_sign -1).  The reference mixes with
+    exp(+j th) in both acquisition.m files and B2a/tracking.m (:309) and with exp(-j th) in
+    B1C/{NB,WB}_tracking.m (:320 / :341), so a complex record needs iq_sign -1 for the former
+    and +1 for the latter to correlate."""
     codegen = codegen or default_codegen()
     rng = np.random.default_rng(seed)
     fs = float(settings.samplingFreq)
@@ -60,11 +65,13 @@ def make_if(settings, sats, n_samples, seed=3550, sigma=20.0, codegen=None, chun
     syms = {s.prn: (rng.choice([-1.0, 1.0], n_periods).astype(np.float32),
                     rng.choice([-1.0, 1.0], n_periods).astype(np.float32)) for s in sats}
     if out is None:
-        out = np.empty(n_samples, dtype=np.int8)
+        out = np.empty(n_samples * (2 if iq_sign else 1), dtype=np.int8)
     for a in range(0, n_samples, chunk):
         b = min(n_samples, a + chunk)
         n = np.arange(a, b, dtype=np.float64)
         acc = rng.normal(0.0, sigma, b - a)
+        if iq_sign:
+            acc = acc + 1j * rng.normal(0.0, sigma, b - a)
         for s in sats:
             amp = sigma * np.sqrt(4.0 * 10 ** (s.cn0_dbhz / 10) / fs)
             fcode = fc * (1.0 + s.doppler / float(settings.carrFreqBasis))
@@ -83,8 +90,17 @@ def make_if(settings, sats, n_samples, seed=3550, sigma=20.0, codegen=None, chun
                 boc61 = np.where(sub12 % 2 == 0, -1.0, 1.0)
                 s_i = 0.5 * d_sym * cd * boc11 - np.sqrt(1 / 11) * cp * boc61
                 s_q = np.sqrt(29 / 44) * cp * boc11 * p_sym
-                acc += amp * (s_i * np.cos(th) - s_q * np.sin(th))
+                base = s_i + 1j * s_q
+            else:  # d sin(th) + p cos(th) = Re[(p - j d) e^{j th}]
+                base = p_sym * cp - 1j * (d_sym * cd)
+            z = amp * base * np.exp(1j * th)
+            if iq_sign:
+                acc += z if iq_sign > 0 else np.conj(z)
             else:
-                acc += amp * (d_sym * cd * np.sin(th) + p_sym * cp * np.cos(th))
-        out[a:b] = np.clip(np.rint(acc), -127, 127).astype(np.int8)
+                acc += z.real
+        if iq_sign:
+            out[2 * a:2 * b:2] = np.clip(np.rint(acc.real), -127, 127).astype(np.int8)
+            out[2 * a + 1:2 * b:2] = np.clip(np.rint(acc.imag), -127, 127).astype(np.int8)
+        else:
+            out[a:b] = np.clip(np.rint(acc), -127, 127).astype(np.int8)
     return out

@@ -9,7 +9,8 @@
  *       LDFLAGS='$LDFLAGS -Wl,-rpath,/opt/rocm/lib'
  *
  * Usage from the drop-in wrappers in this directory:
- *   [carrFreq, codePhase, peakMetric, detected] = bds_mex('acquire', int8(longSignal), settings, signal)
+ *   [carrFreq, codePhase, peakMetric, detected] = bds_mex('acquire', int8(longSignal), settings, signal, iq)
+ *       iq (optional, default false): longSignal holds interleaved I/Q pairs (fileType 2)
  *   out = bds_mex('track', path, channel, settings, signal)        % struct of [nCh x nEpochs] arrays
  *   code = bds_mex('gen_code', signal, kind, prn)
  * signal: 1 = B1C, 2 = B2a (the reference keeps one directory per receiver).
@@ -85,9 +86,11 @@ static void pack_settings(const mxArray *s, int signal, bds_settings *o) {
 
 static void do_acquire(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     bds_settings s;
-    int max_prn = 0, i, rc;
+    int max_prn = 0, i, rc, iq;
     mxArray *det;
-    if (nrhs != 4 || !mxIsInt8(prhs[1])) mexErrMsgIdAndTxt("bds:args", "acquire: (int8 longSignal, settings, signal)");
+    if ((nrhs != 4 && nrhs != 5) || !mxIsInt8(prhs[1]))
+        mexErrMsgIdAndTxt("bds:args", "acquire: (int8 longSignal, settings, signal[, iq])");
+    iq = nrhs == 5 && mxGetScalar(prhs[4]) != 0;
     pack_settings(prhs[2], (int)mxGetScalar(prhs[3]), &s);
     for (i = 0; i < s.n_acq; ++i)
         if (s.acqSatelliteList[i] > max_prn) max_prn = s.acqSatelliteList[i];
@@ -95,7 +98,7 @@ static void do_acquire(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[
     plhs[1] = mxCreateDoubleMatrix(1, max_prn, mxREAL);
     plhs[2] = mxCreateDoubleMatrix(1, max_prn, mxREAL);
     det = mxCreateNumericMatrix(1, max_prn, mxINT32_CLASS, mxREAL);
-    rc = bds_acquire(ctx(), &s, (const int8_t *)mxGetInt8s(prhs[1]), mxGetNumberOfElements(prhs[1]), 0, max_prn,
+    rc = bds_acquire(ctx(), &s, (const int8_t *)mxGetInt8s(prhs[1]), mxGetNumberOfElements(prhs[1]) / (iq ? 2 : 1), iq, max_prn,
                      mxGetDoubles(plhs[0]), mxGetDoubles(plhs[1]), mxGetDoubles(plhs[2]), (int32_t *)mxGetInt32s(det));
     if (rc) mexErrMsgIdAndTxt("bds:acquire", "%s", bds_last_error(g_ctx));
     if (nlhs > 3)

@@ -209,7 +209,8 @@ def acquisition_b1c(long_signal, settings, diag=None):
                              row_max=row_max.copy(), row_arg=row_arg + 1)
         if peak / sig_power > settings.acqThreshold:  # :244
             data_tab = codes.make_data_table(settings, prn)
-            sig0 = np.asarray(long_signal[code_phase - 1: code_phase - 1 + spc], dtype=np.float64)
+            sig0 = np.asarray(long_signal[code_phase - 1: code_phase - 1 + spc])
+            sig0 = sig0.astype(np.complex128 if np.iscomplexobj(sig0) else np.float64)
             sig0 = sig0 - np.mean(sig0)  # :253-254
             xc = sig0 * data_tab  # :257
             if settings.pilotACQflag == 1:

@@ -21,7 +21,10 @@ def m_rem(x, y):
 
 def m_var(x: np.ndarray) -> float:
     """MATLAB var(): normalised by N-1."""
-    return float(np.var(np.asarray(x, dtype=np.float64), ddof=1))
+    x = np.asarray(x)
+    if np.iscomplexobj(x):  # var of a complex vector: sum |x - mean|^2 / (N-1), real
+        return float(np.var(x.astype(np.complex128), ddof=1))
+    return float(np.var(x.astype(np.float64), ddof=1))
 
 
 def m_max_first(x: np.ndarray):

@@ -9,14 +9,14 @@ import pytest
 import bds_amd
 from oracle import acquisition as oacq
 
-from helpers import cfg1_b2a, medium_b2a, small_b1c
+from helpers import as_complex, cfg1_b2a, cfg1_b2a_iq, medium_b2a, small_b1c, small_b1c_iq
 
 pytestmark = pytest.mark.gpu
 
 
 def _compare(s, x, ctx, oracle_fn):
     diag = {}
-    ref = oracle_fn(x.astype(np.float64), s, diag)
+    ref = oracle_fn(x.astype(np.complex128 if np.iscomplexobj(x) else np.float64), s, diag)
     got = bds_amd.acquisition(x, s)
     sats = [int(p) for p in s.acqSatelliteList]
     np.testing.assert_array_equal(got.codePhase, ref.codePhase)
@@ -58,6 +58,21 @@ def test_b1c_data_only_and_short_coherent(ctx):
     s, x, _ = small_b1c(prns=(3, 7), band=300)
     s = s.copy(pilotACQflag=0, acqCohT=5, acqStep=100)
     _compare(s, x, ctx, oacq.acquisition_b1c)
+
+
+def test_b2a_complex_iq_record(ctx):
+    """fileType 2: longSignal = I + 1i*Q (B2a/postProcessing.m:92-96)."""
+    s, x, sats = cfg1_b2a_iq()
+    ref, got = _compare(s, as_complex(x), ctx, oacq.acquisition_b2a)
+    assert got.carrFreq[18] != 0 and got.carrFreq[19] != 0 and got.carrFreq[20] == 0
+    for sat in sats:
+        assert abs(got.carrFreq[sat.prn - 1] - (s.IF + sat.doppler)) <= 25
+
+
+def test_b1c_complex_iq_record(ctx):
+    s, x, _ = small_b1c_iq()
+    ref, got = _compare(s, as_complex(x), ctx, oacq.acquisition_b1c)
+    assert got.carrFreq[2] != 0 and got.carrFreq[6] == 0
 
 
 def test_prn_shards_sum_to_the_full_result(ctx):

@@ -14,12 +14,14 @@ from helpers import track_case
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("B2A", "B2A", 60), ("B1C", "NB", 12), ("B1C", "WB", 12)]
+CASES = [("B2A", "B2A", 60, False), ("B1C", "NB", 12, False), ("B1C", "WB", 12, False),
+         # fileType 2: interleaved I/Q record (tracking.m:132-136,242-246)
+         ("B2A", "B2A", 40, True), ("B1C", "NB", 8, True), ("B1C", "WB", 8, True)]
 
 
-@pytest.mark.parametrize("signal,mode,n_epochs", CASES)
-def test_open_loop_correlators(ctx, signal, mode, n_epochs):
-    s, x, chans = track_case(signal, mode, n_epochs)
+@pytest.mark.parametrize("signal,mode,n_epochs,iq", CASES)
+def test_open_loop_correlators(ctx, signal, mode, n_epochs, iq):
+    s, x, chans = track_case(signal, mode, n_epochs, iq=iq)
     trace = []
     otrk.tracking(otrk.RawFile(x), chans, s, mode=mode, trace=trace)
     assert len(trace) == n_epochs * len(chans)
@@ -33,9 +35,9 @@ def test_open_loop_correlators(ctx, signal, mode, n_epochs):
             np.testing.assert_allclose(g, t["sums"], rtol=0, atol=1e-6 * p)
 
 
-@pytest.mark.parametrize("signal,mode,n_epochs", CASES)
-def test_closed_loop_tracking(ctx, signal, mode, n_epochs):
-    s, x, chans = track_case(signal, mode, n_epochs)
+@pytest.mark.parametrize("signal,mode,n_epochs,iq", CASES)
+def test_closed_loop_tracking(ctx, signal, mode, n_epochs, iq):
+    s, x, chans = track_case(signal, mode, n_epochs, iq=iq)
     ref, _ = otrk.tracking(otrk.RawFile(x), chans, s, mode=mode)
     got, _ = bds_amd.tracking(x, chans, s, mode=mode)
     for r, g in zip(ref, got):
