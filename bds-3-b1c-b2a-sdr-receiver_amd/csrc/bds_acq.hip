@@ -297,7 +297,11 @@ struct AcqState {
     std::vector<float> h_rowmax;
     std::vector<int> h_rowarg;
     std::map<int, PrnResult> last;
-    int group = 16;            // (PRN, bin) cells per launch pair (measured: 1 -> 41, 4 -> 25, 8 -> 23.6, 16 -> 22.9 us/cell)
+    // (PRN, bin) cells per launch pair; 0 = all Doppler bins of the PRN that fit the work-buffer budget.
+    // Measured on the B1C plan (us/cell): 1 -> 41, 4 -> 25, 16 -> 21 without the row-pass cell loop;
+    // with it 16 -> 17.5, 48 -> 16.5, 201 -> 15.9 (tools/exp_gchunk.sh)
+    int group_env = 0;
+    int group = 16;
     bool half = false;         // spectra + inter-pass buffer stored as fp16 complex (specialised plans only)
     bool hmath = false;        // ... and the search arithmetic itself in packed fp16 (k_*_h kernels)
     float in_scale = 1.f;      // power of two applied to the spectrum row on load (fp16 arithmetic)
@@ -387,7 +391,7 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
     a.n_ext = N + X - 1;
     a.ncomp = ncomp;
     if ((rc = plan_build(ctx, a.plan, a.n_ext))) return rc;
-    if (const char *g = std::getenv("BDS_ACQ_GROUP")) a.group = std::max(1, std::min(64, atoi(g)));
+    if (const char *g = std::getenv("BDS_ACQ_GROUP")) a.group_env = std::max(1, std::min(1024, atoi(g)));
     a.half = a.plan.fast;
     if (const char *h = std::getenv("BDS_ACQ_FP16")) a.half = a.plan.fast && atoi(h) != 0;
     a.hmath = a.half;
@@ -500,14 +504,27 @@ static void launch_fast(hipStream_t sr, hipStream_t sc, hipEvent_t ev_rows, hipE
 }
 
 // ---- fp16-arithmetic search kernels ---------------------------------------------------------------
+// cells of a group one row-pass workgroup walks through (BDS_ACQ_GCHUNK overrides)
+static int rows_cells_per_wg() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = std::getenv("BDS_ACQ_GCHUNK");
+        v = e ? std::atoi(e) : 34;
+        if (v < 1) v = 1;
+    }
+    return v;
+}
 template <int S, int NC>
 static void launch_rows_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
                           float in_scale) {
     static bool attr = false;
     const size_t lds = sizeof(h2) * (((tspan<S>() + 3) & ~3) + half_table_entries<S>());
     if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_inv_h<S, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
-    const RowsHArgs A{(const h2 *)pl.d_htab2, pl.twl, (const __half2 *)Xs, pl.L, pl.L1, G, bin0, (const __half2 *)Cs, (__half2 *)Bw, in_scale};
-    hipLaunchKernelGGL((k_rows_inv_h<S, NC>), dim3(pl.L1 * G), dim3(rows_threads<S>()), lds, sr, A);
+    // balanced chunks of at most rows_cells_per_wg() cells
+    const int nch = (G + rows_cells_per_wg() - 1) / rows_cells_per_wg();
+    const int gc = (G + nch - 1) / nch;
+    const RowsHArgs A{(const h2 *)pl.d_htab2, pl.twl, (const __half2 *)Xs, pl.L, pl.L1, G, bin0, (const __half2 *)Cs, (__half2 *)Bw, in_scale, gc, nch};
+    hipLaunchKernelGGL((k_rows_inv_h<S, NC>), dim3(pl.L1 * nch), dim3(rows_threads<S>()), lds, sr, A);
 }
 template <int S, int T, int NC>
 static void launch_cols_hh(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
@@ -582,6 +599,16 @@ static void launch_fused(hipStream_t st_, const Plan2D &pl, const RowsHArgs &RA,
 // inter-pass work buffer: two halves of `group` cells each (float2-sized elements)
 static size_t bw_batches(const AcqState &a) { return (size_t)std::max(2 * a.group * a.ncomp, 8); }
 
+// cells per launch pair for a search over D bins: the whole Doppler row of a PRN when the two
+// halves of the inter-pass buffer stay under 24 GiB (B1C cfg3: 201 cells, 20 GiB of the 288)
+static void pick_group(AcqState &a, const bds_settings &s) {
+    const int D = (int)m_round(s.acqSearchBand * 2 / s.acqStep) + 1;
+    const double per_cell = 2.0 * a.ncomp * (double)a.plan.L * sizeof(float2);
+    const int cap = (int)std::max(1.0, std::floor(24.0 * 1073741824.0 / per_cell));
+    a.group = a.group_env ? a.group_env : std::min(cap, 256);
+    a.group = std::max(1, std::min(a.group, D));
+}
+
 }  // namespace bds
 
 using namespace bds;
@@ -637,6 +664,7 @@ extern "C" int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s) {
     BDS_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = set_lds_limits(ctx))) return rc;
     Plan2D &pl = a.plan;
+    pick_group(a, *s);
     if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a) * (size_t)pl.L))) return rc;
     std::vector<int> todo;
     for (int i = 0; i < s->n_acq; ++i)
@@ -763,7 +791,9 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     a.D = D;
     const int P = (int)prns.size();
     const int ncomp = a.ncomp;
+    pick_group(a, *s);
     const int G = a.group;
+    if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a) * (size_t)pl.L))) return rc;
     if ((rc = ensure(ctx, &a.d_Xs, &a.xs_cap, (size_t)D * pl.L))) return rc;
     if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * D * pl.ntiles))) return rc;
     if (a.rows_cap < (size_t)P * D) {
@@ -901,8 +931,13 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
                 const Grp &gr = grps[k];
                 RA = RowsHArgs{(const h2 *)pl.d_htab2, pl.twl, (const __half2 *)a.d_Xs, pl.L, pl.L1, gr.nb, gr.b0,
                                (const __half2 *)a.d_Cs + (size_t)a.cs_slot[prns[gr.pi]] * ncomp * pl.L,
-                               (__half2 *)a.d_Bw + (size_t)(k & 1) * half_elems, a.in_scale};
-                nr = pl.L1 * gr.nb / 8;
+                               (__half2 *)a.d_Bw + (size_t)(k & 1) * half_elems, a.in_scale, 1, gr.nb};
+                // row workgroups walk through a few cells each (shorter chunks than the unfused
+                // launch: a long row workgroup late in the mixed grid would be its tail)
+                static const int fch = std::getenv("BDS_ACQ_FCHUNK") ? std::max(1, atoi(std::getenv("BDS_ACQ_FCHUNK"))) : 2;
+                RA.NCH = (gr.nb + fch - 1) / fch;
+                RA.GC = (gr.nb + RA.NCH - 1) / RA.NCH;
+                nr = pl.L1 * RA.NCH / 8;
             }
             if (k >= 1) {
                 const Grp &gc = grps[k - 1];

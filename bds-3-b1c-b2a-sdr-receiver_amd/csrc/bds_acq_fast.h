@@ -212,7 +212,7 @@ __global__ __launch_bounds__((cols_threads<S, T>()), 3) void k_cols_inv_max_t(
         const float w = comp == 0 ? w0 : w1;
         auto out = [&](int i, int q, int, int e, float2 v) {
             if ((long)e * L2 + c0 <= hi_all) {  // wave-uniform for the tail rows
-                const float a = w * sqrtf(v.x * v.x + v.y * v.y);
+                const float a = w * __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);  // 1 ulp; feeds the sieve only
                 mag[i][q] = comp == 0 ? a : mag[i][q] + a;
             }
         };
@@ -278,9 +278,14 @@ struct RowsHArgs {
     const __half2 *Cs;
     __half2 *Bw;
     float in_scale;
+    int GC;   // cells one workgroup walks through (same row k1 of GC consecutive Doppler bins)
+    int NCH;  // = ceil(G / GC): workgroups per row
 };
 
-// body of the fp16 row pass for virtual workgroup index vb (= 8*slot + xcd), thread tid < rows_threads<S>()
+// body of the fp16 row pass for virtual workgroup index vb (= 8*slot + xcd), thread tid < rows_threads<S>().
+// A workgroup owns row k1 of up to GC cells of the group: the code-spectrum rows, the inter-pass
+// twiddles and the LDS stage tables depend on (PRN, k1) only and are set up once; the spectrum row
+// of the next cell is in flight while the current one is transformed.
 template <int S, int NCOMP>
 __device__ __forceinline__ void rows_inv_h_body(const RowsHArgs &A, int vb, int tid) {
     const h2 *__restrict__ htab = A.htab;
@@ -301,22 +306,33 @@ __device__ __forceinline__ void rows_inv_h_body(const RowsHArgs &A, int vb, int 
     h2 *tab = ldsh + ((tspan<S>() + 3) & ~3);
     load_half_table<S, NT>(tab, htab, tid);
     const int xcd = vb & 7, m = vb >> 3;
-    const int g = m % G, k1 = (m / G) * 8 + xcd;
+    const int GC = A.GC, NCH = A.NCH;
+    const int g0 = (m % NCH) * GC, k1 = (m / NCH) * 8 + xcd;
+    const int g1 = g0 + GC < G ? g0 + GC : G;
     if (k1 >= L1) return;
     if (tid < MBL) s_a[tid] = twl.get<+1>((uint32_t)((long)k1 * NT * tid));
     if (tid >= 64 && tid < 64 + RL) s_b[tid - 64] = twl.get<+1>((uint32_t)((long)k1 * NSL * (tid - 64)));
     const float2 wbase = twl.get<+1>((uint32_t)k1 * (uint32_t)tid);
-    const __half2 *xr = Xs + (long)(bin0 + g) * L + (long)k1 * S;
     const h2 sc = {(_Float16)in_scale, (_Float16)in_scale};
-    h2 xv[MB1][16];
+    h2 xn[MB1][16];  // spectrum row of the next cell (raw)
+    auto fetch_x = [&](int g) {
+        const __half2 *xr = Xs + (long)(bin0 + g) * L + (long)k1 * S;
 #pragma unroll
-    for (int i = 0; i < MB1; ++i) {
-        const int bb = tid + i * NT;
-        if (NB1 % NT == 0 || bb < NB1) {
+        for (int i = 0; i < MB1; ++i) {
+            const int bb = tid + i * NT;
+            if (NB1 % NT == 0 || bb < NB1) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) xv[i][q] = ld_h(xr, bb + q * NB1) * sc;
+                for (int q = 0; q < 16; ++q) xn[i][q] = ld_h(xr, bb + q * NB1);
+            }
         }
-    }
+    };
+#ifndef BDS_ROWS_PREFETCH
+#define BDS_ROWS_PREFETCH 1
+#endif
+#ifndef BDS_ROWS_OCC
+#define BDS_ROWS_OCC 3
+#endif
+    if (BDS_ROWS_PREFETCH) fetch_x(g0);
     // code-spectrum rows of every component: all global loads of the workgroup are in flight
     // before the first transform starts
     h2 cv[NCOMP][MB1][16];
@@ -345,13 +361,21 @@ __device__ __forceinline__ void rows_inv_h_body(const RowsHArgs &A, int vb, int 
             wo[i][q] = h2{(_Float16)w.x, (_Float16)w.y};
         }
     }
+    for (int g = g0; g < g1; ++g) {
+        if (!BDS_ROWS_PREFETCH) fetch_x(g);
 #pragma unroll
-    for (int comp = 0; comp < NCOMP; ++comp) {
-        h2 *dst = reinterpret_cast<h2 *>(Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S);
-        auto src = [&](int i, int q, int, int) { return cmul(xv[i][q], cv[comp][i][q]); };
-        auto out = [&](int i, int q, int, int e, h2 v) { dst[e] = cmul(v, wo[i][q]); };
-        TPlan<S>::template run<1, NT, +1>(ldsh, (const h2 *)tab, tid, src, out);
-        if (comp + 1 < NCOMP) __syncthreads();
+        for (int comp = 0; comp < NCOMP; ++comp) {
+            h2 *dst = reinterpret_cast<h2 *>(Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S);
+            auto src = [&](int i, int q, int, int) { return cmul(xn[i][q] * sc, cv[comp][i][q]); };
+            auto out = [&](int i, int q, int, int e, h2 v) { dst[e] = cmul(v, wo[i][q]); };
+            // the last component's first stage is the last reader of xn: the next cell's row is
+            // fetched into the same registers while stages 2.. and the stores run
+            auto next = [&]() {
+                if (BDS_ROWS_PREFETCH && comp == NCOMP - 1 && g + 1 < g1) fetch_x(g + 1);
+            };
+            TPlan<S>::template run_hook<1, NT, +1>(ldsh, (const h2 *)tab, tid, src, out, next);
+            if (comp + 1 < NCOMP || g + 1 < g1) __syncthreads();
+        }
     }
 }
 
@@ -430,10 +454,11 @@ __device__ __forceinline__ void cols_inv_max_h_body(const ColsHArgs &A, int tb, 
         // lags (the padded transform is ~1.6 N long) is skipped with a workgroup-uniform test.
         auto out = [&](int i, int q, int, int, h2 v) {
             if (q * NSL <= e_max) {
-                // |v|^2 as one v_dot2_f32_f16 (fp32 accumulate), then sqrt and the component weight
                 // (v_dot2_f32_f16 for |v|^2 measured 1% slower than convert + fma: tools/exp_mag.sh)
                 const float x = (float)v.x, y = (float)v.y;
-                const float a = w * sqrtf(x * x + y * y);
+                // raw v_sqrt_f32 (1 ulp): sqrtf() expands to ~12 instructions of denormal scaling and
+                // Newton fix-up, a third of this kernel's scalar-rate VALU work; the value only feeds the sieve
+                const float a = w * __builtin_amdgcn_sqrtf(x * x + y * y);
                 mag[i][q] = comp == 0 ? a : mag[i][q] + a;
             }
         };
@@ -485,7 +510,7 @@ __device__ __forceinline__ void cols_inv_max_h_body(const ColsHArgs &A, int tb, 
 }
 
 template <int S, int NCOMP>
-__global__ __launch_bounds__(rows_threads<S>(), 4) void k_rows_inv_h(RowsHArgs A) {
+__global__ __launch_bounds__(rows_threads<S>(), BDS_ROWS_OCC) void k_rows_inv_h(RowsHArgs A) {
     rows_inv_h_body<S, NCOMP>(A, (int)blockIdx.x, (int)threadIdx.x);
 }
 
@@ -502,7 +527,7 @@ __global__ __launch_bounds__((cols_threads<S, T>()), 4) void k_cols_inv_max_h(Co
 // use different halves of the inter-pass buffer.  nr / nc = row / column slots (workgroups / 8);
 // either may be 0 (first / last launch of the chain).
 template <int S2, int S1, int T, int NCOMP>
-__global__ __launch_bounds__(rows_threads<S2>(), 4) void k_search_fused_h(RowsHArgs RA, ColsHArgs CA, int nr, int nc,
+__global__ __launch_bounds__(rows_threads<S2>(), BDS_ROWS_OCC) void k_search_fused_h(RowsHArgs RA, ColsHArgs CA, int nr, int nc,
                                                                         int ntiles) {
     static_assert(rows_threads<S2>() >= cols_threads<S1, T>(), "block size is the row pass's");
     const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;

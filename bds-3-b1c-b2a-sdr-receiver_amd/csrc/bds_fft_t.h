@@ -137,13 +137,20 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
 }
 
 // All stages of a plan; the first stage takes Src, the last one Dst, everything between is LDS.
-template <class C, int S, int T, int NT, int DIR, int NS, int TWOFF, class Src, class Dst, int R, int... REST>
-__device__ __forceinline__ void tfft_run(C *__restrict__ buf, const C *__restrict__ tw, int tid, Src src, Dst dst) {
+// hook() runs once, right after the first stage (its inputs are consumed: the caller may start
+// overwriting them, e.g. with the loads of the next transform's operands).
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <class C, int S, int T, int NT, int DIR, int NS, int TWOFF, class Src, class Dst, class Hook, int R, int... REST>
+__device__ __forceinline__ void tfft_run(C *__restrict__ buf, const C *__restrict__ tw, int tid, Src src, Dst dst, Hook hook) {
     if constexpr (sizeof...(REST) == 0) {
         tstage<C, S, T, NT, DIR, NS, R, TWOFF>(buf, tw, tid, src, dst);
+        hook();
     } else {
         tstage<C, S, T, NT, DIR, NS, R, TWOFF>(buf, tw, tid, src, LdsIO{});
-        tfft_run<C, S, T, NT, DIR, NS * R, TWOFF + (NS > 1 ? NS * R : 0), LdsIO, Dst, REST...>(buf, tw, tid, LdsIO{}, dst);
+        hook();
+        tfft_run<C, S, T, NT, DIR, NS * R, TWOFF + (NS > 1 ? NS * R : 0), LdsIO, Dst, NoHook, REST...>(buf, tw, tid, LdsIO{}, dst, NoHook{});
     }
 }
 
@@ -170,7 +177,11 @@ struct TPlan;
     struct TPlan<S_> {                                                                             \
         template <int T, int NT, int DIR, class C, class Src, class Dst>                           \
         __device__ __forceinline__ static void run(C *buf, const C *tw, int tid, Src src, Dst dst) { \
-            tfft_run<C, S_, T, NT, DIR, 1, 0, Src, Dst, __VA_ARGS__>(buf, tw, tid, src, dst);      \
+            tfft_run<C, S_, T, NT, DIR, 1, 0, Src, Dst, NoHook, __VA_ARGS__>(buf, tw, tid, src, dst, NoHook{}); \
+        }                                                                                          \
+        template <int T, int NT, int DIR, class C, class Src, class Dst, class Hook>               \
+        __device__ __forceinline__ static void run_hook(C *buf, const C *tw, int tid, Src src, Dst dst, Hook hook) { \
+            tfft_run<C, S_, T, NT, DIR, 1, 0, Src, Dst, Hook, __VA_ARGS__>(buf, tw, tid, src, dst, hook); \
         }                                                                                          \
         static constexpr int kRadix[] = {__VA_ARGS__};                                             \
     };

@@ -1,0 +1,6 @@
+# cells per row-pass workgroup (BDS_ACQ_GCHUNK) x group size, full 63-PRN B1C search
+for gc in "48 16" "48 24" "67 17" "67 23" "67 34" "67 67" "101 26" "101 34" "101 51" "201 34" "201 67"; do set -- $gc; echo -n "GROUP=$1 GCHUNK=$2: "; BDS_ACQ_GROUP=$1 BDS_ACQ_GCHUNK=$2 timeout 300 python bench.py --workload b1c --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep -E "^\{" | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('ms/step', round(d['ms_per_step'],1), 'search', round(d['stage_ms']['search_ms'],1), len(d['config']['satellites_detected']))
+"; done
