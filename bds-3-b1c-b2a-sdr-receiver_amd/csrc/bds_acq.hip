@@ -830,9 +830,12 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
         if (a.hmath) {
             // fp16 arithmetic: bring the spectrum product to unit RMS after the first radix-16 stage
             // (x4 on noise-like data); later stages are rescaled inside their twiddle tables
-            const double p_rms = std::sqrt(a.sum_sq_ext) * a.sX * std::sqrt((double)a.X) * a.sC / (double)pl.L;
-            a.in_scale = (float)std::exp2(std::round(std::log2(1.0 / (4.0 * std::max(1e-30, p_rms)))));
-            a.sB = (float)(a.in_scale * pl.hscale2 * pl.hscale1);  // total scale the kernels apply themselves
+            // The scale goes into the stored spectrum itself (sX), so the row pass multiplies X by C
+            // as loaded: stored X rms = 1 / (4 C_rms) ~ 1e-2, |X| <= sX * sum|x| ~ 15, well inside fp16.
+            const double p_rms1 = std::sqrt(a.sum_sq_ext) * std::sqrt((double)a.X) * a.sC / (double)pl.L;  // at sX = 1
+            a.sX = (float)std::exp2(std::round(std::log2(1.0 / (4.0 * std::max(1e-30, p_rms1)))));
+            a.in_scale = 1.f;
+            a.sB = (float)(pl.hscale2 * pl.hscale1);  // total scale the kernels apply themselves
         }
     }
 

@@ -313,7 +313,7 @@ __device__ __forceinline__ void rows_inv_h_body(const RowsHArgs &A, int vb, int 
     if (tid < MBL) s_a[tid] = twl.get<+1>((uint32_t)((long)k1 * NT * tid));
     if (tid >= 64 && tid < 64 + RL) s_b[tid - 64] = twl.get<+1>((uint32_t)((long)k1 * NSL * (tid - 64)));
     const float2 wbase = twl.get<+1>((uint32_t)k1 * (uint32_t)tid);
-    const h2 sc = {(_Float16)in_scale, (_Float16)in_scale};
+    (void)in_scale;  // == 1: the unit-RMS scale is part of the stored spectrum (sX)
     h2 xn[MB1][16];  // spectrum row of the next cell (raw)
     auto fetch_x = [&](int g) {
         const __half2 *xr = Xs + (long)(bin0 + g) * L + (long)k1 * S;
@@ -366,7 +366,7 @@ __device__ __forceinline__ void rows_inv_h_body(const RowsHArgs &A, int vb, int 
 #pragma unroll
         for (int comp = 0; comp < NCOMP; ++comp) {
             h2 *dst = reinterpret_cast<h2 *>(Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S);
-            auto src = [&](int i, int q, int, int) { return cmul(xn[i][q] * sc, cv[comp][i][q]); };
+            auto src = [&](int i, int q, int, int) { return cmul(xn[i][q], cv[comp][i][q]); };
             auto out = [&](int i, int q, int, int e, h2 v) { dst[e] = cmul(v, wo[i][q]); };
             // the last component's first stage is the last reader of xn: the next cell's row is
             // fetched into the same registers while stages 2.. and the stores run

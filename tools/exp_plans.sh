@@ -1,17 +1,6 @@
-run() { echo "== $*"; env "$@" timeout 300 python bench.py --workload b1c --steps 1 --warmup 1 --no-cpu-baseline --prns 6 2>&1 | grep -E "^\{|plan" | python -c "
+# alternative 2-D factorizations of the B1C transform length (full 63-PRN search)
+for pl in 768x4096 1024x3072; do echo -n "plan=$pl: "; BDS_VERBOSE=1 BDS_ACQ_FORCE_L1L2=$pl timeout 300 python bench.py --workload b1c --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep -E "^\{" | python -c "
 import sys,json
 for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('   ms/step', round(d['ms_per_step'],1), 'search', round(d['stage_ms']['search_ms'],1), 'us/cell', round(d['stage_ms']['search_ms']*1e3/(6*201),1), 'det', d['config']['satellites_detected'])
-    else: print('  ', l.strip()[:160])
-"; }
-export BDS_VERBOSE=1
-run BDS_ACQ_GROUP=1
-run BDS_ACQ_GROUP=2
-run BDS_ACQ_GROUP=4
-run BDS_ACQ_GROUP=8
-run BDS_ACQ_GROUP=16
-run BDS_ACQ_GROUP=4 BDS_ACQ_FORCE_L1L2=512x6144
-run BDS_ACQ_GROUP=4 BDS_ACQ_FORCE_L1L2=1024x3072
-run BDS_ACQ_GROUP=4 BDS_ACQ_FORCE_L1L2=384x8192
-run BDS_ACQ_GROUP=4 BDS_ACQ_FORCE_L1L2=1000x3000
+    d=json.loads(l); print('ms/step', round(d['ms_per_step'],1), 'search', round(d['stage_ms']['search_ms'],1), len(d['config']['satellites_detected']))
+"; done
