@@ -66,10 +66,11 @@ struct TrkOut {  // device arrays [n_ch][n_epochs]
 //   units = 1  : chips           (B2a)
 //   units = 2  : BOC(1,1) half-chips  [-c, +c]         (generateDataBOC11.m:85-91)
 //   units = 12 : BOC(6,1) twelfths    (-1)^ii c, ii=1..12 (generatePilotBOC61.m:89-96)
+// (32-bit index arithmetic: |i1| <= 12 * 10230 + 2; 64-bit integer ops cost 2-4 VALU instructions each)
 template <int UNITS>
-__device__ __forceinline__ float code_at(const int8_t *__restrict__ prim, int code_len, long i1) {
-    const long n = (long)code_len * UNITS;
-    long u = i1 - 2;  // 0-based index into the unpadded array
+__device__ __forceinline__ float code_at(const int8_t *__restrict__ prim, int code_len, int i1) {
+    const int n = code_len * UNITS;
+    int u = i1 - 2;  // 0-based index into the unpadded array
     if (u < 0) u += n;
     if (u >= n) u -= n;
     if (UNITS == 1) return (float)prim[u];
@@ -77,8 +78,8 @@ __device__ __forceinline__ float code_at(const int8_t *__restrict__ prim, int co
         const float c = (float)prim[u >> 1];
         return (u & 1) ? c : -c;
     }
-    const long chip = u / 12;
-    const int ii = (int)(u - chip * 12);  // ii-1
+    const int chip = (int)((unsigned)u / 12u);
+    const int ii = u - chip * 12;  // ii-1
     const float c = (float)prim[chip];
     return (ii & 1) ? c : -c;  // ii-1 even -> ii odd -> (-1)^ii = -1
 }
@@ -116,7 +117,7 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
     float acc[kNSums];
 #pragma unroll
     for (int i = 0; i < kNSums; ++i) acc[i] = 0.f;
-    for (long k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+    for (int k = (int)k0 + (int)threadIdx.x; k < (int)k1; k += (int)blockDim.x) {  // blksize < 2^31
         float raw, raw_q = 0.f;
         if (p.cplx) {  // rawSignal = data(1:2:end) + 1i*data(2:2:end)  (tracking.m:242-246)
             const char2 v = reinterpret_cast<const char2 *>(data)[g.pos + k];
@@ -127,7 +128,7 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
         }
         const double kd = (double)k;
         const double te = st_e + kd * inc, tl = st_l + kd * inc, tp = st_p + kd * inc;
-        const long ie = (long)ceil(te) + 1, il = (long)ceil(tl) + 1, ip = (long)ceil(tp) + 1;
+        const int ie = (int)ceil(te) + 1, il = (int)ceil(tl) + 1, ip = (int)ceil(tp) + 1;
         // carrier: trigarg = (carrFreq*2*pi)*(k/fs) + remCarrPhase  (tracking.m:303-304), in cycles
         const double cyc = g.carrFreq * (kd * p.inv_fs) + cyc0;
         const double fr = cyc - floor(cyc);
@@ -164,9 +165,9 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
             acc[10] += pl * ib;
             acc[11] += pl * qb;
             if (MODE == BDS_TRACK_WB) {  // pilotBOC61(ceil(tcode*6)+1)  (WB_tracking.m:298,311,324)
-                const float se = code_at<12>(prim_p, p.code_len, (long)ceil(te * 6) + 1);
-                const float sp = code_at<12>(prim_p, p.code_len, (long)ceil(tp * 6) + 1);
-                const float sl = code_at<12>(prim_p, p.code_len, (long)ceil(tl * 6) + 1);
+                const float se = code_at<12>(prim_p, p.code_len, (int)ceil(te * 6) + 1);
+                const float sp = code_at<12>(prim_p, p.code_len, (int)ceil(tp * 6) + 1);
+                const float sl = code_at<12>(prim_p, p.code_len, (int)ceil(tl * 6) + 1);
                 acc[12] += se * ib;
                 acc[13] += se * qb;
                 acc[14] += sp * ib;
@@ -252,21 +253,35 @@ __global__ void k_trk_reduce_open(const double *__restrict__ part, int nblocks, 
     }
 }
 
-// one workgroup (64 lanes) per channel
+// one workgroup per channel: kUpdGroups x 18 threads add up the correlate workgroups' partial sums,
+// thread 0 then runs the loop filters
+static constexpr int kUpdGroups = 14;
+static constexpr int kUpdThreads = 256;  // >= kUpdGroups * kNSums
 template <int MODE>
-__global__ __launch_bounds__(64) void k_trk_update(TrkParams p, ChanState *__restrict__ st,
+__global__ __launch_bounds__(kUpdThreads) void k_trk_update(TrkParams p, ChanState *__restrict__ st,
                                                    const double *__restrict__ part, int nblocks, int epoch,
                                                    TrkOut o) {
     const int ch = blockIdx.x;
     __shared__ double s_sum[kNSums];
+    __shared__ double s_grp[kUpdGroups][kNSums];
     ChanState s = st[ch];
     if (!s.active) return;
     const EpochGeom g = epoch_geom(s, p);
-    if (threadIdx.x < kNSums) {
-        // fixed-order sum over the correlate workgroups: bit-stable from run to run
+    // fixed-order two-level sum over the correlate workgroups (bit-stable from run to run): group j
+    // takes workgroups j, j+14, ...; the 14 group sums are then added in order.  (A single thread per
+    // sum walking all ~243 workgroups of a 10-ms epoch cost 60 us of dependent loads per epoch.)
+    if (threadIdx.x < kUpdGroups * kNSums) {
+        const int grp = threadIdx.x / kNSums, i = threadIdx.x - grp * kNSums;
         const long nb = min((long)nblocks, (g.blk + kChunk - 1) / kChunk);
         double v = 0;
-        for (long b = 0; b < nb; ++b) v += part[((long)ch * nblocks + b) * kNSums + threadIdx.x];
+        for (long b = grp; b < nb; b += kUpdGroups) v += part[((long)ch * nblocks + b) * kNSums + i];
+        s_grp[grp][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNSums) {
+        double v = 0;
+#pragma unroll
+        for (int j = 0; j < kUpdGroups; ++j) v += s_grp[j][threadIdx.x];
         s_sum[threadIdx.x] = v;
     }
     __syncthreads();
@@ -579,15 +594,15 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_byte
         switch (p.mode) {
             case BDS_TRACK_B2A:
                 hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_B2A>, gc, dim3(kTrkThreads), 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
-                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_B2A>, dim3(n_ch), dim3(64), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
+                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_B2A>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
                 break;
             case BDS_TRACK_NB:
                 hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_NB>, gc, dim3(kTrkThreads), 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
-                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_NB>, dim3(n_ch), dim3(64), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
+                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_NB>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
                 break;
             default:
                 hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_WB>, gc, dim3(kTrkThreads), 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
-                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_WB>, dim3(n_ch), dim3(64), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
+                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_WB>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
                 break;
         }
     }
