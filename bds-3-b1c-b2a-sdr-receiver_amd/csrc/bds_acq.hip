@@ -265,13 +265,20 @@ struct AcqState {
     Plan2D plan;
     CodeTable tab{};   // xlen = X (coarse)
     // device buffers
-    int8_t *d_sig = nullptr;
+    int8_t *d_sig = nullptr;        // int8 record as loaded (pairs when complex)
     size_t sig_cap = 0;
-    long n_samples = 0;
-    std::vector<int8_t> h_sig;
-    std::vector<int64_t> h_prefix;  // prefix sums of the samples (exact DC means)
-    std::vector<int64_t> h_prefix_q;  // ... of the Q samples (fileType 2)
-    bool cplx = false;              // longSignal = I + 1i*Q (postProcessing.m:92-96), stored as int8 pairs
+    double *d_sig64 = nullptr;      // conditioned f64 block of the resampling branch (acquisition.m:56-124)
+    size_t sig64_cap = 0;
+    double *d_ffa = nullptr, *d_ffb = nullptr, *d_fir = nullptr;  // filtfilt work buffers, fir1 taps
+    size_t ffa_cap = 0, ffb_cap = 0, fir_cap = 0;
+    int skind = kS8;                // what the search reads: SampleKind
+    long n_samples = 0;             // samples of the block the search sees (after resampling, if any)
+    ResamplePlan rs;                // resampling branch of the loaded block
+    std::vector<double> h_re, h_im;       // host copy of that block (exact for int8 data)
+    std::vector<double> h_prefix;         // prefix sums (DC means; integers below 2^53 for int8 data)
+    std::vector<double> h_prefix_q;       // ... of the imaginary part
+    bool cplx = false;              // longSignal = I + 1i*Q (postProcessing.m:92-96)
+    SampleView sview() const { return SampleView{skind >= kF64 ? (const void *)d_sig64 : (const void *)d_sig, skind}; }
     int8_t *d_prim = nullptr;       // [63][2][code_len]
     float2 *d_Cs = nullptr;         // [slots][ncomp][L]
     size_t cs_cap_slots = 0;
@@ -315,7 +322,7 @@ void acq_state_free(AcqState *a) {
     plan_free(a->plan);
     for (void *p : {(void *)a->d_sig, (void *)a->d_prim, (void *)a->d_Cs, (void *)a->d_Xs, (void *)a->d_Bw,
                     (void *)a->d_recs, (void *)a->d_rowmax, (void *)a->d_rowarg, (void *)a->d_jobs, (void *)a->d_codes,
-                    (void *)a->d_jobout})
+                    (void *)a->d_jobout, (void *)a->d_sig64, (void *)a->d_ffa, (void *)a->d_ffb, (void *)a->d_fir})
         if (p) (void)hipFree(p);
     delete a;
 }
@@ -327,9 +334,11 @@ static int check_settings(bds_ctx *ctx, const bds_settings &s) {
         return fail(ctx, BDS_ERR_ARG, "settings.samplingFreq/codeFreqBasis must be positive and codeLength 10230");
     if (!(s.acqStep > 0) || !(s.acqSearchBand >= 0))
         return fail(ctx, BDS_ERR_ARG, "settings.acqStep must be > 0 and acqSearchBand >= 0");
-    if (s.resamplingflag == 1 && s.samplingFreq > s.resamplingThreshold)
-        return fail(ctx, BDS_ERR_UNSUPPORTED,
-                    "acquisition resampling branch (acquisition.m:56-124) is not built; set resamplingflag = 0");
+    if (s.resamplingflag == 1 && s.samplingFreq > s.resamplingThreshold) {
+        const ResamplePlan r = resample_plan(s);
+        if (!(r.wp1 > 0 && r.wp2 < 1 && r.wp1 < r.wp2))
+            return fail(ctx, BDS_ERR_ARG, "resampling band edges [%g %g] outside (0, 1): fir1 would fail (acquisition.m:66-68)", r.wp1, r.wp2);
+    }
     if (s.n_acq < 1 || s.n_acq > BDS_MAX_PRN) return fail(ctx, BDS_ERR_ARG, "settings.acqSatelliteList is empty or too long");
     for (int i = 0; i < s.n_acq; ++i)
         if (s.acqSatelliteList[i] < 1 || s.acqSatelliteList[i] > BDS_MAX_PRN)
@@ -614,41 +623,105 @@ static void pick_group(AcqState &a, const bds_settings &s) {
 using namespace bds;
 
 // =======================================================================================
-extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s, const int8_t *samples, size_t n_samples,
+// The settings acquisition() works with after its resampling branch reassigned samplingFreq and IF
+// (acquisition.m:103,119); everything downstream -- code tables, sizes, frequency bins -- uses these.
+static const bds_settings *effective(const bds_settings *s, bds_settings *tmp) {
+    const ResamplePlan r = resample_plan(*s);
+    if (!r.on) return s;
+    *tmp = *s;
+    tmp->samplingFreq = r.new_fs;
+    tmp->IF = r.new_if;
+    tmp->resamplingflag = 0;
+    return tmp;
+}
+
+// filtfilt(fir1(700, wp), 1, longSignal) + index decimation on the device (acquisition.m:56-112);
+// leaves the conditioned block in a.d_sig64 and its host copy in h_re / h_im.
+template <int NCH>
+static int condition_block(bds_ctx *ctx, AcqState &a, const ResamplePlan &r, long n_in, long *n_out) {
+    constexpr int kTaps = 701, kFact = 3 * (kTaps - 1);  // filtfilt: nfact = 3*(nfilt-1)
+    if (n_in <= kFact) return fail(ctx, BDS_ERR_ARG, "longSignal (%ld samples) is too short for filtfilt (needs > %d)", n_in, kFact);
+    const std::vector<double> b = fir1_bandpass(kTaps, r.wp1, r.wp2);
+    const long len = n_in + 2L * kFact;
+    int rc;
+    if ((rc = ensure(ctx, &a.d_fir, &a.fir_cap, (size_t)kTaps))) return rc;
+    if ((rc = ensure(ctx, &a.d_ffa, &a.ffa_cap, (size_t)len * NCH))) return rc;
+    if ((rc = ensure(ctx, &a.d_ffb, &a.ffb_cap, (size_t)len * NCH))) return rc;
+    BDS_HIP(ctx, hipMemcpyAsync(a.d_fir, b.data(), sizeof(double) * kTaps, hipMemcpyHostToDevice, st(ctx)));
+    const dim3 grid(2048), blk(256);
+    hipLaunchKernelGGL(k_ff_extend<NCH>, grid, blk, 0, st(ctx), (const int8_t *)a.d_sig, n_in, kFact, a.d_ffa);
+    hipLaunchKernelGGL(k_ff_fir<NCH>, grid, blk, sizeof(double) * kTaps, st(ctx), (const double *)a.d_ffa, len,
+                       (const double *)a.d_fir, kTaps, 0, a.d_ffb);
+    hipLaunchKernelGGL(k_ff_fir<NCH>, grid, blk, sizeof(double) * kTaps, st(ctx), (const double *)a.d_ffb, len,
+                       (const double *)a.d_fir, kTaps, 1, a.d_ffa);
+    const long sig_len = (long)std::floor((double)(n_in - 1) / r.old_fs * r.new_fs);  // :107
+    if (sig_len < 1) return fail(ctx, BDS_ERR_ARG, "resampled longSignal is empty");
+    if ((rc = ensure(ctx, &a.d_sig64, &a.sig64_cap, (size_t)sig_len * NCH))) return rc;
+    hipLaunchKernelGGL(k_ff_decimate<NCH>, grid, blk, 0, st(ctx), (const double *)a.d_ffa, kFact, sig_len, r.new_fs,
+                       r.old_fs, a.d_sig64);
+    BDS_HIP(ctx, hipGetLastError());
+    std::vector<double> h((size_t)sig_len * NCH);
+    BDS_HIP(ctx, hipMemcpyAsync(h.data(), a.d_sig64, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st(ctx)));
+    BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+    a.h_re.resize((size_t)sig_len);
+    a.h_im.assign(NCH == 2 ? (size_t)sig_len : 0, 0.0);
+    for (long i = 0; i < sig_len; ++i) {
+        a.h_re[(size_t)i] = h[(size_t)i * NCH];
+        if (NCH == 2) a.h_im[(size_t)i] = h[(size_t)i * NCH + 1];
+    }
+    *n_out = sig_len;
+    return BDS_OK;
+}
+
+extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s_in, const int8_t *samples, size_t n_samples,
                             int is_complex) {
-    if (!ctx || !s || !samples) return BDS_ERR_ARG;
+    if (!ctx || !s_in || !samples) return BDS_ERR_ARG;
+    if (int rc0 = check_settings(ctx, *s_in)) return rc0;  // (the resampling band edges are only visible here)
+    bds_settings eff;
+    const bds_settings *s = effective(s_in, &eff);
     // n_samples counts complex samples when is_complex: `samples` then holds 2*n_samples int8 (I,Q pairs)
     const bool cplx = is_complex != 0;
     int rc = acq_configure(ctx, *s);
     if (rc) return rc;
     AcqState &a = *ctx->acq;
-    if ((long)n_samples < a.N)
-        return fail(ctx, BDS_ERR_ARG, "longSignal has %zu samples; acquisition needs at least %ld (acquisition.m:140)",
-                    n_samples, a.N);
+    const ResamplePlan r = resample_plan(*s_in);
     BDS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nb = n_samples * (cplx ? 2 : 1);
     if ((rc = ensure(ctx, &a.d_sig, &a.sig_cap, nb))) return rc;
     BDS_HIP(ctx, hipMemcpyAsync(a.d_sig, samples, nb, hipMemcpyHostToDevice, st(ctx)));
     a.cplx = cplx;
-    a.h_sig.assign(samples, samples + nb);
-    a.h_prefix.resize(n_samples + 1);
+    a.rs = r;
+    long n_eff = (long)n_samples;
+    if (r.on) {
+        rc = cplx ? condition_block<2>(ctx, a, r, (long)n_samples, &n_eff) : condition_block<1>(ctx, a, r, (long)n_samples, &n_eff);
+        if (rc) return rc;
+        a.skind = cplx ? kF64C : kF64;
+    } else {
+        a.skind = cplx ? kS8C : kS8;
+        a.h_re.resize(n_samples);
+        a.h_im.assign(cplx ? n_samples : 0, 0.0);
+        for (size_t i = 0; i < n_samples; ++i) {
+            a.h_re[i] = (double)samples[cplx ? 2 * i : i];
+            if (cplx) a.h_im[i] = (double)samples[2 * i + 1];
+        }
+    }
+    if (n_eff < a.N)
+        return fail(ctx, BDS_ERR_ARG, "longSignal has %ld samples%s; acquisition needs at least %ld (acquisition.m:140)",
+                    n_eff, r.on ? " after resampling" : "", a.N);
+    a.h_prefix.resize((size_t)n_eff + 1);
     a.h_prefix[0] = 0;
     a.h_prefix_q.clear();
+    for (long i = 0; i < n_eff; ++i) a.h_prefix[(size_t)i + 1] = a.h_prefix[(size_t)i] + a.h_re[(size_t)i];
     if (cplx) {
-        a.h_prefix_q.resize(n_samples + 1);
+        a.h_prefix_q.resize((size_t)n_eff + 1);
         a.h_prefix_q[0] = 0;
-        for (size_t i = 0; i < n_samples; ++i) {
-            a.h_prefix[i + 1] = a.h_prefix[i] + samples[2 * i];
-            a.h_prefix_q[i + 1] = a.h_prefix_q[i] + samples[2 * i + 1];
-        }
-    } else {
-        for (size_t i = 0; i < n_samples; ++i) a.h_prefix[i + 1] = a.h_prefix[i] + samples[i];
+        for (long i = 0; i < n_eff; ++i) a.h_prefix_q[(size_t)i + 1] = a.h_prefix_q[(size_t)i] + a.h_im[(size_t)i];
     }
-    a.n_samples = (long)n_samples;
+    a.n_samples = n_eff;
     a.sum_abs_ext = a.sum_sq_ext = 0;
     for (long i = 0; i < a.n_ext; ++i) {
         const long m = i < a.N ? i : i - a.N;
-        const double v = cplx ? std::hypot((double)samples[2 * m], (double)samples[2 * m + 1]) : std::fabs((double)samples[m]);
+        const double v = cplx ? std::hypot(a.h_re[(size_t)m], a.h_im[(size_t)m]) : std::fabs(a.h_re[(size_t)m]);
         a.sum_abs_ext += v;
         a.sum_sq_ext += v * v;
     }
@@ -656,8 +729,11 @@ extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s, const int8_t *s
     return BDS_OK;
 }
 
-extern "C" int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s) {
-    if (!ctx || !s) return BDS_ERR_ARG;
+extern "C" int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s_in) {
+    if (!ctx || !s_in) return BDS_ERR_ARG;
+    if (int rc0 = check_settings(ctx, *s_in)) return rc0;  // (the resampling band edges are only visible here)
+    bds_settings eff;
+    const bds_settings *s = effective(s_in, &eff);
     int rc = acq_configure(ctx, *s);
     if (rc) return rc;
     AcqState &a = *ctx->acq;
@@ -743,7 +819,7 @@ static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vecto
         a.jobs_cap = cap;
     }
     BDS_HIP(ctx, hipMemcpyAsync(a.d_jobs, jobs.data(), sizeof(CorrJob) * jobs.size(), hipMemcpyHostToDevice, st(ctx)));
-    hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size()), dim3(256), 0, st(ctx), (const int8_t *)a.d_sig, a.cplx ? 1 : 0, a.N,
+    hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size()), dim3(256), 0, st(ctx), a.sview(), a.N,
                        (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
     BDS_HIP(ctx, hipGetLastError());
     BDS_HIP(ctx, hipMemcpyAsync(out.data(), a.d_jobout, sizeof(double2) * jobs.size(), hipMemcpyDeviceToHost, st(ctx)));
@@ -763,13 +839,18 @@ static inline double combine(const AcqState &a, const double2 *v) {
 
 }  // namespace bds
 
-extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *prn_list, int n_prn, int max_prn,
+extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t *prn_list, int n_prn, int max_prn,
                            double *carrFreq, double *codePhase, double *peakMetric, int32_t *detected) {
-    if (!ctx || !s || !carrFreq || !codePhase || !peakMetric) return BDS_ERR_ARG;
+    if (!ctx || !s_in || !carrFreq || !codePhase || !peakMetric) return BDS_ERR_ARG;
+    if (int rc0 = check_settings(ctx, *s_in)) return rc0;  // (the resampling band edges are only visible here)
+    bds_settings eff;
+    const bds_settings *s = effective(s_in, &eff);
     int rc = acq_configure(ctx, *s);
     if (rc) return rc;
     AcqState &a = *ctx->acq;
     if (!a.d_sig || a.n_samples < a.N) return fail(ctx, BDS_ERR_ARG, "bds_acq_run: no IF block loaded (bds_acq_load)");
+    if (a.rs.on != resample_plan(*s_in).on || (a.rs.on && a.rs.new_fs != s->samplingFreq))
+        return fail(ctx, BDS_ERR_ARG, "bds_acq_run: the loaded block was conditioned for different resampling settings");
     if ((rc = bds_acq_prepare(ctx, s))) return rc;
     std::vector<int> prns;
     if (prn_list && n_prn > 0)
@@ -844,7 +925,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
         const int chunk = (int)bw_batches(a);
         for (int b0 = 0; b0 < D; b0 += chunk) {
             const int nb = std::min(chunk, D - b0);
-            SignalLoader ld{a.d_sig, a.N, a.n_ext, f0, s->acqStep, 1.0 / a.fs, b0, a.cplx ? 1 : 0};
+            SignalLoader ld{a.sview(), a.N, a.n_ext, f0, s->acqStep, 1.0 / a.fs, b0};
             float2 *xs_dst = a.half ? (float2 *)((__half2 *)a.d_Xs + (size_t)b0 * pl.L) : a.d_Xs + (size_t)b0 * pl.L;
             if ((rc = forward(ctx, a, ld, nb, xs_dst, pl.L, 0, a.sX))) return rc;
         }
@@ -1086,17 +1167,13 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     if (a.signal == BDS_SIGNAL_B1C) {
         // sigPower = sqrt(var(sig(1:X)) * X), unbiased variance (B1C/acquisition.m:150)
         // (complex input: var = sum |x - mean|^2 / (X-1), as MATLAB's var of a complex vector)
-        const double mean = (double)(a.h_prefix[a.X] - a.h_prefix[0]) / (double)a.X;
-        const double mean_q = a.cplx ? (double)(a.h_prefix_q[a.X] - a.h_prefix_q[0]) / (double)a.X : 0.0;
+        const double mean = (a.h_prefix[a.X] - a.h_prefix[0]) / (double)a.X;
+        const double mean_q = a.cplx ? (a.h_prefix_q[a.X] - a.h_prefix_q[0]) / (double)a.X : 0.0;
         long double acc = 0;
         for (long i = 0; i < a.X; ++i) {
-            if (a.cplx) {
-                const double d = (double)a.h_sig[2 * i] - mean, dq = (double)a.h_sig[2 * i + 1] - mean_q;
-                acc += (long double)(d * d + dq * dq);
-            } else {
-                const double d = (double)a.h_sig[i] - mean;
-                acc += (long double)(d * d);
-            }
+            const double d = a.h_re[(size_t)i] - mean;
+            const double dq = a.cplx ? a.h_im[(size_t)i] - mean_q : 0.0;
+            acc += (long double)(d * d + dq * dq);
         }
         const double var = (double)(acc / (long double)(a.X - 1));
         const double sigPower = std::sqrt(var * (double)a.X);
@@ -1180,8 +1257,8 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
             if (r.codePhase < 1 || r.codePhase - 1 + a.spc > a.n_samples)
                 return fail(ctx, BDS_ERR_ARG, "PRN %d: fine-search block %ld..%ld outside longSignal (B1C/acquisition.m:253)",
                             prns[pi], r.codePhase, r.codePhase + a.spc - 1);
-            const double mean = (double)(a.h_prefix[r.codePhase - 1 + a.spc] - a.h_prefix[r.codePhase - 1]) / (double)a.spc;  // :254
-            const double mean_q = a.cplx ? (double)(a.h_prefix_q[r.codePhase - 1 + a.spc] - a.h_prefix_q[r.codePhase - 1]) / (double)a.spc : 0.0;
+            const double mean = (a.h_prefix[r.codePhase - 1 + a.spc] - a.h_prefix[r.codePhase - 1]) / (double)a.spc;  // :254
+            const double mean_q = a.cplx ? (a.h_prefix_q[r.codePhase - 1 + a.spc] - a.h_prefix_q[r.codePhase - 1]) / (double)a.spc : 0.0;
             for (int kf = 0; kf < nfine; ++kf) {
                 const double f = fb - s->acqStep + 25.0 * kf;  // :282-283
                 fine_frq[pi].push_back(f);
@@ -1247,6 +1324,16 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
             if (cf == 0) cf = 1;  // :333-335
             carrFreq[prns[pi] - 1] = cf;
             codePhase[prns[pi] - 1] = (double)res[pi].codePhase;
+            if (a.rs.on) {
+                // results back at the original sampling rate (B2a/acquisition.m:339-356, B1C :311-328)
+                codePhase[prns[pi] - 1] = std::floor((double)(res[pi].codePhase - 1) / s->samplingFreq * a.rs.old_fs) + 1;
+                double doppler;
+                if (s->IF >= s->samplingFreq / 2)
+                    doppler = (s->samplingFreq - s->IF) - cf;
+                else
+                    doppler = cf - s->IF;
+                carrFreq[prns[pi] - 1] = doppler + a.rs.old_if;
+            }
             if (detected) detected[prns[pi] - 1] = 1;
         }
     }
@@ -1282,6 +1369,23 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *p
     t.half_storage = a.hmath ? 2 : a.half ? 1 : 0;  // 0 fp32; 1 fp16 storage, fp32 arithmetic; 2 fp16 storage and arithmetic  // storage of the spectra / inter-pass buffer: 1 = fp16 complex
     for (hipEvent_t e : {ev0, ev1, ev2, ev3, ev_rows[0], ev_rows[1], ev_cols[0], ev_cols[1]}) (void)hipEventDestroy(e);
     for (int i = 0; i < kSamples; ++i) (void)hipEventDestroy(sa[i]), (void)hipEventDestroy(sb[i]);
+    return BDS_OK;
+}
+
+extern "C" int bds_resample_plan(const bds_settings *s, double *new_fs, double *new_if, double *wp) {
+    if (!s) return BDS_ERR_ARG;
+    const ResamplePlan r = resample_plan(*s);
+    if (!r.on) return 0;
+    if (new_fs) *new_fs = r.new_fs;
+    if (new_if) *new_if = r.new_if;
+    if (wp) wp[0] = r.wp1, wp[1] = r.wp2;
+    return 1;
+}
+
+extern "C" int bds_fir1_bandpass(int n_taps, double wp1, double wp2, double *b) {
+    if (n_taps < 3 || !b || !(wp1 > 0 && wp1 < wp2 && wp2 < 1)) return BDS_ERR_ARG;
+    const std::vector<double> h = fir1_bandpass(n_taps, wp1, wp2);
+    std::copy(h.begin(), h.end(), b);
     return BDS_OK;
 }
 

@@ -12,6 +12,7 @@
 #pragma once
 
 #include "bds_fft.h"
+#include "bds_resample.h"
 
 namespace bds {
 
@@ -23,24 +24,18 @@ namespace bds {
 // The phase is reduced to [0,1) cycles in f64 (the reference's f*(n*2*pi*ts) reaches
 // 1.8e6 rad: an fp32 ramp, as B1C/GPU_acquisition.m:150,206 uses, is off by ~1e-2 rad).
 struct SignalLoader {
-    const int8_t *sig;
+    SampleView sig;   // int8 record as read from the file, or the f64 block the resampling branch leaves
     long n_circ;      // N
     long n_ext;       // N + X - 1
     double f0, fstep; // bin frequency = f0 + fstep*batch  [Hz]
     double inv_fs;    // 1/fs
     int bin0;         // first bin of this launch
-    int cplx;         // sig holds (I,Q) int8 pairs: x = I + 1i*Q (fileType 2, postProcessing.m:92-96)
     __device__ __forceinline__ float2 operator()(int batch, long n) const {
         if (n >= n_ext) return make_float2(0.f, 0.f);
         const long m = n < n_circ ? n : n - n_circ;
-        float x, xq = 0.f;
-        if (cplx) {
-            const char2 v = reinterpret_cast<const char2 *>(sig)[m];
-            x = (float)v.x;
-            xq = (float)v.y;
-        } else {
-            x = (float)sig[m];
-        }
+        // x = I + 1i*Q for a complex record (fileType 2, postProcessing.m:92-96)
+        const double2 xv = sig.load(m);
+        const float x = (float)xv.x, xq = (float)xv.y;
         const double f = f0 + fstep * (double)(bin0 + batch);
         const double cyc = f * ((double)m * inv_fs);
         const double fr = cyc - floor(cyc);
@@ -356,7 +351,7 @@ struct CorrJob {
     int pad;
 };
 
-__global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig, int cplx, long n_circ,
+__global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
                                                   const int8_t *__restrict__ codes, long code_stride,
                                                   double inv_fs, const CorrJob *__restrict__ jobs,
                                                   double2 *__restrict__ out) {
@@ -382,14 +377,9 @@ __global__ __launch_bounds__(256) void k_corr_f64(const int8_t *__restrict__ sig
             t = a;
         }
         const int8_t cv = codes[cbase + n];
-        double x, xq = 0.0;
-        if (cplx) {
-            const char2 v = reinterpret_cast<const char2 *>(sig)[a];
-            x = ((double)v.x - jb.mean) * (double)cv;
-            xq = ((double)v.y - jb.mean_q) * (double)cv;
-        } else {
-            x = ((double)sig[a] - jb.mean) * (double)cv;
-        }
+        const double2 xv = sig.load(a);
+        const double x = (xv.x - jb.mean) * (double)cv;
+        const double xq = (xv.y - jb.mean_q) * (double)cv;
         if (resync) {
             const double cyc = jb.freq * ((double)t * inv_fs);
             sincospi(2.0 * (cyc - floor(cyc)), &ci, &cr);

@@ -72,7 +72,7 @@ class Timing(C.Structure):
 
 EXPORTS = [
     "bds_create", "bds_destroy", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_gen_code", "bds_acquire",
-    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_acq_grid", "bds_acq_peaks", "bds_get_timing",
+    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_acq_grid", "bds_acq_peaks", "bds_get_timing",
     "bds_track", "bds_track_mem", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
     "bds_calc_weighing_factor", "bds_pre_run",
 ]
@@ -123,6 +123,8 @@ def lib():
     L.bds_calc_loop_coef_carr.restype, L.bds_calc_loop_coef_carr.argtypes = None, [SP, _DP, _DP, _DP]
     L.bds_calc_weighing_factor.restype, L.bds_calc_weighing_factor.argtypes = C.c_double, [SP]
     L.bds_pre_run.restype = i32
+    L.bds_resample_plan.restype, L.bds_resample_plan.argtypes = i32, [SP, _DP, _DP, _DP]
+    L.bds_fir1_bandpass.restype, L.bds_fir1_bandpass.argtypes = i32, [i32, C.c_double, C.c_double, _DP]
     L.bds_pre_run.argtypes = [SP, i32, _DP, _DP, _DP, C.POINTER(Channel)]
     L.bds_abi_check.restype, L.bds_abi_check.argtypes = i32, [i32, i32, i32, i32]
     if L.bds_abi_check(C.sizeof(Settings), C.sizeof(Channel), C.sizeof(TrackOut), C.sizeof(Timing)) != 0:
@@ -362,6 +364,26 @@ def calc_loop_coef_carr(settings):
 def calc_weighing_factor(settings):
     cs = pack_settings(settings)
     return float(lib().bds_calc_weighing_factor(C.byref(cs)))
+
+
+def resample_plan(settings):
+    """(new_fs, new_if, (wp1, wp2)) of the acquisition's resampling branch, or None when it is not taken
+    (acquisition.m:54-55,66,103,119)."""
+    cs = pack_settings(settings)
+    fs, fi, wp = C.c_double(), C.c_double(), (C.c_double * 2)()
+    rc = lib().bds_resample_plan(C.byref(cs), C.byref(fs), C.byref(fi), wp)
+    if rc < 0:
+        raise BdsError(rc, "bds_resample_plan")
+    return (fs.value, fi.value, (wp[0], wp[1])) if rc else None
+
+
+def fir1_bandpass(n_taps, wp1, wp2):
+    """b = fir1(n_taps - 1, [wp1 wp2])."""
+    b = np.zeros(n_taps)
+    rc = lib().bds_fir1_bandpass(int(n_taps), float(wp1), float(wp2), b.ctypes.data_as(_DP))
+    if rc < 0:
+        raise BdsError(rc, "bds_fir1_bandpass")
+    return b
 
 
 def pre_run(settings, carr_freq, code_phase, peak_metric):

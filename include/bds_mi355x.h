@@ -73,7 +73,7 @@ typedef struct bds_settings {
     int32_t pilotACQflag;          /* B1C only                                       */
     int32_t fineNoncoh;            /* B2a only: code periods in the fine search      */
     double resamplingThreshold;
-    int32_t resamplingflag;        /* must be 0 (resampling branch not built)        */
+    int32_t resamplingflag;        /* 1: condition + resample when fs > threshold   */
     int32_t n_acq;                 /* length of acqSatelliteList                     */
     int32_t acqSatelliteList[BDS_MAX_PRN];
     /* tracking */
@@ -223,6 +223,13 @@ BDS_API double bds_calc_weighing_factor(const bds_settings *s);
 /* preRun.m:61-76 (B1C applies Doppler aiding to codeFreq, B2a does not) */
 BDS_API int bds_pre_run(const bds_settings *s, int max_prn, const double *carrFreq,
                         const double *codePhase, const double *peakMetric, bds_channel *channel);
+/* The acquisition's resampling branch (B2a/acquisition.m:54-124, B1C/acquisition.m:54-123), taken
+ * inside bds_acq_load when samplingFreq > resamplingThreshold && resamplingflag == 1.
+ * bds_resample_plan: returns 1 and the sampling rate / IF acquisition() continues with (:103,:119)
+ *   plus the fir1 band edges (:66) when the branch is taken, 0 (outputs untouched) otherwise.
+ * bds_fir1_bandpass: b = fir1(n_taps-1, [wp1 wp2]) (Hamming window, unit gain at the band centre). */
+BDS_API int bds_resample_plan(const bds_settings *s, double *new_fs, double *new_if, double *wp);
+BDS_API int bds_fir1_bandpass(int n_taps, double wp1, double wp2, double *b);
 
 #ifdef __cplusplus
 }

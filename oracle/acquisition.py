@@ -1,9 +1,14 @@
 """Parallel code-phase search acquisition (oracle; test infrastructure).
 
 Restates, in float64 / complex128,
-  B2a/acquisition.m:126-336   (resampling branch :56-124,:339-356 is off at all
-                               configs, B2a/initSettings.m:89 -- not restated)
-  B1C/acquisition.m:125-307   (likewise :56-123,:311-328)
+  B2a/acquisition.m:126-336   plus the optional resampling pre-conditioner :56-124 and
+                              the result recovery :339-356 (off at the shipped
+                              configs, B2a/initSettings.m:89)
+  B1C/acquisition.m:125-307   (likewise :56-123, :311-328)
+The pre-conditioner's fir1 / filtfilt are MATLAB Signal Processing Toolbox calls; they are
+restated with scipy.signal.firwin (Hamming window, unit gain at the centre of the pass
+band -- fir1's default scaling) and scipy.signal.filtfilt with MATLAB's edge length
+3*(numel(b)-1) (odd reflection, steady-state initial conditions).
 
 The D x N ``results`` matrix of the reference (B2a/acquisition.m:154,
 B1C/acquisition.m:154; 3.2 GB at the B1C config) is streamed one Doppler row at
@@ -42,6 +47,56 @@ def _new_results(settings):
     )
 
 
+def resample_condition(long_signal, settings):
+    """Input conditioning of B2a/acquisition.m:56-124 / B1C/acquisition.m:56-123.
+
+    Returns (longSignal', settings', old) -- ``old`` is None when the branch is not taken,
+    else (oldFreq, oldIF) for :func:`resample_recover`."""
+    if not (settings.samplingFreq > settings.resamplingThreshold and int(settings.resamplingflag) == 1):
+        return np.asarray(long_signal), settings, None
+    import scipy.signal as ssig
+
+    fs = float(settings.samplingFreq)
+    IF = float(settings.IF)
+    if str(settings.signal).upper() == "B1C":
+        bw = 9e6  # B1C :62
+    else:
+        bw = settings.codeFreqBasis * 2 + 0.5e6  # B2a :62
+    w1 = IF - bw / 2
+    w2 = IF + bw / 2
+    wp = [w1 * 2 / fs - 0.002, w2 * 2 / fs + 0.002]  # :66
+    b = ssig.firwin(701, wp, window="hamming", pass_zero=False, scale=True)  # fir1(700, wp) :68
+    x = np.asarray(long_signal)
+    x = x.astype(np.complex128 if np.iscomplexobj(x) else np.float64)
+    x = ssig.filtfilt(b, [1.0], x, padtype="odd", padlen=3 * 700)  # :70
+    fu = IF + bw / 2  # :77
+    n = int(np.floor(fu / bw))
+    if n < 1:
+        n = 1
+    lower = 2 * fu / n
+    fl = IF - bw / 2
+    upper = 2 * fl / (n - 1) if n > 1 else lower
+    old_freq = fs
+    new_fs = float(np.ceil((lower + upper) / 2))  # :103
+    sig_len = int(np.floor((x.size - 1) / old_freq * new_fs))  # :107
+    idx = np.ceil(np.arange(sig_len, dtype=np.float64) / new_fs * old_freq).astype(np.int64)  # :109
+    idx[0] = 1
+    x = x[idx - 1]
+    new_if = float(np.fmod(IF, new_fs))  # :119 rem()
+    return x, settings.copy(samplingFreq=new_fs, IF=new_if), (old_freq, IF)
+
+
+def resample_recover(acq, prn, code_phase, settings, old):
+    """B2a/acquisition.m:339-356 / B1C/acquisition.m:311-328 (settings = the resampled ones)."""
+    old_freq, old_if = old
+    acq.codePhase[prn - 1] = np.floor((code_phase - 1) / settings.samplingFreq * old_freq) + 1
+    if settings.IF >= settings.samplingFreq / 2:
+        doppler = (settings.samplingFreq - settings.IF) - acq.carrFreq[prn - 1]
+    else:
+        doppler = acq.carrFreq[prn - 1] - settings.IF
+    acq.carrFreq[prn - 1] = doppler + old_if
+
+
 def freq_bins(settings) -> np.ndarray:
     """frqBins(b) = IF - acqSearchBand + acqStep*(b-1), b = 1..D
     (B2a/acquisition.m:150,190-191; B1C/acquisition.m:147,194-195)."""
@@ -76,7 +131,7 @@ def acquisition_b2a(long_signal, settings, diag=None):
 
     ``diag`` (optional dict) receives per-PRN intermediate values for tests.
     """
-    long_signal = np.asarray(long_signal)
+    long_signal, settings, old = resample_condition(long_signal, settings)
     spc = codes.samples_per_code(settings)
     n = spc * 2  # len2ms :134
     samples2chip = int(np.ceil(settings.samplingFreq / settings.codeFreqBasis)) * 2  # :137
@@ -144,6 +199,8 @@ def acquisition_b2a(long_signal, settings, diag=None):
             acq.codePhase[prn - 1] = code_phase  # :330
             if acq.carrFreq[prn - 1] == 0:
                 acq.carrFreq[prn - 1] = 1  # :333-335
+            if old is not None:
+                resample_recover(acq, prn, code_phase, settings, old)  # :339-356
             if diag is not None:
                 diag[prn]["fine"] = fine_res
     return acq
@@ -182,7 +239,7 @@ def b1c_coarse_rows(long_signal, settings, prn, bins=None):
 
 def acquisition_b1c(long_signal, settings, diag=None):
     """acqResults = acquisition(longSignal, settings)   (B1C/acquisition.m:1)."""
-    long_signal = np.asarray(long_signal)
+    long_signal, settings, old = resample_condition(long_signal, settings)
     spc, x_len, n = _b1c_sizes(settings)
     ts = 1.0 / settings.samplingFreq
     frq = freq_bins(settings)
@@ -230,6 +287,8 @@ def acquisition_b1c(long_signal, settings, diag=None):
             if acq.carrFreq[prn - 1] == 0:
                 acq.carrFreq[prn - 1] = 1  # :303-305
             acq.codePhase[prn - 1] = code_phase  # :307
+            if old is not None:
+                resample_recover(acq, prn, code_phase, settings, old)  # :311-328
             if diag is not None:
                 diag[prn]["fine"] = fine_res
     return acq

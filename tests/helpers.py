@@ -60,6 +60,26 @@ def small_b1c_iq(prns=(3, 7, 12), n_codes=5, band=500):
     return s, x, sats
 
 
+def resample_b2a():
+    """B2a with the reference's resampling pre-conditioner on (B2a/acquisition.m:54-124):
+    fs = 99.375 MS/s > resamplingThreshold, fir1(700) + filtfilt, fs' = 48.06 MS/s."""
+    s = bds_amd.init_settings_b2a(acqSatelliteList=[19, 20, 21], acqSearchBand=800, acqStep=400, resamplingflag=1)
+    spc = spc_of(s)
+    sats = [synth.Sat(19, 310.0, 0.37 * spc, 1.1, 47.0), synth.Sat(20, -200.0, 0.71 * spc, 0.3, 45.0)]
+    x = synth.make_if(s, sats, 17 * spc, seed=3550)
+    return s, x, sats
+
+
+def resample_b1c(iq=False):
+    """B1C, fs = 40 MS/s, IF = 10 MHz, resampling on: 9-MHz band-pass, fs' = 29 MS/s (B1C/acquisition.m:54-123)."""
+    s = bds_amd.init_settings_b1c(samplingFreq=40e6, IF=10e6, acqSatelliteList=[3, 7, 12], acqSearchBand=500,
+                                  resamplingflag=1, resamplingThreshold=15e6, fileType=2 if iq else 1)
+    spc = spc_of(s)
+    sats = [synth.Sat(3, 230.0, 120000.3, 1.0, 46.0), synth.Sat(12, -410.0, 299000.8, 2.0, 44.0)]
+    x = synth.make_if(s, sats, 4 * spc, seed=13, iq_sign=-1 if iq else 0)
+    return s, x, sats
+
+
 def track_case(signal, mode, n_epochs, seed=21, iq=False):
     """Synthetic record + channels for the tracking tests at a reduced sampling rate.
 

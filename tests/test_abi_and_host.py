@@ -103,6 +103,28 @@ def test_host_helpers_match_oracle():
         assert abs(native.calc_weighing_factor(s) - otrk.calc_weighing_factor(s)) < 1e-9
 
 
+def test_resampling_plan_and_fir1_match_oracle():
+    """Host side of the resampling branch (acquisition.m:54-124): rate / IF choice and the fir1 taps
+    against the oracle's scipy restatement; the filter itself is checked on the GPU."""
+    import scipy.signal as ssig
+
+    from oracle import acquisition as oacq
+
+    assert native.resample_plan(bds_amd.init_settings_b2a()) is None  # resamplingflag = 0 (initSettings.m:89)
+    for s in (bds_amd.init_settings_b2a(resamplingflag=1),
+              bds_amd.init_settings_b1c(resamplingflag=1),
+              bds_amd.init_settings_b1c(samplingFreq=40e6, IF=10e6, resamplingflag=1, resamplingThreshold=15e6)):
+        fs, fi, wp = native.resample_plan(s)
+        x = np.zeros(6000)
+        _, s2, old = oacq.resample_condition(x, s)
+        assert (fs, fi) == (s2.samplingFreq, s2.IF) and old == (s.samplingFreq, s.IF)
+        b = native.fir1_bandpass(701, *wp)
+        ref = ssig.firwin(701, list(wp), window="hamming", pass_zero=False, scale=True)
+        np.testing.assert_allclose(b, ref, rtol=0, atol=2e-16 * np.abs(ref).max() * 701)
+        np.testing.assert_allclose(b, b[::-1], rtol=0, atol=1e-16)  # linear phase
+    assert native.resample_plan(bds_amd.init_settings_b1c(samplingFreq=12.5e6, resamplingflag=1)) is None  # fs below threshold
+
+
 def test_pre_run_matches_oracle():
     rng = np.random.default_rng(0)
     for sig, mk in (("B1C", bds_amd.init_settings_b1c), ("B2A", bds_amd.init_settings_b2a)):

@@ -9,7 +9,8 @@ import pytest
 import bds_amd
 from oracle import acquisition as oacq
 
-from helpers import as_complex, cfg1_b2a, cfg1_b2a_iq, medium_b2a, small_b1c, small_b1c_iq
+from helpers import (as_complex, cfg1_b2a, cfg1_b2a_iq, medium_b2a, resample_b1c, resample_b2a, small_b1c,
+                     small_b1c_iq)
 
 pytestmark = pytest.mark.gpu
 
@@ -73,6 +74,33 @@ def test_b1c_complex_iq_record(ctx):
     s, x, _ = small_b1c_iq()
     ref, got = _compare(s, as_complex(x), ctx, oacq.acquisition_b1c)
     assert got.carrFreq[2] != 0 and got.carrFreq[6] == 0
+
+
+def test_b2a_resampling_branch(ctx):
+    """resamplingflag = 1: fir1(700) + filtfilt + band-pass-sampling decimation before the search,
+    codePhase / carrFreq mapped back afterwards (B2a/acquisition.m:54-124, 339-356)."""
+    s, x, sats = resample_b2a()
+    ref = oacq.acquisition_b2a(x.astype(np.float64), s)
+    got = bds_amd.acquisition(x, s)
+    np.testing.assert_array_equal(got.codePhase, ref.codePhase)
+    np.testing.assert_array_equal(got.carrFreq, ref.carrFreq)
+    np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0)
+    for sat in sats:
+        assert abs(got.carrFreq[sat.prn - 1] - (s.IF + sat.doppler)) <= 25
+        assert abs(got.codePhase[sat.prn - 1] - 1 - sat.delay) <= 4  # 48 MS/s grid mapped back to 99 MS/s
+    assert got.carrFreq[20] == 0
+
+
+@pytest.mark.parametrize("iq", [False, True])
+def test_b1c_resampling_branch(ctx, iq):
+    s, x, sats = resample_b1c(iq)
+    xo = as_complex(x) if iq else x.astype(np.float64)
+    ref = oacq.acquisition_b1c(xo, s)
+    got = bds_amd.acquisition(xo if iq else x, s)
+    np.testing.assert_array_equal(got.codePhase, ref.codePhase)
+    np.testing.assert_array_equal(got.carrFreq, ref.carrFreq)
+    np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0)
+    assert got.carrFreq[2] != 0 and got.carrFreq[11] != 0 and got.carrFreq[6] == 0
 
 
 def test_prn_shards_sum_to_the_full_result(ctx):

@@ -74,8 +74,8 @@ def test_argument_errors_are_reported(ctx):
     with pytest.raises(bds_amd.native.BdsError, match="acquisition needs at least"):
         bds_amd.acquisition(x, s, verbose=False)
     x = np.zeros(17 * 99375, dtype=np.int8)
-    with pytest.raises(bds_amd.native.BdsError, match="resampling"):
-        bds_amd.acquisition(x, s.copy(resamplingflag=1, resamplingThreshold=1e6), verbose=False)
+    with pytest.raises(bds_amd.native.BdsError, match="resampling band edges"):  # fir1 would reject them
+        bds_amd.acquisition(x, s.copy(resamplingflag=1, IF=5e6), verbose=False)
     with pytest.raises(bds_amd.native.BdsError, match="out of 1..63"):
         bds_amd.acquisition(x, s.copy(acqSatelliteList=[64]), verbose=False)
     with pytest.raises(bds_amd.native.BdsError, match="acquisition needs at least"):
