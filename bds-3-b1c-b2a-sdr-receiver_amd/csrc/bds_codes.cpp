@@ -81,6 +81,21 @@ static void b2a_primary(int prn, bool pilot, int8_t *out) {
     }
 }
 
+// (w, p) of the pilot secondary codes (generate2ndCode.m:44-57), Weil codes over N = 3607
+static const uint16_t kB1cWpSecondary[63][2] = {
+    {269, 1889}, {1448, 1268}, {1028, 1593}, {1324, 1186}, {822, 1239}, {5, 1930},
+    {155, 176}, {458, 1696}, {310, 26}, {959, 1344}, {1238, 1271}, {1180, 1182},
+    {1288, 1381}, {334, 1604}, {885, 1333}, {1362, 1185}, {181, 31}, {1648, 704},
+    {838, 1190}, {313, 1646}, {750, 1385}, {225, 113}, {1477, 860}, {309, 1656},
+    {108, 1921}, {1457, 1173}, {149, 1928}, {322, 57}, {271, 150}, {576, 1214},
+    {1103, 1148}, {450, 1458}, {399, 1519}, {241, 1635}, {1045, 1257}, {164, 1687},
+    {513, 1382}, {687, 1514}, {422, 1}, {303, 1583}, {324, 1806}, {495, 1664},
+    {725, 1338}, {780, 1111}, {367, 1706}, {882, 1543}, {631, 1813}, {37, 228},
+    {647, 2871}, {1043, 2884}, {24, 1823}, {120, 75}, {134, 11}, {136, 63},
+    {158, 1937}, {214, 22}, {335, 1768}, {340, 1526}, {661, 1402}, {889, 1445},
+    {929, 1680}, {1002, 1290}, {1149, 1245}};
+static constexpr int kWeilN2 = 3607;
+
 static const std::vector<uint8_t> &legendre() {
     static std::vector<uint8_t> leg;
     static std::once_flag once;
@@ -102,6 +117,23 @@ static void b1c_primary(int prn, bool pilot, int8_t *out) {
     }
 }
 
+// generate2ndCode.m:59-84: 1800 chips, bipolar
+int gen_secondary(int prn, int8_t *out) {
+    if (prn < 1 || prn > BDS_MAX_PRN) return BDS_ERR_ARG;
+    static std::vector<uint8_t> leg;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        leg.assign(kWeilN2, 0);
+        for (long i = 1; i < kWeilN2; ++i) leg[(i * i) % kWeilN2] = 1;
+    });
+    const int w = kB1cWpSecondary[prn - 1][0], p = kB1cWpSecondary[prn - 1][1];
+    for (int ind = 0; ind < 1800; ++ind) {
+        const int k = (ind + p - 1) % kWeilN2;
+        out[ind] = (leg[k] ^ leg[(k + w) % kWeilN2]) ? -1 : 1;
+    }
+    return 1800;
+}
+
 int gen_primary(int signal, bool pilot, int prn, int8_t *out) {
     if (prn < 1 || prn > BDS_MAX_PRN) return BDS_ERR_ARG;
     if (signal == BDS_SIGNAL_B1C)
@@ -117,6 +149,10 @@ int gen_primary(int signal, bool pilot, int prn, int8_t *out) {
 
 extern "C" int bds_gen_code(int signal, int kind, int prn, int8_t *out, int n) {
     if (!out || prn < 1 || prn > BDS_MAX_PRN) return BDS_ERR_ARG;
+    if (kind == BDS_CODE_PILOT_SECONDARY) {
+        if (signal != BDS_SIGNAL_B1C || n < 1800) return BDS_ERR_ARG;
+        return bds::gen_secondary(prn, out);
+    }
     int8_t prim[10230];
     const bool pilot = (kind == BDS_CODE_PILOT_PRIMARY || kind == BDS_CODE_PILOT_BOC11 ||
                         kind == BDS_CODE_PILOT_BOC61);

@@ -13,6 +13,7 @@ namespace bds {
 
 // host code generation (bds_codes.cpp)
 int gen_primary(int signal, bool pilot, int prn, int8_t *out /*10230*/);
+int gen_secondary(int prn, int8_t *out /*1800*/);
 
 // MATLAB round(): half away from zero
 inline double m_round(double x) { return x >= 0 ? (double)(long long)(x + 0.5) : -(double)(long long)(-x + 0.5); }

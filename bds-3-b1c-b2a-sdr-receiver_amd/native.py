@@ -14,8 +14,8 @@ import numpy as np
 BDS_MAX_PRN = 63
 SIGNAL = {"B1C": 1, "B2A": 2}
 TRACK_MODE = {"B2A": 0, "NB": 1, "WB": 2}
-CODE_KIND = {"data": 0, "pilot": 1, "data_boc11": 2, "pilot_boc11": 3, "pilot_boc61": 4}
-CODE_LEN = {0: 10230, 1: 10230, 2: 20460, 3: 20460, 4: 122760}
+CODE_KIND = {"data": 0, "pilot": 1, "data_boc11": 2, "pilot_boc11": 3, "pilot_boc61": 4, "pilot_secondary": 5}
+CODE_LEN = {0: 10230, 1: 10230, 2: 20460, 3: 20460, 4: 122760, 5: 1800}
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbds_mi355x.so")
 
@@ -72,7 +72,7 @@ class Timing(C.Structure):
 
 EXPORTS = [
     "bds_create", "bds_destroy", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_gen_code", "bds_acquire",
-    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_acq_grid", "bds_acq_peaks", "bds_get_timing",
+    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_acq_grid", "bds_acq_peaks", "bds_get_timing",
     "bds_track", "bds_track_mem", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
     "bds_calc_weighing_factor", "bds_pre_run",
 ]
@@ -123,6 +123,9 @@ def lib():
     L.bds_calc_loop_coef_carr.restype, L.bds_calc_loop_coef_carr.argtypes = None, [SP, _DP, _DP, _DP]
     L.bds_calc_weighing_factor.restype, L.bds_calc_weighing_factor.argtypes = C.c_double, [SP]
     L.bds_pre_run.restype = i32
+    L.bds_frame_sync.restype = i32
+    L.bds_frame_sync.argtypes = [vp, i32, i32, _IP, _DP, i32, _IP, _IP, _IP, i32]
+    L.bds_sync_pattern.restype, L.bds_sync_pattern.argtypes = i32, [i32, i32, C.POINTER(C.c_int8), i32]
     L.bds_resample_plan.restype, L.bds_resample_plan.argtypes = i32, [SP, _DP, _DP, _DP]
     L.bds_fir1_bandpass.restype, L.bds_fir1_bandpass.argtypes = i32, [i32, C.c_double, C.c_double, _DP]
     L.bds_pre_run.argtypes = [SP, i32, _DP, _DP, _DP, C.POINTER(Channel)]
@@ -198,6 +201,15 @@ def gen_code(signal: str, kind: str, prn: int) -> np.ndarray:
     if rc < 0:
         raise BdsError(rc, f"bds_gen_code({signal}, {kind}, {prn})")
     return out
+
+
+def sync_pattern(signal: str, prn: int = 1) -> np.ndarray:
+    """+-1 frame-sync pattern: B1C pilot secondary code of the PRN (1800) or the B2a preamble x NH (120)."""
+    out = np.empty(1800, dtype=np.int8)
+    rc = lib().bds_sync_pattern(SIGNAL[signal.upper()], int(prn), out.ctypes.data_as(C.POINTER(C.c_int8)), out.size)
+    if rc < 0:
+        raise BdsError(rc, f"bds_sync_pattern({signal}, {prn})")
+    return out[:rc].copy()
 
 
 def gen_primary_code(signal: str, kind: str, prn: int) -> np.ndarray:
@@ -281,6 +293,23 @@ class Context:
                                           carr.ctypes.data_as(_DP), cph.ctypes.data_as(_DP),
                                           pm.ctypes.data_as(_DP), det.ctypes.data_as(_IP)))
         return carr, cph, pm, det
+
+    def frame_sync(self, signal, prns, prompt, cap=64):
+        """bds_frame_sync: prompt [n_ch, n] -> (xcorr int32 [n_ch, M], [1-based index arrays])."""
+        pr = np.ascontiguousarray(prompt, dtype=np.float64)
+        n_ch, n = pr.shape
+        sig = SIGNAL[str(signal).upper()]
+        m = 1800 if sig == SIGNAL["B1C"] else 120
+        M = max(n, m)
+        prn = np.ascontiguousarray(prns, dtype=np.int32)
+        xc = np.zeros((n_ch, M), dtype=np.int32)
+        idx = np.zeros((n_ch, cap), dtype=np.int32)
+        cnt = np.zeros(n_ch, dtype=np.int32)
+        self._check(self._lib.bds_frame_sync(self._h, sig, n_ch, prn.ctypes.data_as(_IP), pr.ctypes.data_as(_DP), n,
+                                             xc.ctypes.data_as(_IP), idx.ctypes.data_as(_IP), cnt.ctypes.data_as(_IP), cap))
+        if np.any(cnt > cap):
+            return self.frame_sync(signal, prns, prompt, cap=int(cnt.max()))
+        return xc, [idx[c, :cnt[c]].copy() for c in range(n_ch)]
 
     def acq_grid(self, n_prn, n_bins):
         rm = np.zeros(n_prn * n_bins, dtype=np.float32)

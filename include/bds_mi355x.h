@@ -37,7 +37,8 @@ enum {
     BDS_CODE_PILOT_PRIMARY = 1, /* 10230 chips                                               */
     BDS_CODE_DATA_BOC11 = 2,    /* B1C only, 20460 half-chips   generateDataBOC11.m:85-91    */
     BDS_CODE_PILOT_BOC11 = 3,   /* B1C only, 20460              generatePilotBOC11.m:88-94   */
-    BDS_CODE_PILOT_BOC61 = 4    /* B1C only, 122760             generatePilotBOC61.m:89-96   */
+    BDS_CODE_PILOT_BOC61 = 4,   /* B1C only, 122760             generatePilotBOC61.m:89-96   */
+    BDS_CODE_PILOT_SECONDARY = 5 /* B1C only, 1800 chips         generate2ndCode.m:59-84      */
 };
 
 enum {
@@ -223,6 +224,21 @@ BDS_API double bds_calc_weighing_factor(const bds_settings *s);
 /* preRun.m:61-76 (B1C applies Doppler aiding to codeFreq, B2a does not) */
 BDS_API int bds_pre_run(const bds_settings *s, int max_prn, const double *carrFreq,
                         const double *codePhase, const double *peakMetric, bds_channel *channel);
+/* ---- frame synchronisation correlators (the first consumers of trackResults) -------------
+ * B1C/include/BCNAV1decoding.m:66-91: bits = sign(Pilot_I_P) (wide-band tracking) or sign(Pilot_Q_P)
+ *   (narrow-band), XcorrResult = second half of xcorr(bits, generate2ndCode(PRN)) (1800 chips),
+ *   index = find(abs(XcorrResult) >= 1799.5).
+ * B2a/include/BCNAV2decoding.m:69-97: bits = sign(I_P), pattern = kron(preamble_bits, secondCode)
+ *   (120 taps), index = find(abs(.) > 115).
+ * prompt: double[n_ch * n] prompt-correlator series, one row per channel; prn[n_ch].
+ * xcorr (optional): int32[n_ch * M], M = max(n, pattern length): the correlation at lags 0..M-1.
+ * index (optional): int32[n_ch * cap], 1-based like find(); n_index[n_ch] = number of hits per
+ *   channel (may exceed cap).  Returns the total number of hits or <0.
+ * bds_sync_pattern: the +-1 pattern itself (1800 or 120 values). */
+BDS_API int bds_frame_sync(bds_ctx *ctx, int signal, int n_ch, const int32_t *prn, const double *prompt,
+                           int n, int32_t *xcorr, int32_t *index, int32_t *n_index, int cap);
+BDS_API int bds_sync_pattern(int signal, int prn, int8_t *out, int cap);
+
 /* The acquisition's resampling branch (B2a/acquisition.m:54-124, B1C/acquisition.m:54-123), taken
  * inside bds_acq_load when samplingFreq > resamplingThreshold && resamplingflag == 1.
  * bds_resample_plan: returns 1 and the sampling rate / IF acquisition() continues with (:103,:119)

@@ -13,6 +13,8 @@
  *       iq (optional, default false): longSignal holds interleaved I/Q pairs (fileType 2)
  *   out = bds_mex('track', path, channel, settings, signal)        % struct of [nCh x nEpochs] arrays
  *   code = bds_mex('gen_code', signal, kind, prn)
+ *   [XcorrResult, index] = bds_mex('frame_sync', signal, PRN, bits)   % one channel: second half of
+ *       xcorr(sign(bits), pattern) and find(abs(.) >= 1799.5) (B1C) / find(abs(.) > 115) (B2a)
  * signal: 1 = B1C, 2 = B2a (the reference keeps one directory per receiver).
  */
 #include <string.h>
@@ -183,6 +185,33 @@ static void do_gen_code(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs
     for (i = 0; i < n; ++i) p[i] = buf[i];
 }
 
+/* BCNAV1decoding.m:75-91 / BCNAV2decoding.m:84-97 for one channel */
+static void do_frame_sync(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+    int signal, n, m, M, i, total;
+    int32_t prn, cnt = 0, *xc, *idx;
+    double *p;
+    if (nrhs != 4 || !mxIsDouble(prhs[3])) mexErrMsgIdAndTxt("bds:args", "frame_sync: (signal, PRN, bits)");
+    signal = (int)mxGetScalar(prhs[1]);
+    prn = (int32_t)mxGetScalar(prhs[2]);
+    n = (int)mxGetNumberOfElements(prhs[3]);
+    m = signal == BDS_SIGNAL_B1C ? 1800 : 120;
+    M = n > m ? n : m;
+    xc = (int32_t *)mxCalloc((size_t)M, sizeof(int32_t));
+    idx = (int32_t *)mxCalloc((size_t)M, sizeof(int32_t));
+    total = bds_frame_sync(ctx(), signal, 1, &prn, mxGetDoubles(prhs[3]), n, xc, idx, &cnt, M);
+    if (total < 0) mexErrMsgIdAndTxt("bds:frame_sync", "%s", bds_last_error(g_ctx));
+    plhs[0] = mxCreateDoubleMatrix(1, M, mxREAL);
+    p = mxGetDoubles(plhs[0]);
+    for (i = 0; i < M; ++i) p[i] = xc[i];
+    if (nlhs > 1) {
+        plhs[1] = mxCreateDoubleMatrix(cnt, 1, mxREAL); /* index = find(...)' is a column */
+        p = mxGetDoubles(plhs[1]);
+        for (i = 0; i < cnt; ++i) p[i] = idx[i];
+    }
+    mxFree(xc);
+    mxFree(idx);
+}
+
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     char cmd[32];
     if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof(cmd))) mexErrMsgIdAndTxt("bds:args", "first argument: command string");
@@ -192,6 +221,8 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         do_track(nlhs, plhs, nrhs, prhs);
     else if (!strcmp(cmd, "gen_code"))
         do_gen_code(nlhs, plhs, nrhs, prhs);
+    else if (!strcmp(cmd, "frame_sync"))
+        do_frame_sync(nlhs, plhs, nrhs, prhs);
     else
         mexErrMsgIdAndTxt("bds:args", "unknown command %s", cmd);
 }

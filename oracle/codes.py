@@ -136,6 +136,23 @@ def make_b2a_pilot_table(prn: int, settings) -> np.ndarray:
     return _b2a_table(generate_b2a_pilot_code(prn, settings), settings)
 
 
+# (w, p) of the B1C pilot secondary codes, PRN 1..63 (generate2ndCode.m:44-57; BDS-SIS-ICD-B1C table)
+B1C_WP_SECONDARY = [
+    (269, 1889), (1448, 1268), (1028, 1593), (1324, 1186), (822, 1239), (5, 1930),
+    (155, 176), (458, 1696), (310, 26), (959, 1344), (1238, 1271), (1180, 1182),
+    (1288, 1381), (334, 1604), (885, 1333), (1362, 1185), (181, 31), (1648, 704),
+    (838, 1190), (313, 1646), (750, 1385), (225, 113), (1477, 860), (309, 1656),
+    (108, 1921), (1457, 1173), (149, 1928), (322, 57), (271, 150), (576, 1214),
+    (1103, 1148), (450, 1458), (399, 1519), (241, 1635), (1045, 1257), (164, 1687),
+    (513, 1382), (687, 1514), (422, 1), (303, 1583), (324, 1806), (495, 1664),
+    (725, 1338), (780, 1111), (367, 1706), (882, 1543), (631, 1813), (37, 228),
+    (647, 2871), (1043, 2884), (24, 1823), (120, 75), (134, 11), (136, 63),
+    (158, 1937), (214, 22), (335, 1768), (340, 1526), (661, 1402), (889, 1445),
+    (929, 1680), (1002, 1290), (1149, 1245),
+]
+B1C_SECONDARY_N = 3607  # generate2ndCode.m:61
+
+
 # --- B1C ----------------------------------------------------------------------
 @functools.lru_cache(maxsize=None)
 def legendre_sequence(n: int = B1C_WEIL_N) -> np.ndarray:
@@ -180,6 +197,19 @@ def b1c_primary(prn: int, kind: str, code_length: int = 10230) -> np.ndarray:
     leg = legendre_sequence()
     n = B1C_WEIL_N
     ind = np.arange(code_length, dtype=np.int64)
+    k = (ind + p - 1) % n
+    bits = leg[k] ^ leg[(k + w) % n]
+    return (1 - 2 * bits.astype(np.int64)).astype(np.float64)
+
+
+def generate_2nd_code(prn: int) -> np.ndarray:
+    """generate2ndCode.m:59-84: 1800-chip pilot secondary code, bipolar.
+
+    bit(ind) = L[k] xor L[(k+w) mod N], k = (ind + p - 1) mod N, N = 3607, ind = 0..1799."""
+    w, p = B1C_WP_SECONDARY[prn - 1]
+    n = B1C_SECONDARY_N
+    leg = legendre_sequence(n)
+    ind = np.arange(1800, dtype=np.int64)
     k = (ind + p - 1) % n
     bits = leg[k] ^ leg[(k + w) % n]
     return (1 - 2 * bits.astype(np.int64)).astype(np.float64)
