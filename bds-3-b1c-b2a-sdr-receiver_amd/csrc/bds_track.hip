@@ -491,18 +491,20 @@ static void for_each_field(bds_track_out *o, TrkOut *d, F f) {
 }
 
 // include/Calc_CNo_PLD.m (B1C :45-114, B2a :38-100) over prompt values [k-M, k)
-static void cno_pld_one(const double *I, const double *Q, int M, double T, double *lin, double *cno, double *pld) {
+__device__ static void cno_pld_one(const double *I, const double *Q, int M, double T, double *lin, double *cno, double *pld) {
     double zm = 0;
-    std::vector<double> z((size_t)M);
-    for (int i = 0; i < M; ++i) z[i] = I[i] * I[i] + Q[i] * Q[i], zm += z[i];
+    for (int i = 0; i < M; ++i) zm += I[i] * I[i] + Q[i] * Q[i];
     zm /= M;
     double zv = 0;
-    for (int i = 0; i < M; ++i) zv += (z[i] - zm) * (z[i] - zm);
+    for (int i = 0; i < M; ++i) {
+        const double z = I[i] * I[i] + Q[i] * Q[i];
+        zv += (z - zm) * (z - zm);
+    }
     zv /= (M - 1);  // var(): N-1
-    const double pav = std::sqrt(zm * zm - zv);
+    const double pav = sqrt(zm * zm - zv);
     const double nv = 0.5 * (zm - pav);
-    *lin = std::fabs((1 / T) * pav / (2 * nv));
-    *cno = 10 * std::log10(*lin);
+    *lin = fabs((1 / T) * pav / (2 * nv));
+    *cno = 10 * log10(*lin);
     double sp = 0, sn = 0, sq = 0;
     for (int i = 0; i < M; ++i) {
         if (I[i] > 0) sp += I[i];
@@ -511,6 +513,49 @@ static void cno_pld_one(const double *I, const double *Q, int M, double T, doubl
     }
     const double a = (sp - sn) * (sp - sn);
     *pld = (a - sq * sq) / (a + sq * sq);
+}
+
+// C/N0 + phase-lock detector of every finished CNoInterval (tracking.m:411-434), on the device arrays the
+// tracking loop just wrote: one workgroup per channel, one thread per interval, then the reference's
+// two-point smoothing CNo = new/2 + previous/2 (:420-421; previous = 0 before the first interval).
+// cno5: [5][n_ch][n_cno] = DataCNo, DataPLD, PilotCNo, PilotPLD, SigCNo; pm: 0 no pilot, 1 pilot with
+// I/Q swapped (narrow-band, Calc_CNo_PLD.m:84-87), 2 pilot as is (wide-band).
+__global__ __launch_bounds__(256) void k_trk_cno(TrkOut o, const ChanState *__restrict__ st, int n_epochs, int M,
+                                                 int n_cno, int pm, double T, double *__restrict__ raw3,
+                                                 double *__restrict__ cno5) {
+    const int ch = blockIdx.x, n_ch = gridDim.x;
+    const int done = st[ch].prn ? st[ch].completed : 0;
+    const size_t plane = (size_t)n_ch * n_cno;
+    double *r = raw3 + (size_t)ch * n_cno * 3;
+    for (int q = threadIdx.x; q < n_cno; q += blockDim.x) {
+        const size_t e = (size_t)ch * n_cno + q;
+        for (int f = 0; f < 5; ++f) cno5[f * plane + e] = 0;
+        r[q * 3 + 0] = r[q * 3 + 1] = r[q * 3 + 2] = 0;
+        if ((q + 1) * M > done) continue;
+        const size_t o0 = (size_t)ch * n_epochs + (size_t)q * M;
+        double dlin, dcno, dpld, plin = 0, pcno = 0, ppld = 0;
+        cno_pld_one(o.I_P + o0, o.Q_P + o0, M, T, &dlin, &dcno, &dpld);
+        if (pm == 2)
+            cno_pld_one(o.Pilot_I_P + o0, o.Pilot_Q_P + o0, M, T, &plin, &pcno, &ppld);
+        else if (pm == 1)
+            cno_pld_one(o.Pilot_Q_P + o0, o.Pilot_I_P + o0, M, T, &plin, &pcno, &ppld);
+        r[q * 3 + 0] = dcno;
+        r[q * 3 + 1] = pcno;
+        r[q * 3 + 2] = 10 * log10(dlin + plin);
+        cno5[1 * plane + e] = dpld;
+        if (pm) cno5[3 * plane + e] = ppld;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < n_cno; q += blockDim.x) {
+        if ((q + 1) * M > done) continue;
+        const size_t e = (size_t)ch * n_cno + q;
+        const double p0 = q ? r[(q - 1) * 3 + 0] : 0.0, p1 = q ? r[(q - 1) * 3 + 1] : 0.0, p2 = q ? r[(q - 1) * 3 + 2] : 0.0;
+        cno5[0 * plane + e] = r[q * 3 + 0] * 0.5 + p0 * 0.5;
+        if (pm) {
+            cno5[2 * plane + e] = r[q * 3 + 1] * 0.5 + p1 * 0.5;
+            cno5[4 * plane + e] = r[q * 3 + 2] * 0.5 + p2 * 0.5;
+        }
+    }
 }
 
 static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_bytes, size_t n_bytes, bool on_device,
@@ -645,40 +690,31 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_byte
         out->completed[c] = hs[c].completed;
         if (hs[c].completed == n_epochs) out->status[c] = channel[c].status;  // :441
     }
-    // C/N0 + lock detector post-pass (tracking.m:411-434)
+    // C/N0 + lock detector (tracking.m:411-434): computed on the device from the arrays above
     const int M = s->CNoInterval;
     if (M > 1 && out->n_cno > 0 && out->DataCNo) {
         const int pm = p.pilot ? (p.mode == BDS_TRACK_WB ? 2 : 1) : 0;
-        for (int c = 0; c < n_ch; ++c) {
-            for (int q = 0; q < out->n_cno; ++q) {
-                const size_t e = (size_t)c * out->n_cno + q;
-                out->DataCNo[e] = 0;
-                if (out->DataPLD) out->DataPLD[e] = 0;
-                if (out->PilotCNo) out->PilotCNo[e] = 0;
-                if (out->PilotPLD) out->PilotPLD[e] = 0;
-                if (out->SigCNo) out->SigCNo[e] = 0;
-            }
-            double prev[3] = {0, 0, 0};
-            for (int q = 0; q < out->n_cno && (q + 1) * M <= out->completed[c]; ++q) {
-                const size_t o0 = (size_t)c * n_epochs + (size_t)q * M, e = (size_t)c * out->n_cno + q;
-                double dlin, dcno, dpld, plin = 0, pcno = 0, ppld = 0;
-                cno_pld_one(out->I_P + o0, out->Q_P + o0, M, s->intTime, &dlin, &dcno, &dpld);
-                if (pm == 2 && out->Pilot_I_P && out->Pilot_Q_P)
-                    cno_pld_one(out->Pilot_I_P + o0, out->Pilot_Q_P + o0, M, s->intTime, &plin, &pcno, &ppld);
-                else if (pm == 1 && out->Pilot_I_P && out->Pilot_Q_P)  // I/Q swapped (Calc_CNo_PLD.m:84-87)
-                    cno_pld_one(out->Pilot_Q_P + o0, out->Pilot_I_P + o0, M, s->intTime, &plin, &pcno, &ppld);
-                const double c3 = 10 * std::log10(dlin + plin);
-                out->DataCNo[e] = dcno * 0.5 + prev[0] * 0.5;  // :420-421
-                if (out->DataPLD) out->DataPLD[e] = dpld;
-                if (pm) {
-                    if (out->PilotCNo) out->PilotCNo[e] = pcno * 0.5 + prev[1] * 0.5;
-                    if (out->SigCNo) out->SigCNo[e] = c3 * 0.5 + prev[2] * 0.5;
-                    if (out->PilotPLD) out->PilotPLD[e] = ppld;
+        const int nq = out->n_cno;
+        double *d_raw = nullptr, *d_cno = nullptr;
+        BDS_HIP(ctx, hipMalloc((void **)&d_raw, sizeof(double) * (size_t)n_ch * nq * 3));
+        BDS_HIP(ctx, hipMalloc((void **)&d_cno, sizeof(double) * (size_t)n_ch * nq * 5));
+        BDS_HIP(ctx, hipMemcpyAsync(d_st, hs.data(), sizeof(ChanState) * n_ch, hipMemcpyHostToDevice, st(ctx)));
+        hipLaunchKernelGGL(k_trk_cno, dim3(n_ch), dim3(256), 0, st(ctx), d, (const ChanState *)d_st, n_epochs, M, nq, pm,
+                           s->intTime, d_raw, d_cno);
+        std::vector<double> h((size_t)n_ch * nq * 5);
+        BDS_HIP(ctx, hipMemcpyAsync(h.data(), d_cno, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st(ctx)));
+        BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+        (void)hipFree(d_raw);
+        (void)hipFree(d_cno);
+        double *dst[5] = {out->DataCNo, out->DataPLD, out->PilotCNo, out->PilotPLD, out->SigCNo};
+        const size_t plane = (size_t)n_ch * nq;
+        for (int f = 0; f < 5; ++f) {
+            if (!dst[f]) continue;
+            for (int c = 0; c < n_ch; ++c)
+                for (int q = 0; q < nq; ++q) {
+                    const bool live = out->completed[c] > 0 && (q + 1) * M <= out->completed[c] && (pm || f < 2);
+                    dst[f][(size_t)c * nq + q] = live ? h[f * plane + (size_t)c * nq + q] : 0.0;
                 }
-                prev[0] = dcno;
-                prev[1] = pcno;
-                prev[2] = c3;
-            }
         }
     }
     for (double *a : allocs) (void)hipFree(a);
