@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <vector>
 
 #include "bds_internal.h"
@@ -39,6 +40,20 @@ __global__ __launch_bounds__(256) void k_sync_xcorr(const int8_t *__restrict__ b
         const int kmax = lag < n ? min(m, n - lag) : 0;
         for (int k = 0; k < kmax; ++k) acc += (int)b[lag + k] * (int)s_pat[k];
         out[(long)ch * M + lag] = acc;
+    }
+}
+
+// B2a/include/unpack_cplx.m:16-63: byte -> (I1, Q1, I2, Q2) int8; low nibble first; per nibble bit 0 / 1
+// = sign of I / Q, bit 2 / 3 = magnitude 1 or 3 of I / Q.  One 32-bit store per input byte.
+__device__ __forceinline__ uint32_t unpack_nibble(uint32_t v) {
+    const int i = ((v & 4) ? 3 : 1) * ((v & 1) ? -1 : 1);
+    const int q = ((v & 8) ? 3 : 1) * ((v & 2) ? -1 : 1);
+    return (uint32_t)(uint8_t)(int8_t)i | ((uint32_t)(uint8_t)(int8_t)q << 8);
+}
+__global__ __launch_bounds__(256) void k_unpack_cplx(const uint8_t *__restrict__ in, size_t n, uint32_t *__restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t b = in[i];
+        out[i] = unpack_nibble(b & 15u) | (unpack_nibble(b >> 4) << 16);
     }
 }
 
@@ -123,4 +138,54 @@ extern "C" int bds_frame_sync(bds_ctx *ctx, int signal, int n_ch, const int32_t 
         total += cnt;
     }
     return total;
+}
+
+extern "C" int bds_unpack_cplx(bds_ctx *ctx, const uint8_t *in, size_t n_bytes, int8_t *out) {
+    if (!ctx || (!in && n_bytes) || (!out && n_bytes)) return BDS_ERR_ARG;
+    if (n_bytes == 0) return BDS_OK;
+    BDS_HIP(ctx, hipSetDevice(ctx->device));
+    uint8_t *d_in = nullptr;
+    uint32_t *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_in, n_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, 4 * n_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, n_bytes, hipMemcpyHostToDevice, st(ctx));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_unpack_cplx, dim3((unsigned)std::min<size_t>(8192, (n_bytes + 255) / 256)), dim3(256), 0, st(ctx),
+                           (const uint8_t *)d_in, n_bytes, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 4 * n_bytes, hipMemcpyDeviceToHost, st(ctx));
+    if (e == hipSuccess) e = hipStreamSynchronize(st(ctx));
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, BDS_ERR_HIP, "bds_unpack_cplx: %s", hipGetErrorString(e));
+    return BDS_OK;
+}
+
+// unpack_cplx(filename_in, filename_out): 4e6-byte pieces in the reference (:11), 64 MiB here
+extern "C" int bds_unpack_cplx_file(bds_ctx *ctx, const char *path_in, const char *path_out) {
+    if (!ctx || !path_in || !path_out) return BDS_ERR_ARG;
+    FILE *fi = fopen(path_in, "rb");
+    if (!fi) return fail(ctx, BDS_ERR_IO, "Unable to read file %s", path_in);
+    FILE *fo = fopen(path_out, "wb");
+    if (!fo) {
+        fclose(fi);
+        return fail(ctx, BDS_ERR_IO, "Unable to write file %s", path_out);
+    }
+    const size_t piece = 64u << 20;
+    std::vector<uint8_t> a(piece);
+    std::vector<int8_t> b(4 * piece);
+    int rc = BDS_OK;
+    for (;;) {
+        const size_t n = fread(a.data(), 1, piece, fi);
+        if (n == 0) break;
+        if ((rc = bds_unpack_cplx(ctx, a.data(), n, b.data()))) break;
+        if (fwrite(b.data(), 1, 4 * n, fo) != 4 * n) {
+            rc = fail(ctx, BDS_ERR_IO, "short write on %s", path_out);
+            break;
+        }
+    }
+    fclose(fi);
+    fclose(fo);
+    return rc;
 }

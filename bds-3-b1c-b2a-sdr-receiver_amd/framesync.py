@@ -15,6 +15,12 @@ import numpy as np
 from .acquisition import get_context
 
 
+def unpack_cplx(filename_in, filename_out, device: int = 0):
+    """unpack_cplx(filename_in, filename_out) -- B2a/include/unpack_cplx.m: packed 2+2-bit I/Q bytes
+    to the int8 pairs of a fileType-2 record (device kernel, one 32-bit store per input byte)."""
+    get_context(device).unpack_cplx_file(filename_in, filename_out)
+
+
 def frame_sync(track_results, settings, device: int = 0):
     """[(XcorrResult, index), ...] for every tracked channel (PRN != 0) of ``track_results``."""
     b1c = str(settings.signal).upper() == "B1C"

@@ -72,7 +72,7 @@ class Timing(C.Structure):
 
 EXPORTS = [
     "bds_create", "bds_destroy", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_gen_code", "bds_acquire",
-    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_acq_grid", "bds_acq_peaks", "bds_get_timing",
+    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_get_timing",
     "bds_track", "bds_track_mem", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
     "bds_calc_weighing_factor", "bds_pre_run",
 ]
@@ -126,6 +126,8 @@ def lib():
     L.bds_frame_sync.restype = i32
     L.bds_frame_sync.argtypes = [vp, i32, i32, _IP, _DP, i32, _IP, _IP, _IP, i32]
     L.bds_sync_pattern.restype, L.bds_sync_pattern.argtypes = i32, [i32, i32, C.POINTER(C.c_int8), i32]
+    L.bds_unpack_cplx.restype, L.bds_unpack_cplx.argtypes = i32, [vp, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int8)]
+    L.bds_unpack_cplx_file.restype, L.bds_unpack_cplx_file.argtypes = i32, [vp, C.c_char_p, C.c_char_p]
     L.bds_resample_plan.restype, L.bds_resample_plan.argtypes = i32, [SP, _DP, _DP, _DP]
     L.bds_fir1_bandpass.restype, L.bds_fir1_bandpass.argtypes = i32, [i32, C.c_double, C.c_double, _DP]
     L.bds_pre_run.argtypes = [SP, i32, _DP, _DP, _DP, C.POINTER(Channel)]
@@ -310,6 +312,17 @@ class Context:
         if np.any(cnt > cap):
             return self.frame_sync(signal, prns, prompt, cap=int(cnt.max()))
         return xc, [idx[c, :cnt[c]].copy() for c in range(n_ch)]
+
+    def unpack_cplx(self, data):
+        """bds_unpack_cplx: uint8[n] packed samples -> int8[4n] I/Q pairs (unpack_cplx.m)."""
+        d = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        out = np.empty(4 * d.size, dtype=np.int8)
+        self._check(self._lib.bds_unpack_cplx(self._h, d.ctypes.data_as(C.POINTER(C.c_uint8)), d.size,
+                                              out.ctypes.data_as(C.POINTER(C.c_int8))))
+        return out
+
+    def unpack_cplx_file(self, filename_in, filename_out):
+        self._check(self._lib.bds_unpack_cplx_file(self._h, os.fsencode(filename_in), os.fsencode(filename_out)))
 
     def acq_grid(self, n_prn, n_bins):
         rm = np.zeros(n_prn * n_bins, dtype=np.float32)

@@ -239,6 +239,13 @@ BDS_API int bds_frame_sync(bds_ctx *ctx, int signal, int n_ch, const int32_t *pr
                            int n, int32_t *xcorr, int32_t *index, int32_t *n_index, int cap);
 BDS_API int bds_sync_pattern(int signal, int prn, int8_t *out, int cap);
 
+/* B2a/include/unpack_cplx.m: converter of packed records (one byte = two complex samples, 2-bit
+ * sign/magnitude I and Q each) into the int8 I/Q pairs of a fileType-2 record.
+ * out: int8[4 * n_bytes] = I1, Q1, I2, Q2 per input byte.  The file variant mirrors
+ * unpack_cplx(filename_in, filename_out). */
+BDS_API int bds_unpack_cplx(bds_ctx *ctx, const uint8_t *in, size_t n_bytes, int8_t *out);
+BDS_API int bds_unpack_cplx_file(bds_ctx *ctx, const char *path_in, const char *path_out);
+
 /* The acquisition's resampling branch (B2a/acquisition.m:54-124, B1C/acquisition.m:54-123), taken
  * inside bds_acq_load when samplingFreq > resamplingThreshold && resamplingflag == 1.
  * bds_resample_plan: returns 1 and the sampling rate / IF acquisition() continues with (:103,:119)

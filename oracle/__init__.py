@@ -19,6 +19,9 @@ restatement instead (tests/test_oracle_*.py):
   * synthetic-IF round trips (injected PRN / Doppler / code delay recovered by
     acquisition, tracking loops lock with the documented I/Q conventions);
   * agreement with the independent C++/HIP implementation behind the C ABI.
+One exception is pinned by the reference itself: the packed-sample converter (oracle/unpack.py) is
+checked against the four literal look-up tables of B2a/include/unpack_cplx.m:32-35
+(tests/golden/unpack_cplx_lut.npz).
 
 Path abbreviations used in citations (all under /root/reference/BDS3_B1C_B2a):
   B1C/...    = BDS-3_B1C/...
