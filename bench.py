@@ -188,8 +188,9 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": {0: "f32 search + f64 refinement", 1: "f32 search on f16-stored spectra + f64 refinement",
-                  2: "f16 search (packed v_pk_*_f16, f32 magnitudes) + f64 refinement"}[int(tm.get("half_storage", 0))],
+        "dtype": {0: "f32", 1: "f32", 2: "f16"}[int(tm.get("half_storage", 0))],
+        "dtype_detail": {0: "f32 search + f64 refinement", 1: "f32 search on f16-stored spectra + f64 refinement",
+                         2: "f16 search (packed v_pk_*_f16, f32 magnitudes) + f64 refinement of every candidate"}[int(tm.get("half_storage", 0))],
         "data": "synthetic",
         "config": {"workload": label, "prns": p_total, "doppler_bins": n_bins, "n_circ": n_circ,
                    "fft_len": tm["fft_len"], "components": ncomp, "parallelism": f"prn-shard x{world}",
