@@ -91,7 +91,7 @@ def cpu_baseline(s, x, name, budget_s=20.0):
                       f"{dt:.1f} s, scipy.fft workers={cores}; float64 NumPy restatement of acquisition.m, not MATLAB"}
 
 
-def tracking_leg(name, local_rank):
+def tracking_leg(name, local_rank, base):
     """Second half of the hot path, reported beside the headline metric (not part of `value`):
     closed-loop tracking of 12 channels at 99.375 MS/s on a synthetic int8 record resident in HBM
     (BASELINE.json configs[3] shape, shortened): B1C wide-band, 10-ms epochs / B2a, 1-ms epochs."""
@@ -99,12 +99,14 @@ def tracking_leg(name, local_rank):
 
     import bds_amd
 
+    # same front end as the acquisition workload (fs = 99.375 MS/s)
     if name == "b1c":
-        epochs, spc, mode = 60, 993750, "WB"
-        s = bds_amd.init_settings_b1c(msToProcess=epochs * 10, numberOfChannels=12, pilotTRKflag=2)
+        epochs, mode = 60, "WB"
+        s = base.copy(msToProcess=epochs * 10, numberOfChannels=12, pilotTRKflag=2)
     else:
-        epochs, spc, mode = 600, 99375, "B2A"
-        s = bds_amd.init_settings_b2a(msToProcess=epochs, numberOfChannels=12)
+        epochs, mode = 600, "B2A"
+        s = base.copy(msToProcess=epochs, numberOfChannels=12)
+    spc = int(np.floor(s.samplingFreq / (s.codeFreqBasis / s.codeLength) + 0.5))
     rng = np.random.default_rng(1)
     x = np.clip(np.rint(rng.normal(0, 20, (epochs + 2) * spc)), -127, 127).astype(np.int8)
     ch = [SimpleNamespace(PRN=p, acquiredFreq=s.IF + 100.0 * i, codePhase=float(1000 * i + 1), codeFreq=s.codeFreqBasis,
@@ -115,7 +117,8 @@ def tracking_leg(name, local_rank):
     dev_ms = ctx.timing()["total_ms"]
     samples = float(sum(np.diff(r.absoluteSample).sum() + spc for r in res))
     epoch_s = 0.010 if name == "b1c" else 0.001
-    return {"mode": mode, "channels": 12, "epochs": epochs, "ms_per_epoch": dev_ms / epochs,
+    assert all(r.completed == epochs for r in res), [r.completed for r in res]
+    return {"mode": mode, "channels": 12, "epochs": epochs, "fs_MHz": s.samplingFreq / 1e6, "ms_per_epoch": dev_ms / epochs,
             "channel_Msamples_per_s": samples / dev_ms / 1e3, "x_realtime_12ch": epoch_s * epochs / (dev_ms * 1e-3),
             "note": "device time of the epoch loop (two dependent launches per epoch, record in HBM); noise-only record"}
 
@@ -240,7 +243,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(s, x, args.workload)
         else:
             out["cpu_baseline"] = None
-        out["tracking"] = tracking_leg(args.workload, local_rank) if world == 1 and not args.no_tracking else None
+        out["tracking"] = tracking_leg(args.workload, local_rank, s) if world == 1 and not args.no_tracking else None
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
