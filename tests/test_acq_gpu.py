@@ -103,6 +103,25 @@ def test_b1c_resampling_branch(ctx, iq):
     assert got.carrFreq[2] != 0 and got.carrFreq[11] != 0 and got.carrFreq[6] == 0
 
 
+def test_fp16_overflow_fallback_reruns_in_fp32(ctx, monkeypatch):
+    """A non-finite value in the fp16 search grid makes bds_acq_run repeat the whole search with fp32
+    storage (forced here through the library's test hook); same acqResults, and the resampled
+    settings survive the re-run."""
+    for s, x, fn in ((cfg1_b2a()[0], cfg1_b2a()[1], oacq.acquisition_b2a),
+                     (resample_b1c()[0], resample_b1c()[1], oacq.acquisition_b1c)):
+        ref = fn(x.astype(np.float64), s)
+        monkeypatch.setenv("BDS_ACQ_TEST_FORCE_FALLBACK", "1")
+        got = bds_amd.acquisition(x, s, verbose=False)
+        assert ctx.timing()["half_storage"] == 0
+        monkeypatch.delenv("BDS_ACQ_TEST_FORCE_FALLBACK")
+        np.testing.assert_array_equal(got.codePhase, ref.codePhase)
+        np.testing.assert_array_equal(got.carrFreq, ref.carrFreq)
+        np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0)
+        # a different configuration re-enables the fp16 path
+        bds_amd.acquisition(*small_b1c()[1::-1], verbose=False)
+        assert ctx.timing()["half_storage"] == 2
+
+
 def test_prn_shards_sum_to_the_full_result(ctx):
     s, x, _ = medium_b2a()
     full = bds_amd.acquisition(x, s, verbose=False)
