@@ -886,17 +886,29 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         a.rows_cap = (size_t)P * D;
     }
 
+    // events of this run; released on every exit path
+    struct EventPool {
+        std::vector<hipEvent_t> all;
+        hipError_t make(hipEvent_t *e, unsigned flags = 0) {
+            const hipError_t rc_ = flags ? hipEventCreateWithFlags(e, flags) : hipEventCreate(e);
+            if (rc_ == hipSuccess) all.push_back(*e);
+            return rc_;
+        }
+        ~EventPool() {
+            for (hipEvent_t e : all) (void)hipEventDestroy(e);
+        }
+    } evp;
     hipEvent_t ev0, ev1, ev2, ev3;
-    BDS_HIP(ctx, hipEventCreate(&ev0));
-    BDS_HIP(ctx, hipEventCreate(&ev1));
-    BDS_HIP(ctx, hipEventCreate(&ev2));
-    BDS_HIP(ctx, hipEventCreate(&ev3));
+    BDS_HIP(ctx, evp.make(&ev0));
+    BDS_HIP(ctx, evp.make(&ev1));
+    BDS_HIP(ctx, evp.make(&ev2));
+    BDS_HIP(ctx, evp.make(&ev3));
     constexpr int kSamples = 32;
     hipEvent_t sa[kSamples], sb[kSamples];
     int nsamp = 0;
     for (int i = 0; i < kSamples; ++i) {
-        BDS_HIP(ctx, hipEventCreate(&sa[i]));
-        BDS_HIP(ctx, hipEventCreate(&sb[i]));
+        BDS_HIP(ctx, evp.make(&sa[i]));
+        BDS_HIP(ctx, evp.make(&sb[i]));
     }
     BDS_HIP(ctx, hipEventRecord(ev0, st(ctx)));
 
@@ -948,8 +960,8 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     long pair_idx = 0;
     hipEvent_t ev_rows[2], ev_cols[2];
     for (int i = 0; i < 2; ++i) {
-        BDS_HIP(ctx, hipEventCreateWithFlags(&ev_rows[i], hipEventDisableTiming));
-        BDS_HIP(ctx, hipEventCreateWithFlags(&ev_cols[i], hipEventDisableTiming));
+        BDS_HIP(ctx, evp.make(&ev_rows[i], hipEventDisableTiming));
+        BDS_HIP(ctx, evp.make(&ev_cols[i], hipEventDisableTiming));
     }
     const hipStream_t s_main = st(ctx), s_cols = (hipStream_t)ctx->stream2;
     // Running the column pass of group k beside the row pass of group k+1 on a second stream was
@@ -1073,8 +1085,6 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             a.sC = 1.f;
             a.cs_slot.clear();
             // (a.half stays off until the configuration changes: acq_configure keeps it for the same key)
-            for (hipEvent_t e : {ev0, ev1, ev2, ev3, ev_rows[0], ev_rows[1], ev_cols[0], ev_cols[1]}) (void)hipEventDestroy(e);
-            for (int i = 0; i < kSamples; ++i) (void)hipEventDestroy(sa[i]), (void)hipEventDestroy(sb[i]);
             if ((rc = bds_acq_prepare(ctx, s_in))) return rc;
             return bds_acq_run(ctx, s_in, prn_list, n_prn, max_prn, carrFreq, codePhase, peakMetric, detected);
         }
@@ -1369,9 +1379,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     t.n_bins = D;
     t.n_prn = P;
     t.n_comp = ncomp;
-    t.half_storage = a.hmath ? 2 : a.half ? 1 : 0;  // 0 fp32; 1 fp16 storage, fp32 arithmetic; 2 fp16 storage and arithmetic  // storage of the spectra / inter-pass buffer: 1 = fp16 complex
-    for (hipEvent_t e : {ev0, ev1, ev2, ev3, ev_rows[0], ev_rows[1], ev_cols[0], ev_cols[1]}) (void)hipEventDestroy(e);
-    for (int i = 0; i < kSamples; ++i) (void)hipEventDestroy(sa[i]), (void)hipEventDestroy(sb[i]);
+    t.half_storage = a.hmath ? 2 : a.half ? 1 : 0;  // 0 fp32; 1 fp16 storage, fp32 arithmetic; 2 fp16 storage and arithmetic
     return BDS_OK;
 }
 

@@ -605,10 +605,21 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_byte
     // correlate grid: blksize stays near codeLength*fs/codeFreq; allow +-2 % code-rate excursions
     long max_blk = (long)std::ceil((double)s->codeLength / ((min_code_freq < 1e299 ? min_code_freq : s->codeFreqBasis) * 0.98 / s->samplingFreq)) + 2;
     const int nblocks = (int)((max_blk + p.chunk - 1) / p.chunk);
+    // per-call device buffers, released on every exit path
+    struct DevScope {
+        std::vector<void *> p;
+        void add(void *q) { p.push_back(q); }
+        ~DevScope() {
+            for (void *q : p)
+                if (q) (void)hipFree(q);
+        }
+    } scope;
     ChanState *d_st = nullptr;
     double *d_part = nullptr;
     BDS_HIP(ctx, hipMalloc((void **)&d_st, sizeof(ChanState) * n_ch));
+    scope.add(d_st);
     BDS_HIP(ctx, hipMalloc((void **)&d_part, sizeof(double) * (size_t)n_ch * nblocks * kNSums));
+    scope.add(d_part);
     BDS_HIP(ctx, hipMemcpyAsync(d_st, hs.data(), sizeof(ChanState) * n_ch, hipMemcpyHostToDevice, st(ctx)));
     // device result arrays, initialised like the reference template (tracking.m:48-82)
     const size_t ne = (size_t)n_ch * n_epochs;
@@ -625,6 +636,7 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_byte
             return;
         }
         allocs.push_back(dev);
+        scope.add(dev);
         std::fill(init.begin(), init.end(), v0);
         (void)hipMemcpyAsync(dev, init.data(), sizeof(double) * ne, hipMemcpyHostToDevice, st(ctx));
         (void)hipStreamSynchronize(st(ctx));
@@ -697,15 +709,15 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_byte
         const int nq = out->n_cno;
         double *d_raw = nullptr, *d_cno = nullptr;
         BDS_HIP(ctx, hipMalloc((void **)&d_raw, sizeof(double) * (size_t)n_ch * nq * 3));
+        scope.add(d_raw);
         BDS_HIP(ctx, hipMalloc((void **)&d_cno, sizeof(double) * (size_t)n_ch * nq * 5));
+        scope.add(d_cno);
         BDS_HIP(ctx, hipMemcpyAsync(d_st, hs.data(), sizeof(ChanState) * n_ch, hipMemcpyHostToDevice, st(ctx)));
         hipLaunchKernelGGL(k_trk_cno, dim3(n_ch), dim3(256), 0, st(ctx), d, (const ChanState *)d_st, n_epochs, M, nq, pm,
                            s->intTime, d_raw, d_cno);
         std::vector<double> h((size_t)n_ch * nq * 5);
         BDS_HIP(ctx, hipMemcpyAsync(h.data(), d_cno, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st(ctx)));
         BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
-        (void)hipFree(d_raw);
-        (void)hipFree(d_cno);
         double *dst[5] = {out->DataCNo, out->DataPLD, out->PilotCNo, out->PilotPLD, out->SigCNo};
         const size_t plane = (size_t)n_ch * nq;
         for (int f = 0; f < 5; ++f) {
@@ -717,9 +729,6 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_byte
                 }
         }
     }
-    for (double *a : allocs) (void)hipFree(a);
-    (void)hipFree(d_st);
-    (void)hipFree(d_part);
     return BDS_OK;
 }
 
