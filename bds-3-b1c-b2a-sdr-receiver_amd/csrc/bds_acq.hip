@@ -442,10 +442,57 @@ static int set_lds_limits(bds_ctx *ctx) {
 }
 
 // forward transform of `nb` batches produced by loader `ld` into dst[b*dst_stride]
+// forward passes on the specialised stages (plans with pl.fast)
+template <int S, class Loader>
+static void launch_cols_fwd_t(hipStream_t s_, const Plan2D &pl, Loader ld, int nb, float2 *Bw) {
+#ifndef BDS_FWD_T
+#define BDS_FWD_T 4
+#endif
+    constexpr int T = BDS_FWD_T;
+    static bool attr = false;
+    const size_t lds = sizeof(float2) * (T * tspan<S>() + lds_span(twiddle_entries<S>()));
+    if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_fwd_t<S, T, Loader>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    hipLaunchKernelGGL((k_cols_fwd_t<S, T, Loader>), dim3((pl.L2 + T - 1) / T, nb), dim3(cols_threads<S, T>()), lds, s_,
+                       (const float2 *)pl.d_tw1, pl.twl, pl.L2, ld, Bw, pl.L);
+}
+template <int S, class ST>
+static void launch_rows_fwd_t(hipStream_t s_, const Plan2D &pl, int nb, const float2 *Bw, ST *dst, long dst_stride,
+                              int conj_flag, float scale) {
+    static bool attr = false;
+    const size_t lds = sizeof(float2) * (tspan<S>() + lds_span(twiddle_entries<S>()));
+    if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_fwd_t<S, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    hipLaunchKernelGGL((k_rows_fwd_t<S, ST>), dim3(pl.L1, nb), dim3(rows_threads<S>()), lds, s_, (const float2 *)pl.d_tw2, Bw,
+                       pl.L, dst, dst_stride, conj_flag, scale);
+}
+template <class ST>
+static void launch_rows_fwd_any(hipStream_t s_, const Plan2D &pl, int nb, const float2 *Bw, ST *dst, long dst_stride,
+                                int conj_flag, float scale) {
+    switch (pl.L2) {
+        case 1280: launch_rows_fwd_t<1280, ST>(s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
+        case 2048: launch_rows_fwd_t<2048, ST>(s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
+        case 3072: launch_rows_fwd_t<3072, ST>(s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
+        default: launch_rows_fwd_t<4096, ST>(s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
+    }
+}
+
 template <class Loader>
 static int forward(bds_ctx *ctx, AcqState &a, Loader ld, int nb, float2 *dst, long dst_stride, int conj_flag,
                    float scale) {
     Plan2D &pl = a.plan;
+    if (pl.fast && !std::getenv("BDS_ACQ_GENERIC_FWD")) {
+        switch (pl.L1) {
+            case 256: launch_cols_fwd_t<256>(st(ctx), pl, ld, nb, a.d_Bw); break;
+            case 512: launch_cols_fwd_t<512>(st(ctx), pl, ld, nb, a.d_Bw); break;
+            case 768: launch_cols_fwd_t<768>(st(ctx), pl, ld, nb, a.d_Bw); break;
+            default: launch_cols_fwd_t<1024>(st(ctx), pl, ld, nb, a.d_Bw); break;
+        }
+        if (a.half)
+            launch_rows_fwd_any<__half2>(st(ctx), pl, nb, (const float2 *)a.d_Bw, (__half2 *)dst, dst_stride, conj_flag, scale);
+        else
+            launch_rows_fwd_any<float2>(st(ctx), pl, nb, (const float2 *)a.d_Bw, dst, dst_stride, conj_flag, scale);
+        BDS_HIP(ctx, hipGetLastError());
+        return BDS_OK;
+    }
     dim3 g1(pl.ntiles, nb), g2(pl.L1, nb);
     hipLaunchKernelGGL(k_cols_fwd<Loader>, g1, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.twl, pl.L2,
                        pl.logT, pl.Spad, ld, a.d_Bw, pl.L);

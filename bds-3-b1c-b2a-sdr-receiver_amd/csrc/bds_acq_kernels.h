@@ -47,6 +47,26 @@ struct SignalLoader {
         const float cc = c - d * s, ss = s + d * c;
         return make_float2(x * cc - xq * ss, x * ss + xq * cc);
     }
+    // The same value from a carrier phasor the caller maintains: exact() gives exp(+j 2 pi f_b m / fs)
+    // in f64, step() the constant rotation between two samples dn apart, mix() applies a phasor to
+    // extended index n (used by the specialised column pass, whose threads walk n in equal steps).
+    static constexpr bool kHasCarrier = true;
+    __device__ __forceinline__ double freq(int batch) const { return f0 + fstep * (double)(bin0 + batch); }
+    __device__ __forceinline__ void exact(int batch, long n, double *c, double *s) const {
+        const long m = n < n_circ ? n : n - n_circ;
+        const double cyc = freq(batch) * ((double)m * inv_fs);
+        sincospi(2.0 * (cyc - floor(cyc)), s, c);
+    }
+    __device__ __forceinline__ void step(int batch, long dn, double *c, double *s) const {
+        const double cyc = freq(batch) * ((double)dn * inv_fs);
+        sincospi(2.0 * (cyc - floor(cyc)), s, c);
+    }
+    __device__ __forceinline__ float2 mix(long n, double c, double s) const {
+        if (n >= n_ext) return make_float2(0.f, 0.f);
+        const double2 xv = sig.load(n < n_circ ? n : n - n_circ);
+        const float x = (float)xv.x, xq = (float)xv.y, cc = (float)c, ss = (float)s;
+        return make_float2(x * cc - xq * ss, x * ss + xq * cc);
+    }
 };
 
 // Code table value at sample n (0-based), n < X, zero beyond
