@@ -856,21 +856,28 @@ static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vecto
                            a.d_codes + t * (size_t)stride);
         a.code_have[t] = 1;
     }
+    constexpr int kSlices = 8;  // partial sums per job (k_corr_f64 grid.y)
     if (a.jobs_cap < jobs.size()) {
         if (a.d_jobs) (void)hipFree(a.d_jobs), a.d_jobs = nullptr;
         if (a.d_jobout) (void)hipFree(a.d_jobout), a.d_jobout = nullptr;
         size_t cap = std::max<size_t>(jobs.size(), 1024), dummy = 0;
         if ((rc = ensure(ctx, &a.d_jobs, &dummy, cap))) return rc;
         dummy = 0;
-        if ((rc = ensure(ctx, &a.d_jobout, &dummy, cap))) return rc;
+        if ((rc = ensure(ctx, &a.d_jobout, &dummy, cap * kSlices))) return rc;
         a.jobs_cap = cap;
     }
     BDS_HIP(ctx, hipMemcpyAsync(a.d_jobs, jobs.data(), sizeof(CorrJob) * jobs.size(), hipMemcpyHostToDevice, st(ctx)));
-    hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size()), dim3(256), 0, st(ctx), a.sview(), a.N,
+    hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size(), kSlices), dim3(256), 0, st(ctx), a.sview(), a.N,
                        (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
     BDS_HIP(ctx, hipGetLastError());
-    BDS_HIP(ctx, hipMemcpyAsync(out.data(), a.d_jobout, sizeof(double2) * jobs.size(), hipMemcpyDeviceToHost, st(ctx)));
+    std::vector<double2> part(jobs.size() * kSlices);
+    BDS_HIP(ctx, hipMemcpyAsync(part.data(), a.d_jobout, sizeof(double2) * part.size(), hipMemcpyDeviceToHost, st(ctx)));
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int k = 0; k < kSlices; ++k) acc.x += part[j * kSlices + k].x, acc.y += part[j * kSlices + k].y;
+        out[j] = acc;
+    }
     return BDS_OK;
 }
 

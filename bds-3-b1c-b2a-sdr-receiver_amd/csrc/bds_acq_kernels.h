@@ -375,7 +375,12 @@ __global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
                                                   const int8_t *__restrict__ codes, long code_stride,
                                                   double inv_fs, const CorrJob *__restrict__ jobs,
                                                   double2 *__restrict__ out) {
+    // grid (jobs, slices): every job is cut into gridDim.y contiguous slices whose partial sums the
+    // host adds in order -- a handful of million-sample jobs would otherwise run as a handful of
+    // workgroups (a latency chain of ~4000 iterations each)
     const CorrJob jb = jobs[blockIdx.x];
+    const long slice = ((jb.len + gridDim.y - 1) / gridDim.y + 255) & ~255L;
+    const long n_lo = (long)blockIdx.y * slice, n_hi = n_lo + slice < jb.len ? n_lo + slice : jb.len;
     double sr = 0.0, si = 0.0;
     // carrier by rotation: exact sincospi every 16th sample of a thread (and at the circular
     // wrap, where the time index jumps), a constant-angle complex rotation in between
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
     double cr = 1.0, ci = 0.0;
     int it = 0;
     const long cbase = ((long)jb.slot * 2 + jb.mode) * code_stride + (jb.mode ? jb.code_k0 : 0);
-    for (long n = threadIdx.x; n < jb.len; n += blockDim.x, ++it) {
+    for (long n = n_lo + threadIdx.x; n < n_hi; n += blockDim.x, ++it) {
         long a = jb.start + n;
         long t = n;
         bool resync = (it & 15) == 0;
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = make_double2(s_r[0], s_i[0]);
+    if (threadIdx.x == 0) out[(long)blockIdx.x * gridDim.y + blockIdx.y] = make_double2(s_r[0], s_i[0]);
 }
 
 }  // namespace bds
