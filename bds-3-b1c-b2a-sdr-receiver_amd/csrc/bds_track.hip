@@ -63,27 +63,20 @@ struct TrkOut {  // device arrays [n_ch][n_epochs]
     double *dllDiscr, *dllDiscrFilt, *pllDiscr, *pllDiscrFilt, *remCodePhase, *remCarrPhase;
 };
 
-// padded-array lookup of the reference: [c(L) c(1..L) c(1)], 1-based index i in 1..L+2
-// (B2a/tracking.m:158; B1C/WB_tracking.m:181,187,192), evaluated on the primary code.
-//   units = 1  : chips           (B2a)
-//   units = 2  : BOC(1,1) half-chips  [-c, +c]         (generateDataBOC11.m:85-91)
-//   units = 12 : BOC(6,1) twelfths    (-1)^ii c, ii=1..12 (generatePilotBOC61.m:89-96)
-// (32-bit index arithmetic: |i1| <= 12 * 10230 + 2; 64-bit integer ops cost 2-4 VALU instructions each)
-template <int UNITS>
-__device__ __forceinline__ float code_at(const int8_t *__restrict__ prim, int code_len, int i1) {
-    const int n = code_len * UNITS;
-    int u = i1 - 2;  // 0-based index into the unpadded array
-    if (u < 0) u += n;
-    if (u >= n) u -= n;
-    if (UNITS == 1) return (float)prim[u];
-    if (UNITS == 2) {
-        const float c = (float)prim[u >> 1];
-        return (u & 1) ? c : -c;
-    }
-    const int chip = (int)((unsigned)u / 12u);
-    const int ii = u - chip * 12;  // ii-1
-    const float c = (float)prim[chip];
-    return (ii & 1) ? c : -c;  // ii-1 even -> ii odd -> (-1)^ii = -1
+// Padded-array look-up of the reference: [c(L) c(1..L) c(1)], 1-based index i in 1..L+2
+// (B2a/tracking.m:158; B1C/WB_tracking.m:181,187,192).  The device keeps, per PRN, the three arrays
+// the trackers index -- data code, pilot code, pilot BOC(6,1) -- expanded to their own resolution
+//   B2a: chips;  B1C: BOC(1,1) half-chips [-c, +c] (generateDataBOC11.m:85-91);
+//   BOC(6,1): twelfths (-1)^ii c, ii = 1..12 (generatePilotBOC61.m:89-96)
+// with kTabPad wrapped entries on both sides, so a look-up is one clamped index and one byte load
+// (deriving chip, sub-chip sign and wrap from the index cost ~11 instructions per look-up, nine
+// look-ups per sample in wide-band mode).
+static constexpr int kTabPad = 32;
+static constexpr long kTabStride = 122880;  // >= 12 * 10230 + 2 * kTabPad, multiple of 64
+__device__ __forceinline__ float tab_at(const int8_t *__restrict__ tab, int n_units, int i1) {
+    int j = i1 + (kTabPad - 2);  // unit index i1 - 2, shifted by the left padding
+    j = max(0, min(j, n_units + 2 * kTabPad - 1));
+    return (float)tab[j];
 }
 
 struct EpochGeom {
@@ -110,6 +103,7 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
                                                 const EpochGeom &g, long k0, long k1, bool pilot, double *sums) {
     constexpr double scale = MODE == BDS_TRACK_B2A ? 1.0 : 2.0;
     constexpr int UNITS = MODE == BDS_TRACK_B2A ? 1 : 2;
+    const int NU = UNITS * p.code_len;
     const double inc = g.step * scale;
     const double st_e = (g.rem - p.spacing) * scale;  // tracking.m:260-262 / WB_tracking.m:289-291
     const double st_l = (g.rem + p.spacing) * scale;
@@ -147,9 +141,9 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
             ib = raw * c2 + raw_q * s2;
             qb = raw_q * c2 - raw * s2;
         }
-        const float ce = code_at<UNITS>(prim_d, p.code_len, ie);
-        const float cp = code_at<UNITS>(prim_d, p.code_len, ip);
-        const float cl = code_at<UNITS>(prim_d, p.code_len, il);
+        const float ce = tab_at(prim_d, NU, ie);
+        const float cp = tab_at(prim_d, NU, ip);
+        const float cl = tab_at(prim_d, NU, il);
         acc[0] = fmaf(ce, ib, acc[0]);
         acc[1] = fmaf(ce, qb, acc[1]);
         acc[2] = fmaf(cp, ib, acc[2]);
@@ -157,9 +151,9 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
         acc[4] = fmaf(cl, ib, acc[4]);
         acc[5] = fmaf(cl, qb, acc[5]);
         if (pilot) {
-            const float pe = code_at<UNITS>(prim_p, p.code_len, ie);
-            const float pp = code_at<UNITS>(prim_p, p.code_len, ip);
-            const float pl = code_at<UNITS>(prim_p, p.code_len, il);
+            const float pe = tab_at(prim_p, NU, ie);
+            const float pp = tab_at(prim_p, NU, ip);
+            const float pl = tab_at(prim_p, NU, il);
             acc[6] = fmaf(pe, ib, acc[6]);
             acc[7] = fmaf(pe, qb, acc[7]);
             acc[8] = fmaf(pp, ib, acc[8]);
@@ -167,9 +161,10 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
             acc[10] = fmaf(pl, ib, acc[10]);
             acc[11] = fmaf(pl, qb, acc[11]);
             if (MODE == BDS_TRACK_WB) {  // pilotBOC61(ceil(tcode*6)+1)  (WB_tracking.m:298,311,324)
-                const float se = code_at<12>(prim_p, p.code_len, (int)ceil(te * 6) + 1);
-                const float sp = code_at<12>(prim_p, p.code_len, (int)ceil(tp * 6) + 1);
-                const float sl = code_at<12>(prim_p, p.code_len, (int)ceil(tl * 6) + 1);
+                const int8_t *p6 = prim_p + kTabStride;  // the PRN's third array
+                const float se = tab_at(p6, 12 * p.code_len, (int)ceil(te * 6) + 1);
+                const float sp = tab_at(p6, 12 * p.code_len, (int)ceil(tp * 6) + 1);
+                const float sl = tab_at(p6, 12 * p.code_len, (int)ceil(tl * 6) + 1);
                 acc[12] = fmaf(se, ib, acc[12]);
                 acc[13] = fmaf(se, qb, acc[13]);
                 acc[14] = fmaf(sp, ib, acc[14]);
@@ -213,8 +208,8 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__r
         return;
     }
     const long k1 = min(g.blk, k0 + p.chunk);
-    const int8_t *pd = prim + ((long)(s.prn - 1) * 2 + 0) * p.code_len;
-    const int8_t *pp = prim + ((long)(s.prn - 1) * 2 + 1) * p.code_len;
+    const int8_t *pd = prim + ((long)(s.prn - 1) * 3 + 0) * kTabStride;
+    const int8_t *pp = prim + ((long)(s.prn - 1) * 3 + 1) * kTabStride;
     correlate_slice<MODE>(data, pd, pp, p, g, k0, k1, p.pilot != 0, out);
 }
 
@@ -241,8 +236,8 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t
         return;
     }
     const long k1 = min(g.blk, k0 + p.chunk);
-    const int8_t *pd = prim + ((long)(prn[ch] - 1) * 2 + 0) * p.code_len;
-    const int8_t *pp = prim + ((long)(prn[ch] - 1) * 2 + 1) * p.code_len;
+    const int8_t *pd = prim + ((long)(prn[ch] - 1) * 3 + 0) * kTabStride;
+    const int8_t *pp = prim + ((long)(prn[ch] - 1) * 3 + 1) * kTabStride;
     correlate_slice<MODE>(data, pd, pp, p, g, k0, k1, p.pilot != 0, out);
 }
 
@@ -433,11 +428,27 @@ static int pilot_on(const bds_settings &s, int mode) {
 
 static int ensure_prim(bds_ctx *ctx, TrackState &t, int signal) {
     if (t.d_prim && t.prim_signal == signal) return BDS_OK;
-    if (!t.d_prim) BDS_HIP(ctx, hipMalloc((void **)&t.d_prim, (size_t)BDS_MAX_PRN * 2 * 10230));
-    std::vector<int8_t> prim((size_t)BDS_MAX_PRN * 2 * 10230);
+    // per PRN: data, pilot, pilot BOC(6,1) arrays at their own resolution, wrapped padding (tab_at)
+    const size_t bytes = (size_t)BDS_MAX_PRN * 3 * kTabStride;
+    if (!t.d_prim) BDS_HIP(ctx, hipMalloc((void **)&t.d_prim, bytes));
+    std::vector<int8_t> tab(bytes, 0);
+    int8_t prim[10230];
     for (int prn = 1; prn <= BDS_MAX_PRN; ++prn)
-        for (int c = 0; c < 2; ++c) gen_primary(signal, c == 1, prn, &prim[((size_t)(prn - 1) * 2 + c) * 10230]);
-    BDS_HIP(ctx, hipMemcpy(t.d_prim, prim.data(), prim.size(), hipMemcpyHostToDevice));
+        for (int c = 0; c < 3; ++c) {
+            if (c == 2 && signal != BDS_SIGNAL_B1C) continue;
+            gen_primary(signal, c >= 1, prn, prim);
+            const int units = c == 2 ? 12 : (signal == BDS_SIGNAL_B1C ? 2 : 1);
+            const long n = 10230L * units;
+            int8_t *dst = &tab[((size_t)(prn - 1) * 3 + c) * kTabStride];
+            for (long j = 0; j < n + 2 * kTabPad; ++j) {
+                long u = (j - kTabPad) % n;
+                if (u < 0) u += n;
+                const int8_t chip = prim[u / units];
+                const long sub = u % units;  // BOC(1,1): [-c, +c]; BOC(6,1): (-1)^ii c, ii = sub + 1
+                dst[j] = units == 1 ? chip : ((sub & 1) ? chip : (int8_t)-chip);
+            }
+        }
+    BDS_HIP(ctx, hipMemcpy(t.d_prim, tab.data(), bytes, hipMemcpyHostToDevice));
     t.prim_signal = signal;
     return BDS_OK;
 }
