@@ -113,6 +113,12 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
     float acc[kNSums];
 #pragma unroll
     for (int i = 0; i < kNSums; ++i) acc[i] = 0.f;
+    double wr, wi, cr = 1.0, ci = 0.0;
+    {
+        const double dcyc = g.carrFreq * ((double)blockDim.x * p.inv_fs);
+        sincospi(2.0 * (dcyc - floor(dcyc)), &wi, &wr);
+    }
+    int it = 0;
     for (int k = (int)k0 + (int)threadIdx.x; k < (int)k1; k += (int)blockDim.x) {  // blksize < 2^31
         float raw, raw_q = 0.f;
         if (p.cplx) {  // rawSignal = data(1:2:end) + 1i*data(2:2:end)  (tracking.m:242-246)
@@ -125,14 +131,19 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
         const double kd = (double)k;
         const double te = st_e + kd * inc, tl = st_l + kd * inc, tp = st_p + kd * inc;
         const int ie = (int)ceil(te) + 1, il = (int)ceil(tl) + 1, ip = (int)ceil(tp) + 1;
-        // carrier: trigarg = (carrFreq*2*pi)*(k/fs) + remCarrPhase  (tracking.m:303-304), in cycles
-        const double cyc = g.carrFreq * (kd * p.inv_fs) + cyc0;
-        const double fr = cyc - floor(cyc);
-        const float hi = (float)fr, lo = (float)(fr - (double)hi);
-        float sn, cs;
-        sincospif(2.0f * hi, &sn, &cs);
-        const float d = 6.28318530717958647692f * lo;
-        const float c2 = cs - d * sn, s2 = sn + d * cs;
+        // carrier: trigarg = (carrFreq*2*pi)*(k/fs) + remCarrPhase  (tracking.m:303-304).  A thread's
+        // samples are blockDim apart, so its carrier is an f64 phasor rotated by a constant angle; it is
+        // re-evaluated exactly (phase reduced in f64, cycles) every 8th step.
+        if ((it & 7) == 0) {
+            const double cyc = g.carrFreq * (kd * p.inv_fs) + cyc0;
+            sincospi(2.0 * (cyc - floor(cyc)), &ci, &cr);
+        } else {
+            const double nr = cr * wr - ci * wi;
+            ci = cr * wi + ci * wr;
+            cr = nr;
+        }
+        ++it;
+        const float c2 = (float)cr, s2 = (float)ci;
         float ib, qb;
         if (MODE == BDS_TRACK_B2A) {  // exp(+j th): q = real, i = imag (tracking.m:309-314)
             qb = raw * c2 - raw_q * s2;
