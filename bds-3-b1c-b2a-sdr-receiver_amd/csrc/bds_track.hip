@@ -78,6 +78,12 @@ __device__ __forceinline__ float tab_at(const int8_t *__restrict__ tab, int n_un
     j = max(0, min(j, n_units + 2 * kTabPad - 1));
     return (float)tab[j];
 }
+// data and pilot codes are read at the same index: slot 0 of a PRN holds them interleaved
+__device__ __forceinline__ char2 tab2_at(const int8_t *__restrict__ tab, int n_units, int i1) {
+    int j = i1 + (kTabPad - 2);
+    j = max(0, min(j, n_units + 2 * kTabPad - 1));
+    return reinterpret_cast<const char2 *>(tab)[j];
+}
 
 struct EpochGeom {
     long long pos;
@@ -152,9 +158,8 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
             ib = raw * c2 + raw_q * s2;
             qb = raw_q * c2 - raw * s2;
         }
-        const float ce = tab_at(prim_d, NU, ie);
-        const float cp = tab_at(prim_d, NU, ip);
-        const float cl = tab_at(prim_d, NU, il);
+        const char2 ve = tab2_at(prim_d, NU, ie), vp = tab2_at(prim_d, NU, ip), vl = tab2_at(prim_d, NU, il);
+        const float ce = (float)ve.x, cp = (float)vp.x, cl = (float)vl.x;
         acc[0] = fmaf(ce, ib, acc[0]);
         acc[1] = fmaf(ce, qb, acc[1]);
         acc[2] = fmaf(cp, ib, acc[2]);
@@ -162,9 +167,7 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
         acc[4] = fmaf(cl, ib, acc[4]);
         acc[5] = fmaf(cl, qb, acc[5]);
         if (pilot) {
-            const float pe = tab_at(prim_p, NU, ie);
-            const float pp = tab_at(prim_p, NU, ip);
-            const float pl = tab_at(prim_p, NU, il);
+            const float pe = (float)ve.y, pp = (float)vp.y, pl = (float)vl.y;
             acc[6] = fmaf(pe, ib, acc[6]);
             acc[7] = fmaf(pe, qb, acc[7]);
             acc[8] = fmaf(pp, ib, acc[8]);
@@ -172,7 +175,7 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
             acc[10] = fmaf(pl, ib, acc[10]);
             acc[11] = fmaf(pl, qb, acc[11]);
             if (MODE == BDS_TRACK_WB) {  // pilotBOC61(ceil(tcode*6)+1)  (WB_tracking.m:298,311,324)
-                const int8_t *p6 = prim_p + kTabStride;  // the PRN's third array
+                const int8_t *p6 = prim_p;  // the PRN's BOC(6,1) array
                 const float se = tab_at(p6, 12 * p.code_len, (int)ceil(te * 6) + 1);
                 const float sp = tab_at(p6, 12 * p.code_len, (int)ceil(tp * 6) + 1);
                 const float sl = tab_at(p6, 12 * p.code_len, (int)ceil(tl * 6) + 1);
@@ -219,8 +222,8 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__r
         return;
     }
     const long k1 = min(g.blk, k0 + p.chunk);
-    const int8_t *pd = prim + ((long)(s.prn - 1) * 3 + 0) * kTabStride;
-    const int8_t *pp = prim + ((long)(s.prn - 1) * 3 + 1) * kTabStride;
+    const int8_t *pd = prim + ((long)(s.prn - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
+    const int8_t *pp = prim + ((long)(s.prn - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
     correlate_slice<MODE>(data, pd, pp, p, g, k0, k1, p.pilot != 0, out);
 }
 
@@ -247,8 +250,8 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t
         return;
     }
     const long k1 = min(g.blk, k0 + p.chunk);
-    const int8_t *pd = prim + ((long)(prn[ch] - 1) * 3 + 0) * kTabStride;
-    const int8_t *pp = prim + ((long)(prn[ch] - 1) * 3 + 1) * kTabStride;
+    const int8_t *pd = prim + ((long)(prn[ch] - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
+    const int8_t *pp = prim + ((long)(prn[ch] - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
     correlate_slice<MODE>(data, pd, pp, p, g, k0, k1, p.pilot != 0, out);
 }
 
@@ -439,26 +442,34 @@ static int pilot_on(const bds_settings &s, int mode) {
 
 static int ensure_prim(bds_ctx *ctx, TrackState &t, int signal) {
     if (t.d_prim && t.prim_signal == signal) return BDS_OK;
-    // per PRN: data, pilot, pilot BOC(6,1) arrays at their own resolution, wrapped padding (tab_at)
-    const size_t bytes = (size_t)BDS_MAX_PRN * 3 * kTabStride;
+    // per PRN two slots: (data, pilot) pairs at the code's own resolution, and the pilot BOC(6,1)
+    // array; wrapped padding on both sides (tab_at / tab2_at)
+    const size_t bytes = (size_t)BDS_MAX_PRN * 2 * kTabStride;
     if (!t.d_prim) BDS_HIP(ctx, hipMalloc((void **)&t.d_prim, bytes));
     std::vector<int8_t> tab(bytes, 0);
-    int8_t prim[10230];
-    for (int prn = 1; prn <= BDS_MAX_PRN; ++prn)
-        for (int c = 0; c < 3; ++c) {
-            if (c == 2 && signal != BDS_SIGNAL_B1C) continue;
-            gen_primary(signal, c >= 1, prn, prim);
-            const int units = c == 2 ? 12 : (signal == BDS_SIGNAL_B1C ? 2 : 1);
+    int8_t prim[2][10230];
+    for (int prn = 1; prn <= BDS_MAX_PRN; ++prn) {
+        gen_primary(signal, false, prn, prim[0]);
+        gen_primary(signal, true, prn, prim[1]);
+        auto unit = [&](int comp, int units, long j) {  // value at padded position j of a `units`-per-chip array
             const long n = 10230L * units;
-            int8_t *dst = &tab[((size_t)(prn - 1) * 3 + c) * kTabStride];
-            for (long j = 0; j < n + 2 * kTabPad; ++j) {
-                long u = (j - kTabPad) % n;
-                if (u < 0) u += n;
-                const int8_t chip = prim[u / units];
-                const long sub = u % units;  // BOC(1,1): [-c, +c]; BOC(6,1): (-1)^ii c, ii = sub + 1
-                dst[j] = units == 1 ? chip : ((sub & 1) ? chip : (int8_t)-chip);
-            }
+            long u = (j - kTabPad) % n;
+            if (u < 0) u += n;
+            const int8_t chip = prim[comp][u / units];
+            const long sub = u % units;  // BOC(1,1): [-c, +c]; BOC(6,1): (-1)^ii c, ii = sub + 1
+            return units == 1 ? chip : ((sub & 1) ? chip : (int8_t)-chip);
+        };
+        const int units = signal == BDS_SIGNAL_B1C ? 2 : 1;
+        int8_t *dp = &tab[((size_t)(prn - 1) * 2 + 0) * kTabStride];
+        for (long j = 0; j < 10230L * units + 2 * kTabPad; ++j) {
+            dp[2 * j] = unit(0, units, j);
+            dp[2 * j + 1] = unit(1, units, j);
         }
+        if (signal == BDS_SIGNAL_B1C) {
+            int8_t *b6 = &tab[((size_t)(prn - 1) * 2 + 1) * kTabStride];
+            for (long j = 0; j < 10230L * 12 + 2 * kTabPad; ++j) b6[j] = unit(1, 12, j);
+        }
+    }
     BDS_HIP(ctx, hipMemcpy(t.d_prim, tab.data(), bytes, hipMemcpyHostToDevice));
     t.prim_signal = signal;
     return BDS_OK;
