@@ -30,7 +30,10 @@ else:
     spc = 993750
 rng = np.random.default_rng(1)
 n = (a.epochs + 2) * spc
-x = np.clip(np.rint(rng.normal(0, 20, n)), -127, 127).astype(np.int8)
+base = min(n, 202 * spc)  # long records repeat a 202-epoch noise block (timing does not depend on the data)
+x = np.clip(np.rint(rng.normal(0, 20, base)), -127, 127).astype(np.int8)
+if base < n:
+    x = np.tile(x, n // base + 1)[:n]
 ch = [SimpleNamespace(PRN=p, acquiredFreq=s.IF + 100.0 * i, codePhase=float(1000 * i + 1), codeFreq=s.codeFreqBasis, status="T")
       for i, p in enumerate(range(1, a.channels + 1))]
 ctx = bds_amd.get_context(0)
