@@ -295,6 +295,8 @@ struct AcqState {
     int8_t *d_codes = nullptr;       // sampled codes [slot*2 + mode][code_stride] for the f64 sums
     long code_stride = 0;
     std::vector<char> code_have;     // which (slot, mode) tables exist
+    char *d_cells = nullptr;         // cell list of the batched second-peak launch
+    size_t cells_cap = 0;
     CorrJob *d_jobs = nullptr;
     double2 *d_jobout = nullptr;
     size_t jobs_cap = 0;
@@ -322,7 +324,7 @@ void acq_state_free(AcqState *a) {
     plan_free(a->plan);
     for (void *p : {(void *)a->d_sig, (void *)a->d_prim, (void *)a->d_Cs, (void *)a->d_Xs, (void *)a->d_Bw,
                     (void *)a->d_recs, (void *)a->d_rowmax, (void *)a->d_rowarg, (void *)a->d_jobs, (void *)a->d_codes,
-                    (void *)a->d_jobout, (void *)a->d_sig64, (void *)a->d_ffa, (void *)a->d_ffb, (void *)a->d_fir})
+                    (void *)a->d_jobout, (void *)a->d_sig64, (void *)a->d_ffa, (void *)a->d_ffb, (void *)a->d_fir, (void *)a->d_cells})
         if (p) (void)hipFree(p);
     delete a;
 }
@@ -570,24 +572,31 @@ static int rows_cells_per_wg() {
     }
     return v;
 }
+// optional per-cell descriptors (device arrays) for a launch whose cells are not "one PRN, consecutive bins"
+struct CellList {
+    const int *bin = nullptr;    // Doppler bin of cell g
+    const long *cs = nullptr;    // element offset of its code spectra from the Cs base
+    const int4 *rng = nullptr;   // searched lag ranges (lo1, hi1, lo2, hi2)
+};
 template <int S, int NC>
 static void launch_rows_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
-                          float in_scale) {
+                          float in_scale, CellList cl = {}) {
     static bool attr = false;
     const size_t lds = sizeof(h2) * (((tspan<S>() + 3) & ~3) + half_table_entries<S>());
     if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_inv_h<S, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
     // balanced chunks of at most rows_cells_per_wg() cells
-    const int nch = (G + rows_cells_per_wg() - 1) / rows_cells_per_wg();
-    const int gc = (G + nch - 1) / nch;
-    const RowsHArgs A{(const h2 *)pl.d_htab2, pl.twl, (const __half2 *)Xs, pl.L, pl.L1, G, bin0, (const __half2 *)Cs, (__half2 *)Bw, in_scale, gc, nch};
+    int nch = (G + rows_cells_per_wg() - 1) / rows_cells_per_wg();
+    int gc = (G + nch - 1) / nch;
+    if (cl.bin) gc = 1, nch = G;  // listed cells differ in PRN: one cell per workgroup
+    const RowsHArgs A{(const h2 *)pl.d_htab2, pl.twl, (const __half2 *)Xs, pl.L, pl.L1, G, bin0, (const __half2 *)Cs, (__half2 *)Bw, in_scale, gc, nch, cl.bin, cl.cs};
     hipLaunchKernelGGL((k_rows_inv_h<S, NC>), dim3(pl.L1 * nch), dim3(rows_threads<S>()), lds, sr, A);
 }
 template <int S, int T, int NC>
 static void launch_cols_hh(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
-                           int lo2, int hi2, Rec *recs) {
+                           int lo2, int hi2, Rec *recs, CellList cl = {}) {
     const size_t lds = sizeof(h2) * (((T * tspan<S>() + 3) & ~3) + half_table_entries<S>());
-    const ColsHArgs A{(const h2 *)pl.d_htab1, pl.L2, (const __half2 *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles};
-    const bool masked = !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
+    const ColsHArgs A{(const h2 *)pl.d_htab1, pl.L2, (const __half2 *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles, cl.rng};
+    const bool masked = cl.rng || !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
     if (masked) {
         static bool attr = false;
         if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_h<S, T, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
@@ -600,26 +609,27 @@ static void launch_cols_hh(hipStream_t sc, const Plan2D &pl, int G, const void *
 }
 template <int S, int NC>
 static void launch_cols_h(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
-                          int lo2, int hi2, Rec *recs) {
+                          int lo2, int hi2, Rec *recs, CellList cl = {}) {
     if (pl.logT == 2)
-        launch_cols_hh<S, 4, NC>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
+        launch_cols_hh<S, 4, NC>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl);
     else
-        launch_cols_hh<S, 8, NC>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
+        launch_cols_hh<S, 8, NC>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl);
 }
 template <int NC>
 static void launch_fast_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
-                          float in_scale, float w0, float w1, int lo1, int hi1, int lo2, int hi2, Rec *recs) {
+                          float in_scale, float w0, float w1, int lo1, int hi1, int lo2, int hi2, Rec *recs,
+                          CellList cl = {}) {
     switch (pl.L2) {
-        case 1280: launch_rows_h<1280, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale); break;
-        case 2048: launch_rows_h<2048, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale); break;
-        case 3072: launch_rows_h<3072, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale); break;
-        default: launch_rows_h<4096, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale); break;
+        case 1280: launch_rows_h<1280, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
+        case 2048: launch_rows_h<2048, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
+        case 3072: launch_rows_h<3072, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
+        default: launch_rows_h<4096, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
     }
     switch (pl.L1) {
-        case 256: launch_cols_h<256, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        case 512: launch_cols_h<512, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        case 768: launch_cols_h<768, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        default: launch_cols_h<1024, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
+        case 256: launch_cols_h<256, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
+        case 512: launch_cols_h<512, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
+        case 768: launch_cols_h<768, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
+        default: launch_cols_h<1024, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
     }
 }
 
@@ -1253,6 +1263,13 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         const long s2c = (long)std::ceil(s->samplingFreq / s->codeFreqBasis) * 2;  // samples2CodeChip :137
         std::vector<std::array<long, 4>> rng(P);
         if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * D * pl.ntiles))) return rc;
+        // fp16 path: all PRNs' (PRN, winning bin) cells in one launch pair through a cell list
+        // (63 tiny launch pairs were ~1 ms of the 2.7 ms refinement at cfg2)
+        const size_t cap_cells = bw_batches(a) * 2 / (size_t)ncomp;  // 4-byte elements the work buffer holds / (ncomp L)
+        const bool batched = pl.fast && a.half && a.hmath && (size_t)P <= cap_cells;
+        std::vector<int> h_bin(P);
+        std::vector<long> h_cs(P);
+        std::vector<int4> h_rng(P);
         for (int pi = 0; pi < P; ++pi) {
             const long cp = res[pi].codePhase;
             const long e1 = cp - s2c, e2 = cp + s2c, e3 = cp - a.spc + s2c, e4 = cp + a.spc - s2c;
@@ -1262,8 +1279,27 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             rng[pi] = {lo1 - 1, hi1 - 1, lo2 - 1, hi2 - 1};  // 0-based
             if (hi1 < lo1 && hi2 < lo2)
                 return fail(ctx, BDS_ERR_ARG, "PRN %d: empty second-peak range (acquisition.m:248 would fail)", prns[pi]);
-            launch_cells(prns[pi], res[pi].fbin - 1, 1, a.d_recs + (size_t)pi * pl.ntiles, (int)rng[pi][0],
-                         (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3], -1);
+            h_bin[pi] = res[pi].fbin - 1;
+            h_cs[pi] = (long)a.cs_slot[prns[pi]] * ncomp * pl.L;
+            h_rng[pi] = make_int4((int)rng[pi][0], (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3]);
+            if (!batched)
+                launch_cells(prns[pi], res[pi].fbin - 1, 1, a.d_recs + (size_t)pi * pl.ntiles, (int)rng[pi][0],
+                             (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3], -1);
+        }
+        if (batched && P > 0) {
+            const size_t nb_ = sizeof(int) * P + sizeof(long) * P + sizeof(int4) * P + 64;
+            if ((rc = ensure(ctx, &a.d_cells, &a.cells_cap, nb_))) return rc;
+            int4 *d_rng = (int4 *)a.d_cells;                       // 16-byte aligned first
+            long *d_cs = (long *)(d_rng + P);
+            int *d_bin = (int *)(d_cs + P);
+            BDS_HIP(ctx, hipMemcpyAsync(d_rng, h_rng.data(), sizeof(int4) * P, hipMemcpyHostToDevice, st(ctx)));
+            BDS_HIP(ctx, hipMemcpyAsync(d_cs, h_cs.data(), sizeof(long) * P, hipMemcpyHostToDevice, st(ctx)));
+            BDS_HIP(ctx, hipMemcpyAsync(d_bin, h_bin.data(), sizeof(int) * P, hipMemcpyHostToDevice, st(ctx)));
+            const CellList cl{d_bin, d_cs, d_rng};
+            if (ncomp == 2)
+                launch_fast_h<2>(st(ctx), pl, a.d_Xs, P, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, -1, 0, -1, a.d_recs, cl);
+            else
+                launch_fast_h<1>(st(ctx), pl, a.d_Xs, P, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, -1, 0, -1, a.d_recs, cl);
         }
         BDS_HIP(ctx, hipGetLastError());
         std::vector<Rec> r2((size_t)P * pl.ntiles);

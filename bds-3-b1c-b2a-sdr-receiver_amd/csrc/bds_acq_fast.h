@@ -376,6 +376,10 @@ struct RowsHArgs {
     float in_scale;
     int GC;   // cells one workgroup walks through (same row k1 of GC consecutive Doppler bins)
     int NCH;  // = ceil(G / GC): workgroups per row
+    // Optional cell list (GC must be 1): cell g is Doppler bin cell_bin[g] against the code spectra at
+    // Cs + cell_cs[g] -- the B2a second-peak pass evaluates one (PRN, winning bin) cell per PRN in one launch.
+    const int *cell_bin;
+    const long *cell_cs;
 };
 
 // body of the fp16 row pass for virtual workgroup index vb (= 8*slot + xcd), thread tid < rows_threads<S>().
@@ -406,13 +410,15 @@ __device__ __forceinline__ void rows_inv_h_body(const RowsHArgs &A, int vb, int 
     const int g0 = (m % NCH) * GC, k1 = (m / NCH) * 8 + xcd;
     const int g1 = g0 + GC < G ? g0 + GC : G;
     if (k1 >= L1) return;
+    if (A.cell_cs) Cs += A.cell_cs[g0];
     if (tid < MBL) s_a[tid] = twl.get<+1>((uint32_t)((long)k1 * NT * tid));
     if (tid >= 64 && tid < 64 + RL) s_b[tid - 64] = twl.get<+1>((uint32_t)((long)k1 * NSL * (tid - 64)));
     const float2 wbase = twl.get<+1>((uint32_t)k1 * (uint32_t)tid);
     (void)in_scale;  // == 1: the unit-RMS scale is part of the stored spectrum (sX)
     h2 xn[MB1][16];  // spectrum row of the next cell (raw)
     auto fetch_x = [&](int g) {
-        const __half2 *xr = Xs + (long)(bin0 + g) * L + (long)k1 * S;
+        const int bin = A.cell_bin ? A.cell_bin[g] : bin0 + g;
+        const __half2 *xr = Xs + (long)bin * L + (long)k1 * S;
 #pragma unroll
         for (int i = 0; i < MB1; ++i) {
             const int bb = tid + i * NT;
@@ -484,6 +490,7 @@ struct ColsHArgs {
     int lo1, hi1, lo2, hi2;
     Rec *recs;
     int rec_stride;  // = tiles per cell
+    const int4 *cell_rng;  // optional per-cell (lo1, hi1, lo2, hi2), MASKED kernels only
 };
 
 // body of the fp16 column pass for tile index tb (of ntb = tiles per cell) of cell g, thread tid < cols_threads<S,T>()
@@ -495,7 +502,11 @@ __device__ __forceinline__ void cols_inv_max_h_body(const ColsHArgs &A, int tb, 
     const __half2 *__restrict__ Bw = A.Bw;
     const long L = A.L;
     const float w0 = A.w0, w1 = A.w1;
-    const int lo1 = A.lo1, hi1 = A.hi1, lo2 = A.lo2, hi2 = A.hi2;
+    int lo1 = A.lo1, hi1 = A.hi1, lo2 = A.lo2, hi2 = A.hi2;
+    if (MASKED && A.cell_rng) {
+        const int4 r = A.cell_rng[g];
+        lo1 = r.x, hi1 = r.y, lo2 = r.z, hi2 = r.w;
+    }
     Rec *__restrict__ recs = A.recs;
     const int rec_stride = A.rec_stride;
     constexpr int NT = cols_threads<S, T>();
