@@ -577,6 +577,7 @@ struct CellList {
     const int *bin = nullptr;    // Doppler bin of cell g
     const long *cs = nullptr;    // element offset of its code spectra from the Cs base
     const int4 *rng = nullptr;   // searched lag ranges (lo1, hi1, lo2, hi2)
+    int gc = 1;                  // consecutive listed cells that share their code spectra (one row workgroup walks them)
 };
 template <int S, int NC>
 static void launch_rows_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
@@ -587,7 +588,7 @@ static void launch_rows_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int 
     // balanced chunks of at most rows_cells_per_wg() cells
     int nch = (G + rows_cells_per_wg() - 1) / rows_cells_per_wg();
     int gc = (G + nch - 1) / nch;
-    if (cl.bin) gc = 1, nch = G;  // listed cells differ in PRN: one cell per workgroup
+    if (cl.bin) gc = cl.gc, nch = (G + cl.gc - 1) / cl.gc;  // a workgroup stays inside one PRN's cells
     const RowsHArgs A{(const h2 *)pl.d_htab2, pl.twl, (const __half2 *)Xs, pl.L, pl.L1, G, bin0, (const __half2 *)Cs, (__half2 *)Bw, in_scale, gc, nch, cl.bin, cl.cs};
     hipLaunchKernelGGL((k_rows_inv_h<S, NC>), dim3(pl.L1 * nch), dim3(rows_threads<S>()), lds, sr, A);
 }
@@ -1019,7 +1020,18 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         w0 *= inv;
         w1 *= inv;
     }
-    const long n_pairs_total = (long)P * ((D + G - 1) / G);
+    // Small Doppler grids (B2a: 26 bins): one launch pair carries the whole rows of several PRNs through
+    // a cell list, so that the grids fill the chip and a row workgroup still walks one PRN's bins.
+    const bool multiprn = pl.fast && a.half && a.hmath && D <= 104 && P > 1 && !std::getenv("BDS_ACQ_NOMULTI");
+    // (measured at cfg2, 63 PRNs x 26 bins: 104 cells per pair 3.9 ms, 208 -> 3.6, 416 -> 3.2, 832 -> 3.1, all 1638 -> 3.0;
+    //  the fused chain 4.0); the work buffer is capped at 8 GiB
+    static const int pb_env = std::getenv("BDS_ACQ_PBCELLS") ? std::max(1, atoi(std::getenv("BDS_ACQ_PBCELLS"))) : 0;
+    const long pb_cap = std::max<long>(1, (long)(8.0 * 1073741824.0 / ((double)ncomp * (double)pl.L * 4.0)));
+    const long pb_cells = pb_env ? pb_env : pb_cap;
+    const int PB = multiprn ? (int)std::min<long>(P, std::max<long>(2, std::min(pb_cells, pb_cap) / D)) : 1;
+    long n_pairs_total = (long)P * ((D + G - 1) / G);
+    long cells_per_pair = G;
+    if (multiprn) n_pairs_total = (P + PB - 1) / PB, cells_per_pair = (long)PB * D;
     const long sample_every = std::max<long>(1, n_pairs_total / kSamples);
     long pair_idx = 0;
     hipEvent_t ev_rows[2], ev_cols[2];
@@ -1071,8 +1083,39 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
                                pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
         }
     };
-    const bool fused = pl.fast && a.half && a.hmath && fused_available(pl) && !std::getenv("BDS_ACQ_NOFUSE");
-    if (fused) {
+    const bool fused = !multiprn && pl.fast && a.half && a.hmath && fused_available(pl) && !std::getenv("BDS_ACQ_NOFUSE");
+    if (multiprn) {
+        const size_t need = ((size_t)PB * D * ncomp + 1) / 2;  // float2-sized elements per L for PB*D fp16 cells
+        if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, std::max(need, bw_batches(a)) * (size_t)pl.L))) return rc;
+        const size_t nc_ = (size_t)P * D;
+        std::vector<int> h_bin(nc_);
+        std::vector<long> h_cs(nc_);
+        for (int pi = 0; pi < P; ++pi)
+            for (int b = 0; b < D; ++b) {
+                h_bin[(size_t)pi * D + b] = b;
+                h_cs[(size_t)pi * D + b] = (long)a.cs_slot[prns[pi]] * ncomp * pl.L;
+            }
+        if ((rc = ensure(ctx, &a.d_cells, &a.cells_cap, (sizeof(long) + sizeof(int)) * nc_ + 64))) return rc;
+        long *d_cs = (long *)a.d_cells;
+        int *d_bin = (int *)(d_cs + nc_);
+        BDS_HIP(ctx, hipMemcpyAsync(d_cs, h_cs.data(), sizeof(long) * nc_, hipMemcpyHostToDevice, st(ctx)));
+        BDS_HIP(ctx, hipMemcpyAsync(d_bin, h_bin.data(), sizeof(int) * nc_, hipMemcpyHostToDevice, st(ctx)));
+        for (int pi0 = 0; pi0 < P; pi0 += PB, ++pair_idx) {
+            const int np_ = std::min(PB, P - pi0);
+            CellList cl;
+            cl.bin = d_bin + (size_t)pi0 * D;
+            cl.cs = d_cs + (size_t)pi0 * D;
+            cl.gc = D;
+            const bool sample = np_ == PB && (pair_idx % sample_every) == 0 && nsamp < kSamples;
+            if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], st(ctx)));
+            Rec *recs = a.d_recs + (size_t)pi0 * D * pl.ntiles;
+            if (ncomp == 2)
+                launch_fast_h<2>(s_main, pl, a.d_Xs, np_ * D, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, (int)a.N - 1, 1, 0, recs, cl);
+            else
+                launch_fast_h<1>(s_main, pl, a.d_Xs, np_ * D, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, (int)a.N - 1, 1, 0, recs, cl);
+            if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], st(ctx)));
+        }
+    } else if (fused) {
         // chain of fused launches: launch k carries the row pass of group k and the column pass of
         // group k-1 (the two use different halves of the inter-pass buffer)
         struct Grp {
@@ -1462,7 +1505,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     }
     // overlapped passes: the average launch-pair duration is the search time over the pair count
     t.cell_pair_ms = nsamp ? acc / nsamp : (n_pairs_total ? t.search_ms / (double)n_pairs_total : 0);
-    t.cells_per_pair = G;
+    t.cells_per_pair = (int)cells_per_pair;
     t.n_pairs = n_pairs_total;
     t.fft_len = pl.L;
     t.n_circ = a.N;
