@@ -1022,11 +1022,12 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     }
     // Small Doppler grids (B2a: 26 bins): one launch pair carries the whole rows of several PRNs through
     // a cell list, so that the grids fill the chip and a row workgroup still walks one PRN's bins.
-    const bool multiprn = pl.fast && a.half && a.hmath && D <= 104 && P > 1 && !std::getenv("BDS_ACQ_NOMULTI");
+    const bool multiprn = pl.fast && a.half && a.hmath && (D <= 104 || std::getenv("BDS_ACQ_MULTI_ANY")) && P > 1 && !std::getenv("BDS_ACQ_NOMULTI");
     // (measured at cfg2, 63 PRNs x 26 bins: 104 cells per pair 3.9 ms, 208 -> 3.6, 416 -> 3.2, 832 -> 3.1, all 1638 -> 3.0;
     //  the fused chain 4.0); the work buffer is capped at 8 GiB
     static const int pb_env = std::getenv("BDS_ACQ_PBCELLS") ? std::max(1, atoi(std::getenv("BDS_ACQ_PBCELLS"))) : 0;
-    const long pb_cap = std::max<long>(1, (long)(8.0 * 1073741824.0 / ((double)ncomp * (double)pl.L * 4.0)));
+    const double cap_gib = std::getenv("BDS_ACQ_PBCAP_GB") ? atof(std::getenv("BDS_ACQ_PBCAP_GB")) : 8.0;
+    const long pb_cap = std::max<long>(1, (long)(cap_gib * 1073741824.0 / ((double)ncomp * (double)pl.L * 4.0)));
     const long pb_cells = pb_env ? pb_env : pb_cap;
     const int PB = multiprn ? (int)std::min<long>(P, std::max<long>(2, std::min(pb_cells, pb_cap) / D)) : 1;
     long n_pairs_total = (long)P * ((D + G - 1) / G);

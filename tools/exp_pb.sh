@@ -1,6 +1,11 @@
-# cells per multi-PRN launch pair on the B2a plan (BDS_ACQ_PBCELLS), with the row-pass chunk
-for c in 104 208 416 832 1664; do echo -n "PBCELLS=$c: "; BDS_ACQ_PBCELLS=$c timeout 300 python bench.py --workload b2a --steps 5 --warmup 2 --no-cpu-baseline --no-tracking 2>&1 | grep -E "^\{" | python -c "
+# B1C plan: several PRNs' Doppler rows per launch pair (cells = PRNs x 201)
+for c in 201 402 804; do echo -n "B1C PBCELLS=$c: "; BDS_ACQ_MULTI_ANY=1 BDS_ACQ_PBCAP_GB=64 BDS_ACQ_PBCELLS=$c timeout 300 python bench.py --workload b1c --steps 2 --warmup 1 --no-cpu-baseline --no-tracking 2>&1 | grep -E "^\{" | python -c "
 import sys,json
 for l in sys.stdin:
     d=json.loads(l); print('ms/step', round(d['ms_per_step'],2), 'search', round(d['stage_ms']['search_ms'],2), len(d['config']['satellites_detected']))
 "; done
+echo -n "B1C default: "; timeout 300 python bench.py --workload b1c --steps 2 --warmup 1 --no-cpu-baseline --no-tracking 2>&1 | grep -E "^\{" | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('ms/step', round(d['ms_per_step'],2), 'search', round(d['stage_ms']['search_ms'],2))
+"
