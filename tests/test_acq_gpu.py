@@ -151,3 +151,17 @@ def test_fp32_storage_and_generic_kernels_agree(ctx, monkeypatch):
         np.testing.assert_array_equal(carr, base.carrFreq)
         np.testing.assert_array_equal(cph, base.codePhase)
         np.testing.assert_allclose(pm, base.peakMetric, rtol=1e-9)
+
+
+def test_degenerate_grids_and_lists(ctx):
+    """One Doppler bin (acqSearchBand = 0), an unsorted satellite list with a repeated PRN, a single PRN."""
+    s, x, _ = cfg1_b2a()
+    for kw in (dict(acqSearchBand=0, acqSatelliteList=[19, 20]),
+               dict(acqSatelliteList=[20, 19, 19, 5]),
+               dict(acqSatelliteList=[63])):
+        sk = s.copy(**kw)
+        ref = oacq.acquisition_b2a(x.astype(np.float64), sk)
+        got = bds_amd.acquisition(x, sk, verbose=False)
+        np.testing.assert_array_equal(got.codePhase, ref.codePhase)
+        np.testing.assert_array_equal(got.carrFreq, ref.carrFreq)
+        np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0)

@@ -77,3 +77,19 @@ def test_short_file_returns_partial_results(ctx):
     np.testing.assert_allclose(got[0].I_P, ref[0].I_P, atol=1e-4 * np.abs(ref[0].I_P).max())
     for c in (1, 2):
         assert not np.any(got[c].I_P) and np.all(np.isinf(got[c].carrFreq))
+
+
+def test_all_channels_idle(ctx):
+    """preRun leaves PRN = 0 in channels it could not fill (preRun.m:46-56): tracking skips them
+    (tracking.m:141) and returns the untouched result template."""
+    from types import SimpleNamespace
+
+    s, x, chans = track_case("B2A", "B2A", 10)
+    idle = [SimpleNamespace(PRN=0, acquiredFreq=0.0, codePhase=0.0, codeFreq=0.0, status="-") for _ in chans]
+    ref, _ = otrk.tracking(otrk.RawFile(x), idle, s, mode="B2A")
+    got, _ = bds_amd.tracking(x, idle, s, mode="B2A")
+    for r, g in zip(ref, got):
+        assert g.status == r.status == "-" and g.PRN is None and r.PRN is None and g.completed == 0  # PRN is a lazily added field (tracking.m:144)
+        np.testing.assert_array_equal(g.I_P, r.I_P)
+        np.testing.assert_array_equal(g.carrFreq, r.carrFreq)
+        np.testing.assert_array_equal(g.absoluteSample, r.absoluteSample)
