@@ -209,9 +209,11 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
     while (logT > 0 && (1 << logT) > pl.L2) --logT;
     if (const char *e = std::getenv("BDS_ACQ_LOGT")) logT = std::max(0, std::min(logT, atoi(e)));  // tuning
     const bool want_fast = fast_cols(pl.L1) && fast_rows(pl.L2) && !std::getenv("BDS_ACQ_GENERIC");
-    if (want_fast) {  // the specialised column kernel is built for T = 8 (default) and T = 4
+    if (want_fast) {  // the specialised column kernels are built for T = 8 (default) and T = 4
+        // 8 columns per workgroup: a tile row is 32 bytes, shared by two lanes (cfg3 search 201.6 -> 196.0 ms,
+        // cfg2 3.09 -> 2.64 ms against T = 4, with 768 x 8 on 512 threads; on 384 threads it was 241 ms)
         const char *e = std::getenv("BDS_ACQ_LOGT");
-        logT = (e && atoi(e) == 3) ? 3 : 2;  // 4 columns per workgroup: four workgroups per CU (measured best)
+        logT = (e && atoi(e) == 2) ? 2 : 3;
     }
     pl.logT = logT;
     pl.Spad = lds_span(pl.L1) + 4;  // +4: successive columns start 8 dwords apart in the bank row

@@ -27,7 +27,10 @@ template <int S, int T>
 __host__ __device__ constexpr int cols_threads() {
     // 16 points per thread; 768 x 4 takes 256 so that its radix-3 stage (256 butterflies per column)
     // maps one column per unroll step with no index arithmetic (the radix-16 stages idle one wave)
-    return (S == 768 && T == 4) ? 256 : S * T / 16;
+    // (768 x 8 likewise takes 512: three items per thread, the occupancy of the 4-column kernel, and two
+    // adjacent lanes share each 32-byte piece of a tile row)
+    if (S == 768) return T == 4 ? 256 : 512;
+    return S * T / 16;
 }
 
 // ---- forward row pass with a typed store (k_rows_fwd of bds_acq_kernels.h, run-time plan) --------
