@@ -132,11 +132,14 @@ def test_prn_shards_sum_to_the_full_result(ctx):
 
 
 def test_fp32_storage_and_generic_kernels_agree(ctx, monkeypatch):
-    """The specialised fp16-storage path, the specialised fp32-storage path and the run-time generic
-    kernels must return the same acqResults (the f64 refinement decides in all of them)."""
+    """The specialised fp16-storage path, the specialised fp32-storage path, the run-time generic
+    kernels and the launch-structure variants (4-column tiles, fused chain, plain per-PRN groups) must
+    return the same acqResults (the f64 refinement decides in all of them)."""
     s, x, _ = medium_b2a()
     base = bds_amd.acquisition(x, s, verbose=False)
-    for env in ({"BDS_ACQ_HMATH": "0"}, {"BDS_ACQ_FP16": "0"}, {"BDS_ACQ_GENERIC": "1"}):
+    for env in ({"BDS_ACQ_HMATH": "0"}, {"BDS_ACQ_FP16": "0"}, {"BDS_ACQ_GENERIC": "1"}, {"BDS_ACQ_GENERIC_FWD": "1"},
+                {"BDS_ACQ_LOGT": "2"}, {"BDS_ACQ_LOGT": "2", "BDS_ACQ_HMATH": "0"}, {"BDS_ACQ_NOMULTI": "1"},
+                {"BDS_ACQ_NOMULTI": "1", "BDS_ACQ_NOFUSE": "1", "BDS_ACQ_GROUP": "5", "BDS_ACQ_GCHUNK": "2"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         c2 = bds_amd.native.Context(0)
@@ -165,3 +168,34 @@ def test_degenerate_grids_and_lists(ctx):
         np.testing.assert_array_equal(got.codePhase, ref.codePhase)
         np.testing.assert_array_equal(got.carrFreq, ref.carrFreq)
         np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("l1", [256, 512, 768, 1024])
+def test_every_specialised_plan_pair(ctx, monkeypatch, l1):
+    """Each compile-time column length with each row length (forced factorisation), both signals: the
+    search kernels of all 16 plan pairs against the oracle.  The sampling rate differs per case so that
+    the context re-plans."""
+    for k, l2 in enumerate((1280, 2048, 3072, 4096)):
+        monkeypatch.setenv("BDS_ACQ_FORCE_L1L2", f"{l1}x{l2}")
+        fs = 10.0e6 + 1000.0 * (l1 + k)
+        if k % 2 == 0:
+            s = bds_amd.init_settings_b2a(samplingFreq=fs, IF=2.5e6, acqSatelliteList=[7, 19, 33], acqSearchBand=600,
+                                          acqStep=200, fineNoncoh=4)
+            fn, n_codes = oacq.acquisition_b2a, 7
+        else:
+            s = bds_amd.init_settings_b1c(samplingFreq=fs, IF=2.5e6, acqSatelliteList=[7, 19, 33], acqSearchBand=200,
+                                          acqStep=100)
+            fn, n_codes = oacq.acquisition_b1c, 3
+        from helpers import spc_of
+        from bds_amd import synth
+        spc = spc_of(s)
+        sats = [synth.Sat(19, 130.0, 0.41 * spc, 0.7, 47.0), synth.Sat(33, -90.0, 0.83 * spc, 2.2, 45.0)]
+        x = synth.make_if(s, sats, n_codes * spc, seed=500 + l1 + k)
+        ref = fn(x.astype(np.float64), s)
+        got = bds_amd.acquisition(x, s, verbose=False)
+        tm = ctx.timing()
+        assert tm["fft_len"] == l1 * l2 and tm["half_storage"] == 2
+        np.testing.assert_array_equal(got.codePhase, ref.codePhase)
+        np.testing.assert_array_equal(got.carrFreq, ref.carrFreq)
+        np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0)
+        assert got.carrFreq[18] != 0
