@@ -29,7 +29,7 @@
 #include <set>
 #include <tuple>
 
-#include "bds_acq_fast.h"
+#include "bds_acq_f32.h"
 #include "bds_internal.h"
 
 namespace bds {
@@ -110,14 +110,13 @@ static bool fast_rows(int b) { return b == 1280 || b == 2048 || b == 3072 || b =
 // Padded length L >= need (5-smooth) and its split L1 x L2, chosen by a cost model:
 // L * (stage costs of both passes + a memory term) -- a slightly longer transform made of
 // radix-16 stages beats the tightest 5-smooth length made of 3s and 5s.
-static bool choose_lengths(long need, long &L, int &L1, int &L2) {
+static bool choose_lengths(const Tuning &tune, long need, long &L, int &L1, int &L2) {
     const double kMem = 3.0;  // HBM/L2 traffic of the two passes, in units of one LDS stage
     double best = 1e30;
     const long lo = std::max<long>(need, 64), hi = lo + lo / 2 + 64;
-    if (const char *e = std::getenv("BDS_ACQ_FORCE_L1L2")) {  // "L1xL2" (tuning / tests)
-        int a = 0, b = 0;
-        if (sscanf(e, "%dx%d", &a, &b) == 2 && (long)a * b >= need && is_5smooth(a) && is_5smooth(b) &&
-            a <= kMaxColLen && b <= kMaxRowLen) {
+    if (tune.force_l1 > 0) {  // BDS_ACQ_FORCE_L1L2 (tuning / tests)
+        const int a = tune.force_l1, b = tune.force_l2;
+        if ((long)a * b >= need && is_5smooth(a) && is_5smooth(b) && a <= kMaxColLen && b <= kMaxRowLen) {
             L = (long)a * b;
             L1 = a;
             L2 = b;
@@ -200,20 +199,20 @@ static int upload_twiddles(bds_ctx *ctx, int n, long denom, long step, float2 **
 
 static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
     plan_free(pl);
-    if (!choose_lengths(need, pl.L, pl.L1, pl.L2))
+    const Tuning &tune = ctx->tune;
+    if (!choose_lengths(tune, need, pl.L, pl.L1, pl.L2))
         return fail(ctx, BDS_ERR_UNSUPPORTED, "no two-pass transform plan for length >= %ld", need);
     factor_radices(pl.L1, pl.p1);
     factor_radices(pl.L2, pl.p2);
     int logT = 5;
     while (logT > 0 && ((long)pl.L1 << logT) > kColPoints) --logT;
     while (logT > 0 && (1 << logT) > pl.L2) --logT;
-    if (const char *e = std::getenv("BDS_ACQ_LOGT")) logT = std::max(0, std::min(logT, atoi(e)));  // tuning
-    const bool want_fast = fast_cols(pl.L1) && fast_rows(pl.L2) && !std::getenv("BDS_ACQ_GENERIC");
-    if (want_fast) {  // the specialised column kernels are built for T = 8 (default) and T = 4
+    if (tune.logt >= 0) logT = std::max(0, std::min(logT, tune.logt));  // tuning
+    const bool want_fast = fast_cols(pl.L1) && fast_rows(pl.L2) && !tune.generic;
+    if (want_fast) {  // the specialised column kernels are built for T = 8 (default; fp16-arithmetic ones also T = 4)
         // 8 columns per workgroup: a tile row is 32 bytes, shared by two lanes (cfg3 search 201.6 -> 196.0 ms,
         // cfg2 3.09 -> 2.64 ms against T = 4, with 768 x 8 on 512 threads; on 384 threads it was 241 ms)
-        const char *e = std::getenv("BDS_ACQ_LOGT");
-        logT = (e && atoi(e) == 2) ? 2 : 3;
+        logT = tune.logt == 2 ? 2 : 3;
     }
     pl.logT = logT;
     pl.Spad = lds_span(pl.L1) + 4;  // +4: successive columns start 8 dwords apart in the bank row
@@ -225,7 +224,7 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
     pl.lds_cols = sizeof(float2) * (size_t)pl.Spad * (size_t)(1 << logT);
     pl.lds_rows = sizeof(float2) * (size_t)lds_span(pl.L2);
     pl.fast = want_fast;
-    if (std::getenv("BDS_VERBOSE")) {
+    if (tune.verbose) {
         fprintf(stderr, "[bds] search kernels: %s\n", pl.fast ? "specialised" : "generic");
         fprintf(stderr, "[bds] plan: need %ld -> L %ld = %d (cols:", need, pl.L, pl.L1);
         for (int i = 0; i < pl.p1.nstage; ++i) fprintf(stderr, " %d", pl.p1.radix[i]);
@@ -299,6 +298,11 @@ struct AcqState {
     std::vector<char> code_have;     // which (slot, mode) tables exist
     char *d_cells = nullptr;         // cell list of the batched second-peak launch
     size_t cells_cap = 0;
+    Extra *d_extra = nullptr;        // overflow list of the column pass (bds_acq_f32.h)
+    size_t extra_cap = 0;
+    int *d_extra_count = nullptr;
+    int n_extra_last = 0;            // entries of the last search (diagnostics)
+    bool no_fast_search = false;     // this configuration fell back to the run-time-plan search kernels
     CorrJob *d_jobs = nullptr;
     double2 *d_jobout = nullptr;
     size_t jobs_cap = 0;
@@ -318,6 +322,7 @@ struct AcqState {
     float in_scale = 1.f;      // power of two applied to the spectrum row on load (fp16 arithmetic)
     double sum_abs_ext = 0;    // sum |x| over the periodically extended block: bound of |X[k]|
     double sum_sq_ext = 0;     // sum x^2 over it: X_rms^2 (Parseval)
+    long sums_N = 0, sums_next = 0;  // sizes the two sums above were computed for
     float sX = 1.f, sC = 1.f, sB = 1.f;  // power-of-two storage scales
 };
 
@@ -326,7 +331,8 @@ void acq_state_free(AcqState *a) {
     plan_free(a->plan);
     for (void *p : {(void *)a->d_sig, (void *)a->d_prim, (void *)a->d_Cs, (void *)a->d_Xs, (void *)a->d_Bw,
                     (void *)a->d_recs, (void *)a->d_rowmax, (void *)a->d_rowarg, (void *)a->d_jobs, (void *)a->d_codes,
-                    (void *)a->d_jobout, (void *)a->d_sig64, (void *)a->d_ffa, (void *)a->d_ffb, (void *)a->d_fir, (void *)a->d_cells})
+                    (void *)a->d_jobout, (void *)a->d_sig64, (void *)a->d_ffa, (void *)a->d_ffb, (void *)a->d_fir, (void *)a->d_cells,
+                    (void *)a->d_extra, (void *)a->d_extra_count})
         if (p) (void)hipFree(p);
     delete a;
 }
@@ -334,6 +340,8 @@ void acq_state_free(AcqState *a) {
 static int check_settings(bds_ctx *ctx, const bds_settings &s) {
     if (s.signal != BDS_SIGNAL_B1C && s.signal != BDS_SIGNAL_B2A)
         return fail(ctx, BDS_ERR_ARG, "settings.signal must be BDS_SIGNAL_B1C or BDS_SIGNAL_B2A");
+    if (s.dataType != 0)
+        return fail(ctx, BDS_ERR_UNSUPPORTED, "settings.dataType: only 'schar' (int8 samples) is supported");
     if (!(s.samplingFreq > 0) || !(s.codeFreqBasis > 0) || s.codeLength != 10230)
         return fail(ctx, BDS_ERR_ARG, "settings.samplingFreq/codeFreqBasis must be positive and codeLength 10230");
     if (!(s.acqStep > 0) || !(s.acqSearchBand >= 0))
@@ -388,6 +396,7 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
                       a.cohT == s.acqCohT && a.pilotACQ == s.pilotACQflag && a.code_len == s.codeLength &&
                       a.plan.L > 0;
     if (same) return BDS_OK;
+    a.no_fast_search = false;
     a.code_have.clear();  // sampled-code cache: same key
     a.cs_slot.clear();  // the spectra cache is keyed by everything above: drop it (slot size depends on L)
     if (a.d_Cs) (void)hipFree(a.d_Cs), a.d_Cs = nullptr;
@@ -404,11 +413,11 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
     a.n_ext = N + X - 1;
     a.ncomp = ncomp;
     if ((rc = plan_build(ctx, a.plan, a.n_ext))) return rc;
-    if (const char *g = std::getenv("BDS_ACQ_GROUP")) a.group_env = std::max(1, std::min(1024, atoi(g)));
-    a.half = a.plan.fast;
-    if (const char *h = std::getenv("BDS_ACQ_FP16")) a.half = a.plan.fast && atoi(h) != 0;
-    a.hmath = a.half;
-    if (const char *h = std::getenv("BDS_ACQ_HMATH")) a.hmath = a.half && atoi(h) != 0;
+    a.group_env = ctx->tune.group;
+    // default: fp32 search arithmetic on fp16-stored spectra (BDS_ACQ_FP16=0: fp32 storage;
+    // BDS_ACQ_HMATH=1: the packed-fp16 arithmetic kernels)
+    a.half = a.plan.fast && ctx->tune.fp16_storage != 0;
+    a.hmath = a.half && ctx->tune.hmath > 0;
     // code spectrum: |fft(code)| <= X; stored value conj(C)/L * sC, kept below 2^15
     a.sC = a.half ? (float)std::exp2(std::floor(std::log2(32768.0 * (double)a.plan.L / (double)a.X))) : 1.f;
     // primary codes of every PRN, both components
@@ -429,9 +438,16 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
 
 static hipStream_t st(bds_ctx *ctx) { return (hipStream_t)ctx->stream; }
 
+// raise a kernel's dynamic-LDS limit once per context (= per device)
+template <class K>
+static void want_lds(bds_ctx *ctx, K kern, size_t bytes) {
+    if (ctx->lds_attr_done.insert((const void *)kern).second)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+
 static int set_lds_limits(bds_ctx *ctx) {
-    static bool done = false;
-    if (done) return BDS_OK;
+    if (!ctx->lds_attr_done.insert((const void *)k_rows_fwd).second) return BDS_OK;
     const int maxlds = 160 * 1024 - 4096;  // leave room for the kernels' small static LDS
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_fwd<SignalLoader>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_fwd<CodeLoader>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
@@ -441,41 +457,38 @@ static int set_lds_limits(bds_ctx *ctx) {
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_rows_inv<2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_inv_max<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     BDS_HIP(ctx, hipFuncSetAttribute((const void *)k_cols_inv_max<2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
-    done = true;
     return BDS_OK;
 }
 
 // forward transform of `nb` batches produced by loader `ld` into dst[b*dst_stride]
 // forward passes on the specialised stages (plans with pl.fast)
 template <int S, class Loader>
-static void launch_cols_fwd_t(hipStream_t s_, const Plan2D &pl, Loader ld, int nb, float2 *Bw) {
+static void launch_cols_fwd_t(bds_ctx *ctx, hipStream_t s_, const Plan2D &pl, Loader ld, int nb, float2 *Bw) {
 #ifndef BDS_FWD_T
 #define BDS_FWD_T 4
 #endif
     constexpr int T = BDS_FWD_T;
-    static bool attr = false;
     const size_t lds = sizeof(float2) * (T * tspan<S>() + lds_span(twiddle_entries<S>()));
-    if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_fwd_t<S, T, Loader>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    want_lds(ctx, k_cols_fwd_t<S, T, Loader>, lds);
     hipLaunchKernelGGL((k_cols_fwd_t<S, T, Loader>), dim3((pl.L2 + T - 1) / T, nb), dim3(cols_threads<S, T>()), lds, s_,
                        (const float2 *)pl.d_tw1, pl.twl, pl.L2, ld, Bw, pl.L);
 }
 template <int S, class ST>
-static void launch_rows_fwd_t(hipStream_t s_, const Plan2D &pl, int nb, const float2 *Bw, ST *dst, long dst_stride,
+static void launch_rows_fwd_t(bds_ctx *ctx, hipStream_t s_, const Plan2D &pl, int nb, const float2 *Bw, ST *dst, long dst_stride,
                               int conj_flag, float scale) {
-    static bool attr = false;
     const size_t lds = sizeof(float2) * (tspan<S>() + lds_span(twiddle_entries<S>()));
-    if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_fwd_t<S, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    want_lds(ctx, k_rows_fwd_t<S, ST>, lds);
     hipLaunchKernelGGL((k_rows_fwd_t<S, ST>), dim3(pl.L1, nb), dim3(rows_threads<S>()), lds, s_, (const float2 *)pl.d_tw2, Bw,
                        pl.L, dst, dst_stride, conj_flag, scale);
 }
 template <class ST>
-static void launch_rows_fwd_any(hipStream_t s_, const Plan2D &pl, int nb, const float2 *Bw, ST *dst, long dst_stride,
+static void launch_rows_fwd_any(bds_ctx *ctx, hipStream_t s_, const Plan2D &pl, int nb, const float2 *Bw, ST *dst, long dst_stride,
                                 int conj_flag, float scale) {
     switch (pl.L2) {
-        case 1280: launch_rows_fwd_t<1280, ST>(s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
-        case 2048: launch_rows_fwd_t<2048, ST>(s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
-        case 3072: launch_rows_fwd_t<3072, ST>(s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
-        default: launch_rows_fwd_t<4096, ST>(s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
+        case 1280: launch_rows_fwd_t<1280, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
+        case 2048: launch_rows_fwd_t<2048, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
+        case 3072: launch_rows_fwd_t<3072, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
+        default: launch_rows_fwd_t<4096, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
     }
 }
 
@@ -483,17 +496,17 @@ template <class Loader>
 static int forward(bds_ctx *ctx, AcqState &a, Loader ld, int nb, float2 *dst, long dst_stride, int conj_flag,
                    float scale) {
     Plan2D &pl = a.plan;
-    if (pl.fast && !std::getenv("BDS_ACQ_GENERIC_FWD")) {
+    if (pl.fast && !ctx->tune.generic_fwd) {
         switch (pl.L1) {
-            case 256: launch_cols_fwd_t<256>(st(ctx), pl, ld, nb, a.d_Bw); break;
-            case 512: launch_cols_fwd_t<512>(st(ctx), pl, ld, nb, a.d_Bw); break;
-            case 768: launch_cols_fwd_t<768>(st(ctx), pl, ld, nb, a.d_Bw); break;
-            default: launch_cols_fwd_t<1024>(st(ctx), pl, ld, nb, a.d_Bw); break;
+            case 256: launch_cols_fwd_t<256>(ctx, st(ctx), pl, ld, nb, a.d_Bw); break;
+            case 512: launch_cols_fwd_t<512>(ctx, st(ctx), pl, ld, nb, a.d_Bw); break;
+            case 768: launch_cols_fwd_t<768>(ctx, st(ctx), pl, ld, nb, a.d_Bw); break;
+            default: launch_cols_fwd_t<1024>(ctx, st(ctx), pl, ld, nb, a.d_Bw); break;
         }
         if (a.half)
-            launch_rows_fwd_any<__half2>(st(ctx), pl, nb, (const float2 *)a.d_Bw, (__half2 *)dst, dst_stride, conj_flag, scale);
+            launch_rows_fwd_any<__half2>(ctx, st(ctx), pl, nb, (const float2 *)a.d_Bw, (__half2 *)dst, dst_stride, conj_flag, scale);
         else
-            launch_rows_fwd_any<float2>(st(ctx), pl, nb, (const float2 *)a.d_Bw, dst, dst_stride, conj_flag, scale);
+            launch_rows_fwd_any<float2>(ctx, st(ctx), pl, nb, (const float2 *)a.d_Bw, dst, dst_stride, conj_flag, scale);
         BDS_HIP(ctx, hipGetLastError());
         return BDS_OK;
     }
@@ -510,70 +523,6 @@ static int forward(bds_ctx *ctx, AcqState &a, Loader ld, int nb, float2 *dst, lo
     return BDS_OK;
 }
 
-// ---- specialised search kernels: dispatch on the compile-time lengths ------------------------
-template <int S, int NC, class ST>
-static void launch_rows_t(hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
-                          float out_scale) {
-    static bool attr = false;
-    const size_t lds = sizeof(float2) * (tspan<S>() + lds_span(twiddle_entries<S>()));
-    if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_inv_t<S, NC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
-    hipLaunchKernelGGL((k_rows_inv_t<S, NC, ST>), dim3(pl.L1 * G), dim3(rows_threads<S>()), lds, sr,
-                       (const float2 *)pl.d_tw2, pl.twl, (const ST *)Xs, pl.L, pl.L1, G, bin0, (const ST *)Cs, (ST *)Bw, out_scale);
-}
-template <int S, int T, int NC, class ST>
-static void launch_cols_tt(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
-                           int lo2, int hi2, Rec *recs) {
-    static bool attr = false;
-    const size_t lds = sizeof(float2) * (T * tspan<S>() + lds_span(twiddle_entries<S>()));
-    if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_t<S, T, NC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
-    hipLaunchKernelGGL((k_cols_inv_max_t<S, T, NC, ST>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc,
-                       (const float2 *)pl.d_tw1, pl.L2, (const ST *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
-}
-template <int S, int NC, class ST>
-static void launch_cols_t(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
-                          int lo2, int hi2, Rec *recs) {
-    if (pl.logT == 2)
-        launch_cols_tt<S, 4, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
-    else
-        launch_cols_tt<S, 8, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs);
-}
-// One group of cells: row pass on stream sr, column pass on stream sc (sr == sc: plain ordering;
-// otherwise ev_rows / ev_cols chain them so the column pass of group k overlaps the row pass of
-// group k+1, which works in the other half of the inter-pass buffer).
-template <int NC, class ST>
-static void launch_fast(hipStream_t sr, hipStream_t sc, hipEvent_t ev_rows, hipEvent_t ev_cols, const Plan2D &pl,
-                        const void *Xs, int G, int bin0, const void *Cs, void *Bw, float out_scale, float w0, float w1,
-                        int lo1, int hi1, int lo2, int hi2, Rec *recs) {
-    switch (pl.L2) {
-        case 1280: launch_rows_t<1280, NC, ST>(sr, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
-        case 2048: launch_rows_t<2048, NC, ST>(sr, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
-        case 3072: launch_rows_t<3072, NC, ST>(sr, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
-        default: launch_rows_t<4096, NC, ST>(sr, pl, Xs, G, bin0, Cs, Bw, out_scale); break;
-    }
-    if (sr != sc) {
-        (void)hipEventRecord(ev_rows, sr);
-        (void)hipStreamWaitEvent(sc, ev_rows, 0);
-    }
-    switch (pl.L1) {
-        case 256: launch_cols_t<256, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        case 512: launch_cols_t<512, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        case 768: launch_cols_t<768, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-        default: launch_cols_t<1024, NC, ST>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs); break;
-    }
-    if (sr != sc) (void)hipEventRecord(ev_cols, sc);
-}
-
-// ---- fp16-arithmetic search kernels ---------------------------------------------------------------
-// cells of a group one row-pass workgroup walks through (BDS_ACQ_GCHUNK overrides)
-static int rows_cells_per_wg() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = std::getenv("BDS_ACQ_GCHUNK");
-        v = e ? std::atoi(e) : 34;
-        if (v < 1) v = 1;
-    }
-    return v;
-}
 // optional per-cell descriptors (device arrays) for a launch whose cells are not "one PRN, consecutive bins"
 struct CellList {
     const int *bin = nullptr;    // Doppler bin of cell g
@@ -581,70 +530,134 @@ struct CellList {
     const int4 *rng = nullptr;   // searched lag ranges (lo1, hi1, lo2, hi2)
     int gc = 1;                  // consecutive listed cells that share their code spectra (one row workgroup walks them)
 };
+// where a column pass reports: per-tile records + the overflow list of the sieve
+struct SieveOut {
+    Rec *recs = nullptr;
+    Extra *extra = nullptr;
+    int *extra_count = nullptr;
+    int extra_cap = 0;
+    int cell0 = 0;     // run-wide index of cell 0 of the launch
+    float keep = 1.f;  // 1 - sieve tolerance
+    hipEvent_t mid = nullptr;  // recorded between the two passes of a sampled launch pair (timing)
+};
+
+// ---- fp32-arithmetic search kernels (bds_acq_f32.h): dispatch on the compile-time lengths --------------
+template <int S, int NC, class ST>
+static void launch_rows_f(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs,
+                          void *Bw, float out_scale, const CellList &cl) {
+    const size_t lds = sizeof(float2) * (tspan<S>() + lds_span(twiddle_entries<S>()));
+    want_lds(ctx, k_rows_inv_f<S, NC, ST>, lds);
+    // balanced chunks of at most tune.gchunk cells
+    int nch = (G + ctx->tune.gchunk - 1) / ctx->tune.gchunk;
+    int gc = (G + nch - 1) / nch;
+    if (cl.bin) gc = cl.gc, nch = (G + cl.gc - 1) / cl.gc;  // a workgroup stays inside one PRN's cells
+    const RowsFArgs A{(const float2 *)pl.d_tw2, pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs};
+    hipLaunchKernelGGL((k_rows_inv_f<S, NC, ST>), dim3(pl.L1 * nch), dim3(rows_threads<S>()), lds, sr, A);
+}
+template <int S, int T, int NC, class ST>
+static void launch_cols_ft(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1,
+                           int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl) {
+    const size_t lds = sizeof(float2) * (T * tspan<S>() + lds_span(twiddle_entries<S>()));
+    const ColsFArgs A{(const float2 *)pl.d_tw1, pl.L2, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, so.recs, pl.ntiles, cl.rng,
+                      so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep};
+    const bool masked = cl.rng || !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
+    if (masked) {
+        want_lds(ctx, k_cols_inv_max_f<S, T, NC, true, ST>, lds);
+        hipLaunchKernelGGL((k_cols_inv_max_f<S, T, NC, true, ST>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
+    } else {
+        want_lds(ctx, k_cols_inv_max_f<S, T, NC, false, ST>, lds);
+        hipLaunchKernelGGL((k_cols_inv_max_f<S, T, NC, false, ST>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
+    }
+}
+template <int S, int NC, class ST>
+static void launch_cols_f(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1,
+                          int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl) {
+    if (pl.logT == 2)
+        launch_cols_ft<S, 4, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl);
+    else
+        launch_cols_ft<S, 8, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl);
+}
+// one group of cells: row pass, then column pass, on one stream
+template <int NC, class ST>
+static void launch_fast_f(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs,
+                          void *Bw, float out_scale, float w0, float w1, int lo1, int hi1, int lo2, int hi2, const SieveOut &so,
+                          const CellList &cl = {}) {
+    switch (pl.L2) {
+        case 1280: launch_rows_f<1280, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl); break;
+        case 2048: launch_rows_f<2048, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl); break;
+        case 3072: launch_rows_f<3072, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl); break;
+        default: launch_rows_f<4096, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl); break;
+    }
+    if (so.mid) (void)hipEventRecord(so.mid, st_);
+    switch (pl.L1) {
+        case 256: launch_cols_f<256, NC, ST>(ctx, st_, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
+        case 512: launch_cols_f<512, NC, ST>(ctx, st_, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
+        case 768: launch_cols_f<768, NC, ST>(ctx, st_, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
+        default: launch_cols_f<1024, NC, ST>(ctx, st_, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
+    }
+}
+
+// ---- fp16-arithmetic search kernels ---------------------------------------------------------------
 template <int S, int NC>
-static void launch_rows_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
+static void launch_rows_h(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
                           float in_scale, CellList cl = {}) {
-    static bool attr = false;
     const size_t lds = sizeof(h2) * (((tspan<S>() + 3) & ~3) + half_table_entries<S>());
-    if (!attr) (void)hipFuncSetAttribute((const void *)k_rows_inv_h<S, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
-    // balanced chunks of at most rows_cells_per_wg() cells
-    int nch = (G + rows_cells_per_wg() - 1) / rows_cells_per_wg();
+    want_lds(ctx, k_rows_inv_h<S, NC>, lds);
+    // balanced chunks of at most tune.gchunk cells
+    int nch = (G + ctx->tune.gchunk - 1) / ctx->tune.gchunk;
     int gc = (G + nch - 1) / nch;
     if (cl.bin) gc = cl.gc, nch = (G + cl.gc - 1) / cl.gc;  // a workgroup stays inside one PRN's cells
     const RowsHArgs A{(const h2 *)pl.d_htab2, pl.twl, (const __half2 *)Xs, pl.L, pl.L1, G, bin0, (const __half2 *)Cs, (__half2 *)Bw, in_scale, gc, nch, cl.bin, cl.cs};
     hipLaunchKernelGGL((k_rows_inv_h<S, NC>), dim3(pl.L1 * nch), dim3(rows_threads<S>()), lds, sr, A);
 }
 template <int S, int T, int NC>
-static void launch_cols_hh(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
+static void launch_cols_hh(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
                            int lo2, int hi2, Rec *recs, CellList cl = {}) {
     const size_t lds = sizeof(h2) * (((T * tspan<S>() + 3) & ~3) + half_table_entries<S>());
     const ColsHArgs A{(const h2 *)pl.d_htab1, pl.L2, (const __half2 *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles, cl.rng};
     const bool masked = cl.rng || !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
     if (masked) {
-        static bool attr = false;
-        if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_h<S, T, NC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+        want_lds(ctx, k_cols_inv_max_h<S, T, NC, true>, lds);
         hipLaunchKernelGGL((k_cols_inv_max_h<S, T, NC, true>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
     } else {
-        static bool attr = false;
-        if (!attr) (void)hipFuncSetAttribute((const void *)k_cols_inv_max_h<S, T, NC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+        want_lds(ctx, k_cols_inv_max_h<S, T, NC, false>, lds);
         hipLaunchKernelGGL((k_cols_inv_max_h<S, T, NC, false>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
     }
 }
 template <int S, int NC>
-static void launch_cols_h(hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
+static void launch_cols_h(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
                           int lo2, int hi2, Rec *recs, CellList cl = {}) {
     if (pl.logT == 2)
-        launch_cols_hh<S, 4, NC>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl);
+        launch_cols_hh<S, 4, NC>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl);
     else
-        launch_cols_hh<S, 8, NC>(sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl);
+        launch_cols_hh<S, 8, NC>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl);
 }
 template <int NC>
-static void launch_fast_h(hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
+static void launch_fast_h(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
                           float in_scale, float w0, float w1, int lo1, int hi1, int lo2, int hi2, Rec *recs,
                           CellList cl = {}) {
     switch (pl.L2) {
-        case 1280: launch_rows_h<1280, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
-        case 2048: launch_rows_h<2048, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
-        case 3072: launch_rows_h<3072, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
-        default: launch_rows_h<4096, NC>(sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
+        case 1280: launch_rows_h<1280, NC>(ctx, sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
+        case 2048: launch_rows_h<2048, NC>(ctx, sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
+        case 3072: launch_rows_h<3072, NC>(ctx, sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
+        default: launch_rows_h<4096, NC>(ctx, sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
     }
     switch (pl.L1) {
-        case 256: launch_cols_h<256, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
-        case 512: launch_cols_h<512, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
-        case 768: launch_cols_h<768, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
-        default: launch_cols_h<1024, NC>(sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
+        case 256: launch_cols_h<256, NC>(ctx, sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
+        case 512: launch_cols_h<512, NC>(ctx, sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
+        case 768: launch_cols_h<768, NC>(ctx, sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
+        default: launch_cols_h<1024, NC>(ctx, sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
     }
 }
 
 // Fused row(k+1) + column(k) launch.  Instantiated for the plan pairs the cost model picks at the
 // BASELINE configs; other specialised pairs run the two kernels back to back.
 template <int S2, int S1, int T, int NC>
-static void launch_fused_tt(hipStream_t st_, const Plan2D &pl, const RowsHArgs &RA, const ColsHArgs &CA, int nr, int nc) {
-    static bool attr = false;
+static void launch_fused_tt(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const RowsHArgs &RA, const ColsHArgs &CA, int nr, int nc) {
     const size_t lr = sizeof(h2) * (((tspan<S2>() + 3) & ~3) + half_table_entries<S2>());
     const size_t lc = sizeof(h2) * (((T * tspan<S1>() + 3) & ~3) + half_table_entries<S1>());
     const size_t lds = std::max(lr, lc);
-    if (!attr) (void)hipFuncSetAttribute((const void *)k_search_fused_h<S2, S1, T, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    want_lds(ctx, k_search_fused_h<S2, S1, T, NC>, lds);
     hipLaunchKernelGGL((k_search_fused_h<S2, S1, T, NC>), dim3(8u * (unsigned)(nr + nc)), dim3(rows_threads<S2>()), lds, st_, RA, CA,
                        nr, nc, pl.ntiles);
 }
@@ -652,17 +665,17 @@ static void launch_fused_tt(hipStream_t st_, const Plan2D &pl, const RowsHArgs &
 // the launches, and its grids are short) and is neutral-to-worse on the B1C plan (287 vs 275 ms:
 // the mixed grid runs at the row pass's LDS footprint, which costs the column pass occupancy), so
 // the large plan only fuses on request (BDS_ACQ_FUSE=1).
-static bool fused_available(const Plan2D &pl) {
+static bool fused_available(const Tuning &tune, const Plan2D &pl) {
     if (pl.logT != 2) return false;
     if (pl.L2 == 1280 && pl.L1 == 256) return true;
-    return pl.L2 == 4096 && pl.L1 == 768 && std::getenv("BDS_ACQ_FUSE") != nullptr;
+    return pl.L2 == 4096 && pl.L1 == 768 && tune.fuse;
 }
 template <int NC>
-static void launch_fused(hipStream_t st_, const Plan2D &pl, const RowsHArgs &RA, const ColsHArgs &CA, int nr, int nc) {
+static void launch_fused(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const RowsHArgs &RA, const ColsHArgs &CA, int nr, int nc) {
     if (pl.L2 == 4096)
-        launch_fused_tt<4096, 768, 4, NC>(st_, pl, RA, CA, nr, nc);
+        launch_fused_tt<4096, 768, 4, NC>(ctx, st_, pl, RA, CA, nr, nc);
     else
-        launch_fused_tt<1280, 256, 4, NC>(st_, pl, RA, CA, nr, nc);
+        launch_fused_tt<1280, 256, 4, NC>(ctx, st_, pl, RA, CA, nr, nc);
 }
 
 // inter-pass work buffer: two halves of `group` cells each (float2-sized elements)
@@ -733,6 +746,20 @@ static int condition_block(bds_ctx *ctx, AcqState &a, const ResamplePlan &r, lon
     return BDS_OK;
 }
 
+// sum |x| and sum x^2 over the periodically extended block the search transforms (they set the fp16
+// storage scales); keyed by the sizes they were computed for, so a run whose settings changed N re-derives them
+static void ext_sums(AcqState &a) {
+    a.sum_abs_ext = a.sum_sq_ext = 0;
+    for (long i = 0; i < a.n_ext; ++i) {
+        const long m = i < a.N ? i : i - a.N;
+        const double v = a.cplx ? std::hypot(a.h_re[(size_t)m], a.h_im[(size_t)m]) : std::fabs(a.h_re[(size_t)m]);
+        a.sum_abs_ext += v;
+        a.sum_sq_ext += v * v;
+    }
+    a.sums_N = a.N;
+    a.sums_next = a.n_ext;
+}
+
 extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s_in, const int8_t *samples, size_t n_samples,
                             int is_complex) {
     if (!ctx || !s_in || !samples) return BDS_ERR_ARG;
@@ -778,13 +805,7 @@ extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s_in, const int8_t
         for (long i = 0; i < n_eff; ++i) a.h_prefix_q[(size_t)i + 1] = a.h_prefix_q[(size_t)i] + a.h_im[(size_t)i];
     }
     a.n_samples = n_eff;
-    a.sum_abs_ext = a.sum_sq_ext = 0;
-    for (long i = 0; i < a.n_ext; ++i) {
-        const long m = i < a.N ? i : i - a.N;
-        const double v = cplx ? std::hypot(a.h_re[(size_t)m], a.h_im[(size_t)m]) : std::fabs(a.h_re[(size_t)m]);
-        a.sum_abs_ext += v;
-        a.sum_sq_ext += v * v;
-    }
+    ext_sums(a);
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
     return BDS_OK;
 }
@@ -971,16 +992,18 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     BDS_HIP(ctx, evp.make(&ev2));
     BDS_HIP(ctx, evp.make(&ev3));
     constexpr int kSamples = 32;
-    hipEvent_t sa[kSamples], sb[kSamples];
+    hipEvent_t sa[kSamples], sb[kSamples], sm[kSamples];
     int nsamp = 0;
     for (int i = 0; i < kSamples; ++i) {
         BDS_HIP(ctx, evp.make(&sa[i]));
         BDS_HIP(ctx, evp.make(&sb[i]));
+        BDS_HIP(ctx, evp.make(&sm[i]));
     }
     BDS_HIP(ctx, hipEventRecord(ev0, st(ctx)));
 
     // ---- storage scales (fp16 mode): powers of two from exact sums of the block ----------
     a.sX = a.sB = 1.f;
+    if (a.sums_N != a.N || a.sums_next != a.n_ext) ext_sums(a);  // settings of this run changed N after bds_acq_load
     if (a.half) {
         // |X[k]| <= sum|x|  -> keep the stored spectrum below 2^15
         a.sX = (float)std::exp2(std::floor(std::log2(32768.0 / std::max(1.0, a.sum_abs_ext))));
@@ -1022,73 +1045,110 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         w0 *= inv;
         w1 *= inv;
     }
+    const Tuning &tune = ctx->tune;
+    const bool fsearch = pl.fast && !a.hmath && !a.no_fast_search;  // fp32-arithmetic specialised kernels (default)
+    const bool hsearch = pl.fast && a.hmath && !a.no_fast_search;   // packed-fp16 arithmetic kernels (opt-in)
+    // sieve tolerance: every lag within kDelta of a PRN's maximum is re-evaluated in f64.  fp32 storage errs by
+    // ~1e-7 of the output RMS, fp16 storage by ~3e-4, fp16 arithmetic by ~1.3e-3 (tools/sieve_error.py)
+    const double kDelta = a.hmath ? 1e-2 : a.half ? 2e-3 : 2e-5;
+    // overflow list of the column pass: lags within kDelta of their tile's maximum (other than the tile's record)
+    constexpr int kExtraCap = 1 << 22;
+    {
+        size_t cap = a.extra_cap;
+        if ((rc = ensure(ctx, &a.d_extra, &cap, (size_t)kExtraCap))) return rc;
+        a.extra_cap = cap;
+        if (!a.d_extra_count) BDS_HIP(ctx, hipMalloc((void **)&a.d_extra_count, sizeof(int)));
+        BDS_HIP(ctx, hipMemsetAsync(a.d_extra_count, 0, sizeof(int), st(ctx)));
+    }
+    SieveOut so{a.d_recs, a.d_extra, a.d_extra_count, kExtraCap, 0, (float)(1.0 - kDelta)};
+    const size_t elem = a.half ? 4 : 8;  // bytes of one stored complex value
     // Small Doppler grids (B2a: 26 bins): one launch pair carries the whole rows of several PRNs through
     // a cell list, so that the grids fill the chip and a row workgroup still walks one PRN's bins.
-    const bool multiprn = pl.fast && a.half && a.hmath && (D <= 104 || std::getenv("BDS_ACQ_MULTI_ANY")) && P > 1 && !std::getenv("BDS_ACQ_NOMULTI");
+    const bool multiprn = (fsearch || hsearch) && (D <= 104 || tune.multi_any) && P > 1 && !tune.nomulti;
     // (measured at cfg2, 63 PRNs x 26 bins: 104 cells per pair 3.9 ms, 208 -> 3.6, 416 -> 3.2, 832 -> 3.1, all 1638 -> 3.0;
     //  the fused chain 4.0); the work buffer is capped at 8 GiB
-    static const int pb_env = std::getenv("BDS_ACQ_PBCELLS") ? std::max(1, atoi(std::getenv("BDS_ACQ_PBCELLS"))) : 0;
-    const double cap_gib = std::getenv("BDS_ACQ_PBCAP_GB") ? atof(std::getenv("BDS_ACQ_PBCAP_GB")) : 8.0;
-    const long pb_cap = std::max<long>(1, (long)(cap_gib * 1073741824.0 / ((double)ncomp * (double)pl.L * 4.0)));
-    const long pb_cells = pb_env ? pb_env : pb_cap;
+    const long pb_cap = std::max<long>(1, (long)(tune.pbcap_gb * 1073741824.0 / ((double)ncomp * (double)pl.L * (double)elem)));
+    const long pb_cells = tune.pbcells ? tune.pbcells : pb_cap;
     const int PB = multiprn ? (int)std::min<long>(P, std::max<long>(2, std::min(pb_cells, pb_cap) / D)) : 1;
     long n_pairs_total = (long)P * ((D + G - 1) / G);
     long cells_per_pair = G;
     if (multiprn) n_pairs_total = (P + PB - 1) / PB, cells_per_pair = (long)PB * D;
     const long sample_every = std::max<long>(1, n_pairs_total / kSamples);
     long pair_idx = 0;
-    hipEvent_t ev_rows[2], ev_cols[2];
-    for (int i = 0; i < 2; ++i) {
-        BDS_HIP(ctx, evp.make(&ev_rows[i], hipEventDisableTiming));
-        BDS_HIP(ctx, evp.make(&ev_cols[i], hipEventDisableTiming));
-    }
-    const hipStream_t s_main = st(ctx), s_cols = (hipStream_t)ctx->stream2;
-    // Running the column pass of group k beside the row pass of group k+1 on a second stream was
-    // measured neutral (both kernels already fill the wave slots), so it stays opt-in.
-    const bool overlap = pl.fast && std::getenv("BDS_ACQ_OVERLAP");
-    long group_idx = 0;
-    // buf < 0: both passes on the main stream; buf = 0/1: half of the inter-pass buffer, passes overlapped
-    auto launch_cells = [&](int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2, int buf) {
-        const float2 *Cs = a.d_Cs + (size_t)a.cs_slot[prn] * ncomp * pl.L;
-        dim3 gr(pl.L1, nb), gc(pl.ntiles, nb);
-        const hipStream_t sc = buf >= 0 ? s_cols : s_main;
-        const int hb = buf >= 0 ? buf : 0;
-        const size_t half_elems = (size_t)G * ncomp * pl.L;  // elements (of the storage type) per half
-        if (pl.fast && a.half && a.hmath) {
-            const void *Ch = (const __half2 *)a.d_Cs + (size_t)a.cs_slot[prn] * ncomp * pl.L;
-            void *Bh = (__half2 *)a.d_Bw + (size_t)hb * half_elems;
+    const hipStream_t s_main = st(ctx);
+    // one group of cells of one PRN (consecutive bins b0 .. b0+nb-1, or one bin with lag ranges): both passes on the
+    // main stream; cell0 = run-wide index of the first cell (overflow-list bookkeeping)
+    bool mids = false;  // the sampled pairs carry a mid event (fp32-arithmetic kernels)
+    auto launch_cells = [&](int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2, int cell0, hipEvent_t mid) {
+        const size_t cs_off = (size_t)a.cs_slot[prn] * ncomp * pl.L;
+        SieveOut so1 = so;
+        so1.recs = recs;
+        so1.cell0 = cell0;
+        so1.mid = mid;
+        if (mid && fsearch) mids = true;
+        if (hsearch) {
+            const void *Ch = (const __half2 *)a.d_Cs + cs_off;
             if (ncomp == 2)
-                launch_fast_h<2>(s_main, pl, a.d_Xs, nb, b0, Ch, Bh, a.in_scale, w0, w1, lo1, hi1, lo2, hi2, recs);
+                launch_fast_h<2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.in_scale, w0, w1, lo1, hi1, lo2, hi2, recs);
             else
-                launch_fast_h<1>(s_main, pl, a.d_Xs, nb, b0, Ch, Bh, a.in_scale, w0, w1, lo1, hi1, lo2, hi2, recs);
-        } else if (pl.fast && a.half) {
-            const void *Ch = (const __half2 *)a.d_Cs + (size_t)a.cs_slot[prn] * ncomp * pl.L;
-            void *Bh = (__half2 *)a.d_Bw + (size_t)hb * half_elems;
+                launch_fast_h<1>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.in_scale, w0, w1, lo1, hi1, lo2, hi2, recs);
+        } else if (fsearch && a.half) {
+            const void *Ch = (const __half2 *)a.d_Cs + cs_off;
             if (ncomp == 2)
-                launch_fast<2, __half2>(s_main, sc, ev_rows[hb], ev_cols[hb], pl, a.d_Xs, nb, b0, Ch, Bh, a.sB, w0, w1, lo1, hi1, lo2, hi2, recs);
+                launch_fast_f<2, __half2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
             else
-                launch_fast<1, __half2>(s_main, sc, ev_rows[hb], ev_cols[hb], pl, a.d_Xs, nb, b0, Ch, Bh, a.sB, w0, w1, lo1, hi1, lo2, hi2, recs);
-        } else if (pl.fast) {
-            void *Bf = a.d_Bw + (size_t)hb * half_elems;
+                launch_fast_f<1, __half2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
+        } else if (fsearch) {
+            const void *Cf = a.d_Cs + cs_off;
             if (ncomp == 2)
-                launch_fast<2, float2>(s_main, sc, ev_rows[hb], ev_cols[hb], pl, a.d_Xs, nb, b0, Cs, Bf, 1.0f, w0, w1, lo1, hi1, lo2, hi2, recs);
+                launch_fast_f<2, float2>(ctx, s_main, pl, a.d_Xs, nb, b0, Cf, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
             else
-                launch_fast<1, float2>(s_main, sc, ev_rows[hb], ev_cols[hb], pl, a.d_Xs, nb, b0, Cs, Bf, 1.0f, w0, w1, lo1, hi1, lo2, hi2, recs);
-        } else if (ncomp == 2) {
-            hipLaunchKernelGGL(k_rows_inv<2>, gr, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, pl.twl,
-                               (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
-            hipLaunchKernelGGL(k_cols_inv_max<2>, gc, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.L2, pl.logT,
-                               pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
+                launch_fast_f<1, float2>(ctx, s_main, pl, a.d_Xs, nb, b0, Cf, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
         } else {
-            hipLaunchKernelGGL(k_rows_inv<1>, gr, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, pl.twl,
-                               (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
-            hipLaunchKernelGGL(k_cols_inv_max<1>, gc, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.L2, pl.logT,
-                               pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
+            const float2 *Cs = a.d_Cs + cs_off;
+            dim3 gr(pl.L1, nb), gc(pl.ntiles, nb);
+            if (ncomp == 2) {
+                hipLaunchKernelGGL(k_rows_inv<2>, gr, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, pl.twl,
+                                   (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
+                hipLaunchKernelGGL(k_cols_inv_max<2>, gc, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.L2, pl.logT,
+                                   pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
+            } else {
+                hipLaunchKernelGGL(k_rows_inv<1>, gr, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, pl.twl,
+                                   (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
+                hipLaunchKernelGGL(k_cols_inv_max<1>, gc, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.L2, pl.logT,
+                                   pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
+            }
         }
     };
-    const bool fused = !multiprn && pl.fast && a.half && a.hmath && fused_available(pl) && !std::getenv("BDS_ACQ_NOFUSE");
+    // cells described by a list (whole rows of several PRNs, or one (PRN, winning bin) cell per PRN)
+    auto launch_list = [&](int ncells, Rec *recs, const CellList &cl, int cell0, hipEvent_t mid) {
+        SieveOut so1 = so;
+        so1.recs = recs;
+        so1.cell0 = cell0;
+        so1.mid = mid;
+        if (mid && !hsearch) mids = true;
+        const int hi1 = cl.rng ? -1 : (int)a.N - 1, lo2 = cl.rng ? 0 : 1, hi2 = cl.rng ? -1 : 0;
+        if (hsearch) {
+            if (ncomp == 2)
+                launch_fast_h<2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, hi1, lo2, hi2, recs, cl);
+            else
+                launch_fast_h<1>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, hi1, lo2, hi2, recs, cl);
+        } else if (a.half) {
+            if (ncomp == 2)
+                launch_fast_f<2, __half2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
+            else
+                launch_fast_f<1, __half2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
+        } else {
+            if (ncomp == 2)
+                launch_fast_f<2, float2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
+            else
+                launch_fast_f<1, float2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
+        }
+    };
+    const bool fused = !multiprn && hsearch && a.half && fused_available(tune, pl) && !tune.nofuse;
     if (multiprn) {
-        const size_t need = ((size_t)PB * D * ncomp + 1) / 2;  // float2-sized elements per L for PB*D fp16 cells
+        // float2-sized elements the PB*D cells of one launch pair occupy
+        const size_t need = ((size_t)PB * D * ncomp * elem + 7) / 8;
         if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, std::max(need, bw_batches(a)) * (size_t)pl.L))) return rc;
         const size_t nc_ = (size_t)P * D;
         std::vector<int> h_bin(nc_);
@@ -1111,16 +1171,12 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             cl.gc = D;
             const bool sample = np_ == PB && (pair_idx % sample_every) == 0 && nsamp < kSamples;
             if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], st(ctx)));
-            Rec *recs = a.d_recs + (size_t)pi0 * D * pl.ntiles;
-            if (ncomp == 2)
-                launch_fast_h<2>(s_main, pl, a.d_Xs, np_ * D, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, (int)a.N - 1, 1, 0, recs, cl);
-            else
-                launch_fast_h<1>(s_main, pl, a.d_Xs, np_ * D, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, (int)a.N - 1, 1, 0, recs, cl);
+            launch_list(np_ * D, a.d_recs + (size_t)pi0 * D * pl.ntiles, cl, pi0 * D, sample ? sm[nsamp] : nullptr);
             if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], st(ctx)));
         }
     } else if (fused) {
-        // chain of fused launches: launch k carries the row pass of group k and the column pass of
-        // group k-1 (the two use different halves of the inter-pass buffer)
+        // chain of fused launches (fp16-arithmetic kernels): launch k carries the row pass of group k and the
+        // column pass of group k-1 (the two use different halves of the inter-pass buffer)
         struct Grp {
             int pi, b0, nb;
         };
@@ -1140,8 +1196,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
                                (__half2 *)a.d_Bw + (size_t)(k & 1) * half_elems, a.in_scale, 1, gr.nb};
                 // row workgroups walk through a few cells each (shorter chunks than the unfused
                 // launch: a long row workgroup late in the mixed grid would be its tail)
-                static const int fch = std::getenv("BDS_ACQ_FCHUNK") ? std::max(1, atoi(std::getenv("BDS_ACQ_FCHUNK"))) : 2;
-                RA.NCH = (gr.nb + fch - 1) / fch;
+                RA.NCH = (gr.nb + tune.fchunk - 1) / tune.fchunk;
                 RA.GC = (gr.nb + RA.NCH - 1) / RA.NCH;
                 nr = pl.L1 * RA.NCH / 8;
             }
@@ -1153,62 +1208,76 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
                 nc = pl.ntiles * gc.nb / 8;
             }
             if (ncomp == 2)
-                launch_fused<2>(s_main, pl, RA, CA, nr, nc);
+                launch_fused<2>(ctx, s_main, pl, RA, CA, nr, nc);
             else
-                launch_fused<1>(s_main, pl, RA, CA, nr, nc);
+                launch_fused<1>(ctx, s_main, pl, RA, CA, nr, nc);
         }
         pair_idx = ng;
-    } else
-    for (int pi = 0; pi < P; ++pi) {
-        for (int b0 = 0; b0 < D; b0 += G, ++pair_idx, ++group_idx) {
-            const int nb = std::min(G, D - b0);
-            const int buf = overlap ? (int)(group_idx & 1) : -1;
-            // the row pass of group k re-uses the buffer half the column pass of group k-2 read
-            if (overlap && group_idx >= 2) BDS_HIP(ctx, hipStreamWaitEvent(s_main, ev_cols[buf], 0));
-            const bool sample = !overlap && nb == G && (pair_idx % sample_every) == 0 && nsamp < kSamples;
-            if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], st(ctx)));
-            launch_cells(prns[pi], b0, nb, a.d_recs + ((size_t)pi * D + b0) * pl.ntiles, 0, (int)a.N - 1, 1, 0, buf);
-            if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], st(ctx)));
+    } else {
+        for (int pi = 0; pi < P; ++pi) {
+            for (int b0 = 0; b0 < D; b0 += G, ++pair_idx) {
+                const int nb = std::min(G, D - b0);
+                const bool sample = nb == G && (pair_idx % sample_every) == 0 && nsamp < kSamples;
+                if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], st(ctx)));
+                launch_cells(prns[pi], b0, nb, a.d_recs + ((size_t)pi * D + b0) * pl.ntiles, 0, (int)a.N - 1, 1, 0, pi * D + b0,
+                             sample ? sm[nsamp] : nullptr);
+                if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], st(ctx)));
+            }
         }
     }
-    if (overlap)  // join: everything after this is ordered on the main stream again
-        for (int i = 0; i < 2 && i < group_idx; ++i) BDS_HIP(ctx, hipStreamWaitEvent(s_main, ev_cols[i], 0));
     BDS_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)(P * D)), dim3(256), 0, st(ctx), (const Rec *)a.d_recs,
                        pl.ntiles, pl.ntiles, a.d_rowmax, a.d_rowarg);
     BDS_HIP(ctx, hipEventRecord(ev2, st(ctx)));
     a.h_rowmax.resize((size_t)P * D);
     a.h_rowarg.resize((size_t)P * D);
+    int n_extra = 0;
     BDS_HIP(ctx, hipMemcpyAsync(a.h_rowmax.data(), a.d_rowmax, sizeof(float) * P * D, hipMemcpyDeviceToHost, st(ctx)));
     BDS_HIP(ctx, hipMemcpyAsync(a.h_rowarg.data(), a.d_rowarg, sizeof(int) * P * D, hipMemcpyDeviceToHost, st(ctx)));
+    BDS_HIP(ctx, hipMemcpyAsync(&n_extra, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, st(ctx)));
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
     a.run_prns = prns;
     a.last.clear();
-    if (a.half) {
+    // Re-run with wider storage / plainer kernels when the sieve cannot be trusted:
+    //  * a non-finite row maximum (an fp16 value overflowed; Parseval bounds every fp16 value by sqrt(L) x its
+    //    unit RMS < 2^11, so int8 input cannot get here -- kept for non-finite f64 input, exercised by a test hook);
+    //  * the overflow list ran over (a surface with massive exact ties): the run-time-plan kernels keep one
+    //    record per tile with MATLAB's first-index tie rule.
+    auto rerun = [&](bool plain_kernels, const char *why) -> int {
+        if (tune.verbose) fprintf(stderr, "[bds] search re-run (%s): %s\n", plain_kernels ? "run-time-plan kernels" : "fp32 storage", why);
+        a.half = a.hmath = false;
+        a.no_fast_search = a.no_fast_search || plain_kernels;
+        a.sC = 1.f;
+        a.cs_slot.clear();
+        // (the flags stay until the configuration changes: acq_configure keeps them for the same key)
+        if (int rc2 = bds_acq_prepare(ctx, s_in)) return rc2;
+        return bds_acq_run(ctx, s_in, prn_list, n_prn, max_prn, carrFreq, codePhase, peakMetric, detected);
+    };
+    {
         bool bad = false;
         for (float v : a.h_rowmax) bad = bad || !std::isfinite(v);
-        // Parseval bounds every fp16 value by sqrt(L) x its unit RMS (< 2^11), so int8 input cannot get
-        // here; the path is kept for non-finite f64 input and is exercised through this test hook
-        if (std::getenv("BDS_ACQ_TEST_FORCE_FALLBACK")) bad = true;
-        if (bad) {  // an fp16 value overflowed: redo the whole search with fp32 storage
-            a.half = a.hmath = false;
-            a.sC = 1.f;
-            a.cs_slot.clear();
-            // (a.half stays off until the configuration changes: acq_configure keeps it for the same key)
-            if ((rc = bds_acq_prepare(ctx, s_in))) return rc;
-            return bds_acq_run(ctx, s_in, prn_list, n_prn, max_prn, carrFreq, codePhase, peakMetric, detected);
+        if (bad && tune.verbose) {
+            int nbad = 0;
+            for (float v : a.h_rowmax) nbad += !std::isfinite(v);
+            fprintf(stderr, "[bds] %d of %zu row maxima are not finite; first rows:", nbad, a.h_rowmax.size());
+            for (size_t i = 0; i < std::min<size_t>(8, a.h_rowmax.size()); ++i) fprintf(stderr, " %g", a.h_rowmax[i]);
+            fprintf(stderr, "  (sX %g sC %g sB %g)\n", a.sX, a.sC, a.sB);
         }
+        if (a.half && (bad || tune.test_force_fallback)) return rerun(false, bad ? "non-finite row maximum" : "test hook");
+        if (n_extra > kExtraCap && !a.no_fast_search) return rerun(true, "overflow list of the sieve ran over");
     }
+    std::vector<Extra> h_extra((size_t)std::min(n_extra, kExtraCap));
+    if (!h_extra.empty())
+        BDS_HIP(ctx, hipMemcpyAsync(h_extra.data(), a.d_extra, sizeof(Extra) * h_extra.size(), hipMemcpyDeviceToHost, st(ctx)));
+    a.n_extra_last = n_extra;
 
     // ---- f64 refinement of the sieve's candidates ---------------------------------------
-    // sieve tolerance: fp32 storage errs by ~1e-7 of the output RMS, fp16 storage by ~3e-4
-    const double kDelta = a.hmath ? 1e-2 : a.half ? 2e-3 : 2e-5;
     auto bin_freq = [&](int b) { return f0 + s->acqStep * (double)b; };
     std::vector<std::vector<Cell>> cells(P);
     std::vector<CorrJob> jobs;
     // only the per-workgroup records of rows that reach the tolerance band travel to the host
     // (the full record array is P*D*tiles*8 B: 104 MB at the B1C config)
-    std::vector<float> thr_of(P);
+    std::vector<float> thr_of(P), max_of(P);
     std::map<std::pair<int, int>, size_t> row_at;
     std::vector<Rec> h_recs;
     {
@@ -1216,6 +1285,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         for (int pi = 0; pi < P; ++pi) {
             float M = -1.f;
             for (int b = 0; b < D; ++b) M = std::max(M, a.h_rowmax[(size_t)pi * D + b]);
+            max_of[pi] = M;
             thr_of[pi] = (float)((1.0 - kDelta) * (double)M);
             for (int b = 0; b < D; ++b)
                 if (!(a.h_rowmax[(size_t)pi * D + b] < thr_of[pi])) rows.push_back({pi, b});
@@ -1236,35 +1306,45 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         }
         BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
     }
-    for (int pi = 0; pi < P; ++pi) {
-        const float thr = thr_of[pi];
-        std::set<Cell> cs;
-        for (int b = 0; b < D; ++b) {
-            if (a.h_rowmax[(size_t)pi * D + b] < thr) continue;
-            const Rec *rr = &h_recs[row_at[{pi, b}]];
-            for (int t = 0; t < pl.ntiles; ++t) {
-                if (rr[t].lag < 0 || rr[t].v < thr) continue;
-                for (int db = -1; db <= 1; ++db)
-                    for (int dl = -1; dl <= 1; ++dl) {
-                        const int bb = b + db;
-                        const long ll = rr[t].lag + dl;
-                        if (bb >= 0 && bb < D && ll >= 0 && ll < a.N) cs.insert(Cell{bb, ll});
-                    }
+    {
+        std::vector<std::set<Cell>> cs(P);
+        auto add = [&](int pi, int b, long lag) {
+            for (int db = -1; db <= 1; ++db)
+                for (int dl = -1; dl <= 1; ++dl) {
+                    const int bb = b + db;
+                    const long ll = lag + dl;
+                    if (bb >= 0 && bb < D && ll >= 0 && ll < a.N) cs[pi].insert(Cell{bb, ll});
+                }
+        };
+        for (int pi = 0; pi < P; ++pi) {
+            const float thr = thr_of[pi];
+            for (int b = 0; b < D; ++b) {
+                if (a.h_rowmax[(size_t)pi * D + b] < thr) continue;
+                const Rec *rr = &h_recs[row_at[{pi, b}]];
+                for (int t = 0; t < pl.ntiles; ++t)
+                    if (rr[t].lag >= 0 && !(rr[t].v < thr)) add(pi, b, rr[t].lag);
             }
         }
-        cells[pi].assign(cs.begin(), cs.end());
-        for (const Cell &c : cells[pi])
-            for (int comp = 0; comp < ncomp; ++comp) {
-                CorrJob j{};
-                j.start = c.lag;
-                j.len = a.X;
-                j.freq = bin_freq(c.b);
-                j.mean = 0;
-                j.slot = (prns[pi] - 1) * 2 + comp;
-                j.circ = 1;
-                j.mode = 0;
-                jobs.push_back(j);
-            }
+        // lags the column pass reported beside their tile's record (within kDelta of the tile maximum)
+        for (const Extra &e : h_extra) {
+            const int pi = e.cell / D, b = e.cell % D;
+            if (pi >= 0 && pi < P && e.lag >= 0 && !(e.v < thr_of[pi])) add(pi, b, e.lag);
+        }
+        for (int pi = 0; pi < P; ++pi) {
+            cells[pi].assign(cs[pi].begin(), cs[pi].end());
+            for (const Cell &c : cells[pi])
+                for (int comp = 0; comp < ncomp; ++comp) {
+                    CorrJob j{};
+                    j.start = c.lag;
+                    j.len = a.X;
+                    j.freq = bin_freq(c.b);
+                    j.mean = 0;
+                    j.slot = (prns[pi] - 1) * 2 + comp;
+                    j.circ = 1;
+                    j.mode = 0;
+                    jobs.push_back(j);
+                }
+        }
     }
     std::vector<double2> jout;
     if ((rc = run_jobs(ctx, a, *s, jobs, jout))) return rc;
@@ -1283,6 +1363,14 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             res[pi].peak = best;
             res[pi].fbin = bc.b + 1;
             res[pi].codePhase = bc.lag + 1;
+            // The sieve's maximum must agree with the f64 value to well inside the tolerance band it was
+            // searched with; otherwise its error model does not hold for this input: redo with fp32 storage.
+            if (a.half && !cells[pi].empty() && std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
+                char why[160];
+                snprintf(why, sizeof(why), "PRN %d: sieve maximum %.9g vs f64 %.9g (rel %.3g > %.3g)", prns[pi], (double)max_of[pi], best,
+                         std::fabs(best - (double)max_of[pi]) / best, 0.5 * kDelta);
+                return rerun(false, why);
+            }
         }
     }
 
@@ -1309,10 +1397,11 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         const long s2c = (long)std::ceil(s->samplingFreq / s->codeFreqBasis) * 2;  // samples2CodeChip :137
         std::vector<std::array<long, 4>> rng(P);
         if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * D * pl.ntiles))) return rc;
-        // fp16 path: all PRNs' (PRN, winning bin) cells in one launch pair through a cell list
+        // specialised kernels: all PRNs' (PRN, winning bin) cells in one launch pair through a cell list
         // (63 tiny launch pairs were ~1 ms of the 2.7 ms refinement at cfg2)
-        const size_t cap_cells = bw_batches(a) * 2 / (size_t)ncomp;  // 4-byte elements the work buffer holds / (ncomp L)
-        const bool batched = pl.fast && a.half && a.hmath && (size_t)P <= cap_cells;
+        const size_t cap_cells = a.bw_cap / (size_t)pl.L * 8 / elem / (size_t)ncomp;  // cells the work buffer holds
+        const bool batched = (fsearch || hsearch) && (size_t)P <= cap_cells;
+        BDS_HIP(ctx, hipMemsetAsync(a.d_extra_count, 0, sizeof(int), st(ctx)));  // overflow list of this pass: cell = PRN index
         std::vector<int> h_bin(P);
         std::vector<long> h_cs(P);
         std::vector<int4> h_rng(P);
@@ -1330,7 +1419,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             h_rng[pi] = make_int4((int)rng[pi][0], (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3]);
             if (!batched)
                 launch_cells(prns[pi], res[pi].fbin - 1, 1, a.d_recs + (size_t)pi * pl.ntiles, (int)rng[pi][0],
-                             (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3], -1);
+                             (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3], pi, nullptr);
         }
         if (batched && P > 0) {
             const size_t nb_ = sizeof(int) * P + sizeof(long) * P + sizeof(int4) * P + 64;
@@ -1342,15 +1431,21 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             BDS_HIP(ctx, hipMemcpyAsync(d_cs, h_cs.data(), sizeof(long) * P, hipMemcpyHostToDevice, st(ctx)));
             BDS_HIP(ctx, hipMemcpyAsync(d_bin, h_bin.data(), sizeof(int) * P, hipMemcpyHostToDevice, st(ctx)));
             const CellList cl{d_bin, d_cs, d_rng};
-            if (ncomp == 2)
-                launch_fast_h<2>(st(ctx), pl, a.d_Xs, P, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, -1, 0, -1, a.d_recs, cl);
-            else
-                launch_fast_h<1>(st(ctx), pl, a.d_Xs, P, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, -1, 0, -1, a.d_recs, cl);
+            launch_list(P, a.d_recs, cl, 0, nullptr);
         }
         BDS_HIP(ctx, hipGetLastError());
         std::vector<Rec> r2((size_t)P * pl.ntiles);
+        int n_extra2 = 0;
         BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, st(ctx)));
+        BDS_HIP(ctx, hipMemcpyAsync(&n_extra2, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, st(ctx)));
         BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+        if (n_extra2 > kExtraCap && !a.no_fast_search) return rerun(true, "overflow list of the second-peak pass ran over");
+        std::vector<Extra> h_extra2((size_t)std::min(n_extra2, kExtraCap));
+        if (!h_extra2.empty()) {
+            BDS_HIP(ctx, hipMemcpyAsync(h_extra2.data(), a.d_extra, sizeof(Extra) * h_extra2.size(), hipMemcpyDeviceToHost, st(ctx)));
+            BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+        }
+
         jobs.clear();
         std::vector<std::vector<long>> lags(P);
         for (int pi = 0; pi < P; ++pi) {
@@ -1367,6 +1462,10 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
                 for (long dl = -1; dl <= 1; ++dl)
                     if (inrange(r.lag + dl)) ls.insert(r.lag + dl);
             }
+            for (const Extra &e : h_extra2)
+                if (e.cell == pi && e.lag >= 0 && !(e.v < thr))
+                    for (long dl = -1; dl <= 1; ++dl)
+                        if (inrange(e.lag + dl)) ls.insert(e.lag + dl);
             lags[pi].assign(ls.begin(), ls.end());
             for (long l : lags[pi])
                 for (int comp = 0; comp < ncomp; ++comp) {
@@ -1501,11 +1600,20 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     t.search_ms = ms;
     BDS_HIP(ctx, hipEventElapsedTime(&ms, ev2, ev3));
     t.refine_ms = ms;
-    double acc = 0;
+    double acc = 0, acc_r = 0, acc_c = 0;
     for (int i = 0; i < nsamp; ++i) {
         BDS_HIP(ctx, hipEventElapsedTime(&ms, sa[i], sb[i]));
         acc += ms;
+        if (mids) {
+            BDS_HIP(ctx, hipEventElapsedTime(&ms, sa[i], sm[i]));
+            acc_r += ms;
+            BDS_HIP(ctx, hipEventElapsedTime(&ms, sm[i], sb[i]));
+            acc_c += ms;
+        }
     }
+    t.rows_ms = nsamp && mids ? acc_r / nsamp : 0;
+    t.cols_ms = nsamp && mids ? acc_c / nsamp : 0;
+    t.n_extra = a.n_extra_last;
     // overlapped passes: the average launch-pair duration is the search time over the pair count
     t.cell_pair_ms = nsamp ? acc / nsamp : (n_pairs_total ? t.search_ms / (double)n_pairs_total : 0);
     t.cells_per_pair = (int)cells_per_pair;

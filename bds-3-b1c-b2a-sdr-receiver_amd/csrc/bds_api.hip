@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <numeric>
 
 #include "bds_internal.h"
@@ -23,6 +24,38 @@ int fail(bds_ctx *ctx, int code, const char *fmt, ...) {
     else
         g_create_error = buf;
     return code;
+}
+
+Tuning tuning_from_env() {
+    Tuning t;
+    auto geti = [](const char *name, int dflt) {
+        const char *e = std::getenv(name);
+        return e ? std::atoi(e) : dflt;
+    };
+    auto has = [](const char *name) { return std::getenv(name) != nullptr; };
+    if (const char *e = std::getenv("BDS_ACQ_FORCE_L1L2")) {
+        int a = 0, b = 0;
+        if (sscanf(e, "%dx%d", &a, &b) == 2) t.force_l1 = a, t.force_l2 = b;
+    }
+    t.logt = geti("BDS_ACQ_LOGT", -1);
+    t.generic = has("BDS_ACQ_GENERIC");
+    t.generic_fwd = has("BDS_ACQ_GENERIC_FWD");
+    t.group = std::max(0, std::min(1024, geti("BDS_ACQ_GROUP", 0)));
+    t.fp16_storage = geti("BDS_ACQ_FP16", -1);
+    t.hmath = geti("BDS_ACQ_HMATH", -1);
+    t.gchunk = std::max(1, geti("BDS_ACQ_GCHUNK", 34));
+    t.multi_any = has("BDS_ACQ_MULTI_ANY");
+    t.nomulti = has("BDS_ACQ_NOMULTI");
+    t.pbcells = std::max(0, geti("BDS_ACQ_PBCELLS", 0));
+    if (const char *e = std::getenv("BDS_ACQ_PBCAP_GB")) t.pbcap_gb = std::atof(e);
+    t.fuse = has("BDS_ACQ_FUSE");
+    t.nofuse = has("BDS_ACQ_NOFUSE");
+    t.fchunk = std::max(1, geti("BDS_ACQ_FCHUNK", 2));
+    t.rows_occ2 = geti("BDS_ACQ_ROWS_OCC2", 0);
+    t.test_force_fallback = has("BDS_ACQ_TEST_FORCE_FALLBACK");
+    t.verbose = has("BDS_VERBOSE");
+    t.trk_chunk = std::max(0, geti("BDS_TRK_CHUNK", 0));
+    return t;
 }
 
 }  // namespace bds
@@ -45,6 +78,7 @@ extern "C" bds_ctx *bds_create(int device_id) {
     }
     bds_ctx *ctx = new bds_ctx();
     ctx->device = device_id;
+    ctx->tune = bds::tuning_from_env();
     hipStream_t s;
     if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) {
         bds::fail(nullptr, BDS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -67,6 +101,12 @@ extern "C" bds_ctx *bds_create(int device_id) {
         ctx->devname += prop.gcnArchName;
     }
     return ctx;
+}
+
+extern "C" int bds_reload_tuning(bds_ctx *ctx) {
+    if (!ctx) return BDS_ERR_ARG;
+    ctx->tune = bds::tuning_from_env();
+    return BDS_OK;
 }
 
 extern "C" void bds_destroy(bds_ctx *ctx) {

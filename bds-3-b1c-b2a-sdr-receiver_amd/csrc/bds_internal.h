@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,29 @@ inline long samples_per_code(const bds_settings &s) {
     return (long)m_round(s.samplingFreq / (s.codeFreqBasis / s.codeLength));
 }
 
+// Tuning / test knobs, read from the environment ONCE at bds_create and kept per context (nothing on the
+// product path calls getenv afterwards).  Defaults are the measured best; tools/README.md lists them.
+struct Tuning {
+    int force_l1 = 0, force_l2 = 0;  // BDS_ACQ_FORCE_L1L2=AxB: two-pass factorisation
+    int logt = -1;                   // BDS_ACQ_LOGT: log2 of the column tile width
+    bool generic = false;            // BDS_ACQ_GENERIC: run-time-radix search kernels
+    bool generic_fwd = false;        // BDS_ACQ_GENERIC_FWD: run-time-radix forward transforms
+    int group = 0;                   // BDS_ACQ_GROUP: (PRN, bin) cells per launch pair (0 = whole Doppler row)
+    int fp16_storage = -1;           // BDS_ACQ_FP16: spectra / inter-pass buffer as fp16 complex (-1 = default on)
+    int hmath = -1;                  // BDS_ACQ_HMATH: packed-fp16 search arithmetic (-1 = default off)
+    int gchunk = 34;                 // BDS_ACQ_GCHUNK: cells one row-pass workgroup walks through
+    bool multi_any = false, nomulti = false;  // BDS_ACQ_MULTI_ANY / BDS_ACQ_NOMULTI: multi-PRN launch pairs
+    int pbcells = 0;                 // BDS_ACQ_PBCELLS
+    double pbcap_gb = 8.0;           // BDS_ACQ_PBCAP_GB
+    bool fuse = false, nofuse = false;  // BDS_ACQ_FUSE / BDS_ACQ_NOFUSE (fp16-arithmetic kernels only)
+    int fchunk = 2;                  // BDS_ACQ_FCHUNK
+    int rows_occ2 = 0;               // BDS_ACQ_ROWS_OCC2: row pass built for 2 waves per SIMD (256 VGPRs)
+    bool test_force_fallback = false;   // BDS_ACQ_TEST_FORCE_FALLBACK: test hook, take the fp16 -> fp32 storage re-run
+    bool verbose = false;            // BDS_VERBOSE
+    int trk_chunk = 0;               // BDS_TRK_CHUNK: samples per correlate workgroup (0 = per-mode default)
+};
+Tuning tuning_from_env();
+
 struct AcqState;    // bds_acq.hip
 struct TrackState;  // bds_track.hip
 void acq_state_free(AcqState *);
@@ -39,6 +63,8 @@ struct bds_ctx {
     bds::AcqState *acq = nullptr;
     bds::TrackState *trk = nullptr;
     bds_timing timing{};
+    bds::Tuning tune;
+    std::set<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit has been raised on this device
 };
 
 namespace bds {

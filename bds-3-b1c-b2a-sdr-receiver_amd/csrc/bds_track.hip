@@ -478,6 +478,8 @@ static int ensure_prim(bds_ctx *ctx, TrackState &t, int signal) {
 static int fill_params(bds_ctx *ctx, const bds_settings &s, TrkParams &p, int n_epochs, size_t n_bytes) {
     if (s.signal != BDS_SIGNAL_B1C && s.signal != BDS_SIGNAL_B2A) return fail(ctx, BDS_ERR_ARG, "settings.signal invalid");
     if (s.fileType != 1 && s.fileType != 2) return fail(ctx, BDS_ERR_ARG, "settings.fileType must be 1 (real) or 2 (I/Q)");
+    if (s.dataType != 0)  // fread(fid, ..., settings.dataType), tracking.m:237-238
+        return fail(ctx, BDS_ERR_UNSUPPORTED, "settings.dataType: only 'schar' (int8 samples) is supported");
     if (s.codeLength != 10230 || !(s.samplingFreq > 0) || !(s.intTime > 0))
         return fail(ctx, BDS_ERR_ARG, "settings.codeLength/samplingFreq/intTime invalid");
     p.mode = track_mode(s);
@@ -493,7 +495,7 @@ static int fill_params(bds_ctx *ctx, const bds_settings &s, TrkParams &p, int n_
     p.factor = p.mode == BDS_TRACK_WB ? bds_calc_weighing_factor(&s) : 0.0;              // WB_tracking.m:138
     p.cplx = s.fileType == 2;
     p.chunk = s.signal == BDS_SIGNAL_B2A ? 2048 : 8192;
-    if (const char *e = std::getenv("BDS_TRK_CHUNK")) p.chunk = std::max(256, atoi(e));
+    if (ctx->tune.trk_chunk > 0) p.chunk = std::max(256, ctx->tune.trk_chunk);
     p.n_bytes = (long long)(n_bytes / (p.cplx ? 2 : 1));  // whole samples an fread can deliver
     return BDS_OK;
 }

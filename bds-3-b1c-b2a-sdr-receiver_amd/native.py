@@ -40,7 +40,7 @@ class Settings(C.Structure):
         ("pilotTRKflag", C.c_int32), ("intTime", C.c_double),
         ("dllCorrelatorSpacing", C.c_double), ("dllDampingRatio", C.c_double),
         ("dllNoiseBandwidth", C.c_double), ("pllNoiseBandwidth", C.c_double),
-        ("CNoInterval", C.c_int32), ("reserved0", C.c_int32), ("FEBW", C.c_double),
+        ("CNoInterval", C.c_int32), ("dataType", C.c_int32), ("FEBW", C.c_double),
     ]
 
 
@@ -67,11 +67,12 @@ class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("forward_ms", C.c_double), ("search_ms", C.c_double),
                 ("refine_ms", C.c_double), ("cell_pair_ms", C.c_double), ("cells_per_pair", C.c_double),
                 ("n_pairs", C.c_int64), ("fft_len", C.c_int64), ("n_circ", C.c_int64),
-                ("n_bins", C.c_int32), ("n_prn", C.c_int32), ("n_comp", C.c_int32), ("half_storage", C.c_int32)]
+                ("n_bins", C.c_int32), ("n_prn", C.c_int32), ("n_comp", C.c_int32), ("half_storage", C.c_int32),
+                ("rows_ms", C.c_double), ("cols_ms", C.c_double), ("n_extra", C.c_int64)]
 
 
 EXPORTS = [
-    "bds_create", "bds_destroy", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_gen_code", "bds_acquire",
+    "bds_create", "bds_destroy", "bds_reload_tuning", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_gen_code", "bds_acquire",
     "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_get_timing",
     "bds_track", "bds_track_mem", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
     "bds_calc_weighing_factor", "bds_pre_run",
@@ -100,6 +101,7 @@ def lib():
     SP = C.POINTER(Settings)
     L.bds_create.restype, L.bds_create.argtypes = vp, [i32]
     L.bds_destroy.restype, L.bds_destroy.argtypes = None, [vp]
+    L.bds_reload_tuning.restype, L.bds_reload_tuning.argtypes = i32, [vp]
     L.bds_last_error.restype, L.bds_last_error.argtypes = C.c_char_p, [vp]
     L.bds_device_name.restype, L.bds_device_name.argtypes = i32, [vp, C.c_char_p, i32]
     L.bds_gen_code.restype, L.bds_gen_code.argtypes = i32, [i32, i32, i32, i8p, i32]
@@ -154,8 +156,9 @@ def pack_settings(s) -> Settings:
     def opt(name, default):
         return getattr(s, name, default)
 
-    if str(opt("dataType", "schar")) not in ("schar", "int8"):
-        raise ValueError("settings.dataType must be 'schar' (int8 samples)")
+    dt = str(opt("dataType", "schar"))
+    # the library rejects anything but int8 samples (BDS_ERR_UNSUPPORTED names the field)
+    cs.dataType = 0 if dt in ("schar", "int8") else 1
     cs.fileType = int(opt("fileType", 1))
     cs.samplingFreq = float(need("samplingFreq"))
     cs.IF = float(need("IF"))
@@ -248,6 +251,10 @@ class Context:
         if rc < 0:
             raise BdsError(rc, self._lib.bds_last_error(self._h).decode())
         return rc
+
+    def reload_tuning(self):
+        """Re-read the BDS_* environment knobs into this context (they are read once at creation)."""
+        self._check(self._lib.bds_reload_tuning(self._h))
 
     def device_name(self) -> str:
         buf = C.create_string_buffer(256)

@@ -236,7 +236,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "GB per launch pair (PMC)", "algorithmic_GB_per_pair": bytes_per_pair / 1e9,
                      "kernel": "row-pass + column-pass launch pair (k_rows_inv_* + k_cols_inv_max_*; one pair = %d (PRN, bin) cells)" % int(cells_per_pair),
-                     "pair_ms": pair_ms, "storage": "fp16 complex" if tm.get("half_storage") else "fp32 complex"},
+                     "pair_ms": pair_ms, "rows_ms": tm.get("rows_ms"), "cols_ms": tm.get("cols_ms"), "n_extra": tm.get("n_extra"),
+                     "storage": "fp16 complex" if tm.get("half_storage") else "fp32 complex"},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -85,7 +85,9 @@ typedef struct bds_settings {
     double dllNoiseBandwidth;      /* [Hz] */
     double pllNoiseBandwidth;      /* [Hz] */
     int32_t CNoInterval;
-    int32_t reserved0;
+    int32_t dataType;              /* settings.dataType: 0 = 'schar' (int8 samples, the only format the tracking
+                                      scripts' fread(..., dataType) is ever called with here); anything else is
+                                      rejected with BDS_ERR_UNSUPPORTED (B2a/tracking.m:237-238)            */
     double FEBW;                   /* [Hz] B1C WB only (CalcWeighingFactor.m:46)     */
 } bds_settings;
 
@@ -131,7 +133,11 @@ typedef struct bds_timing {
     int64_t fft_len;        /* padded transform length L                            */
     int64_t n_circ;         /* N: the reference's circular correlation length       */
     int32_t n_bins, n_prn, n_comp;
-    int32_t half_storage;   /* 1: spectra + inter-pass buffer held as fp16 complex (fp32 arithmetic) */
+    int32_t half_storage;   /* 0: fp32 search on fp32 storage; 1: fp32 arithmetic, spectra + inter-pass buffer
+                               held as fp16 complex (default); 2: packed-fp16 arithmetic (opt-in)       */
+    double rows_ms;         /* average duration of the row-pass kernel of a sampled launch pair        */
+    double cols_ms;         /* ... and of its column-pass kernel                                       */
+    int64_t n_extra;        /* entries of the sieve's overflow list in the last search                 */
 } bds_timing;
 
 typedef struct bds_ctx bds_ctx;
@@ -140,6 +146,9 @@ typedef struct bds_ctx bds_ctx;
 /* One context per GPU (one process per GPU under torch.distributed / RCCL). */
 BDS_API bds_ctx *bds_create(int device_id);
 BDS_API void bds_destroy(bds_ctx *ctx);
+/* Tuning / test hook: the BDS_* environment knobs (tools/README.md) are read once, at bds_create, into the
+ * context; this re-reads them into an existing context.  Never needed by a host application. */
+BDS_API int bds_reload_tuning(bds_ctx *ctx);
 BDS_API const char *bds_last_error(const bds_ctx *ctx); /* ctx may be NULL: creation errors */
 BDS_API int bds_device_name(const bds_ctx *ctx, char *buf, int buflen);
 /* Binding self-check: returns 0 when the caller's struct sizes equal the library's. */

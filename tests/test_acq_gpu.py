@@ -1,7 +1,9 @@
 """GPU parity: HIP acquisition (through the C ABI) vs the float64 oracle on the same int8 block.
 
 Tolerances: codePhase exact, carrFreq exact (a grid value),
-peakMetric <= 1e-6 relative; the fp32 search grid (diagnostic) <= 2e-5 relative.
+peakMetric <= 1e-6 relative.  The search grid is a sieve: every lag within kDelta of a PRN's maximum is
+re-evaluated in f64 (bds_acq.hip), which is complete when the sieve errs by less than kDelta / 2 -- so the
+grid is held to HALF the tolerance of its mode (GRID_TOL), not to the tolerance itself.
 """
 import numpy as np
 import pytest
@@ -13,6 +15,10 @@ from helpers import (as_complex, cfg1_b2a, cfg1_b2a_iq, medium_b2a, resample_b1c
                      small_b1c_iq)
 
 pytestmark = pytest.mark.gpu
+
+# kDelta / 2 per timing()["half_storage"]: 0 fp32 storage (kDelta 2e-5), 1 fp16 storage + fp32 arithmetic
+# (2e-3, the default), 2 packed-fp16 arithmetic (1e-2)
+GRID_TOL = {0: 1e-5, 1: 1e-3, 2: 5e-3}
 
 
 def _compare(s, x, ctx, oracle_fn):
@@ -28,7 +34,7 @@ def _compare(s, x, ctx, oracle_fn):
     pk, dn, fb = ctx.acq_peaks(max(sats))
     for i, p in enumerate(sats):
         # the search grid is a sieve: fp32 storage ~1e-7, fp16 storage ~3e-4 of the output RMS
-        np.testing.assert_allclose(rm[i], diag[p]["row_max"], rtol={0: 2e-5, 1: 2e-3, 2: 3e-2}[ctx.timing()["half_storage"]])
+        np.testing.assert_allclose(rm[i], diag[p]["row_max"], rtol=GRID_TOL[ctx.timing()["half_storage"]])
         assert np.mean(ra[i] == diag[p]["row_arg"]) > (0.3 if ctx.timing()["half_storage"] else 0.9)
         assert fb[p - 1] == diag[p]["fbin"]
         np.testing.assert_allclose(pk[p - 1], diag[p]["peak"], rtol=1e-9)
@@ -111,15 +117,19 @@ def test_fp16_overflow_fallback_reruns_in_fp32(ctx, monkeypatch):
                      (resample_b1c()[0], resample_b1c()[1], oacq.acquisition_b1c)):
         ref = fn(x.astype(np.float64), s)
         monkeypatch.setenv("BDS_ACQ_TEST_FORCE_FALLBACK", "1")
-        got = bds_amd.acquisition(x, s, verbose=False)
-        assert ctx.timing()["half_storage"] == 0
-        monkeypatch.delenv("BDS_ACQ_TEST_FORCE_FALLBACK")
+        ctx.reload_tuning()  # the knobs are read once per context
+        try:
+            got = bds_amd.acquisition(x, s, verbose=False)
+            assert ctx.timing()["half_storage"] == 0
+        finally:
+            monkeypatch.delenv("BDS_ACQ_TEST_FORCE_FALLBACK")
+            ctx.reload_tuning()
         np.testing.assert_array_equal(got.codePhase, ref.codePhase)
         np.testing.assert_array_equal(got.carrFreq, ref.carrFreq)
         np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0)
-        # a different configuration re-enables the fp16 path
+        # a different configuration re-enables fp16 storage
         bds_amd.acquisition(*small_b1c()[1::-1], verbose=False)
-        assert ctx.timing()["half_storage"] == 2
+        assert ctx.timing()["half_storage"] == 1
 
 
 def test_prn_shards_sum_to_the_full_result(ctx):
@@ -132,14 +142,16 @@ def test_prn_shards_sum_to_the_full_result(ctx):
 
 
 def test_fp32_storage_and_generic_kernels_agree(ctx, monkeypatch):
-    """The specialised fp16-storage path, the specialised fp32-storage path, the run-time generic
-    kernels and the launch-structure variants (4-column tiles, fused chain, plain per-PRN groups) must
-    return the same acqResults (the f64 refinement decides in all of them)."""
+    """The default path (fp32 arithmetic on fp16 storage), fp32 storage, the packed-fp16 arithmetic kernels,
+    the run-time generic kernels and the launch-structure variants (4-column tiles, fused chain, plain
+    per-PRN groups) must return the same acqResults (the f64 refinement decides in all of them)."""
     s, x, _ = medium_b2a()
     base = bds_amd.acquisition(x, s, verbose=False)
-    for env in ({"BDS_ACQ_HMATH": "0"}, {"BDS_ACQ_FP16": "0"}, {"BDS_ACQ_GENERIC": "1"}, {"BDS_ACQ_GENERIC_FWD": "1"},
-                {"BDS_ACQ_LOGT": "2"}, {"BDS_ACQ_LOGT": "2", "BDS_ACQ_HMATH": "0"}, {"BDS_ACQ_NOMULTI": "1"},
-                {"BDS_ACQ_NOMULTI": "1", "BDS_ACQ_NOFUSE": "1", "BDS_ACQ_GROUP": "5", "BDS_ACQ_GCHUNK": "2"}):
+    for env in ({"BDS_ACQ_HMATH": "1"}, {"BDS_ACQ_FP16": "0"}, {"BDS_ACQ_GENERIC": "1"}, {"BDS_ACQ_GENERIC_FWD": "1"},
+                {"BDS_ACQ_LOGT": "2"}, {"BDS_ACQ_LOGT": "2", "BDS_ACQ_HMATH": "1"}, {"BDS_ACQ_NOMULTI": "1"},
+                {"BDS_ACQ_NOMULTI": "1", "BDS_ACQ_FP16": "0"}, {"BDS_ACQ_NOMULTI": "1", "BDS_ACQ_GROUP": "5", "BDS_ACQ_GCHUNK": "2"},
+                {"BDS_ACQ_NOMULTI": "1", "BDS_ACQ_HMATH": "1"},
+                {"BDS_ACQ_NOMULTI": "1", "BDS_ACQ_HMATH": "1", "BDS_ACQ_NOFUSE": "1", "BDS_ACQ_GROUP": "5", "BDS_ACQ_GCHUNK": "2"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         c2 = bds_amd.native.Context(0)
@@ -177,6 +189,7 @@ def test_every_specialised_plan_pair(ctx, monkeypatch, l1):
     the context re-plans."""
     for k, l2 in enumerate((1280, 2048, 3072, 4096)):
         monkeypatch.setenv("BDS_ACQ_FORCE_L1L2", f"{l1}x{l2}")
+        ctx.reload_tuning()
         fs = 10.0e6 + 1000.0 * (l1 + k)
         if k % 2 == 0:
             s = bds_amd.init_settings_b2a(samplingFreq=fs, IF=2.5e6, acqSatelliteList=[7, 19, 33], acqSearchBand=600,
@@ -194,8 +207,10 @@ def test_every_specialised_plan_pair(ctx, monkeypatch, l1):
         ref = fn(x.astype(np.float64), s)
         got = bds_amd.acquisition(x, s, verbose=False)
         tm = ctx.timing()
-        assert tm["fft_len"] == l1 * l2 and tm["half_storage"] == 2
+        assert tm["fft_len"] == l1 * l2 and tm["half_storage"] == 1
         np.testing.assert_array_equal(got.codePhase, ref.codePhase)
         np.testing.assert_array_equal(got.carrFreq, ref.carrFreq)
         np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0)
         assert got.carrFreq[18] != 0
+    monkeypatch.delenv("BDS_ACQ_FORCE_L1L2")
+    ctx.reload_tuning()

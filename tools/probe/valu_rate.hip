@@ -41,6 +41,23 @@ VALU_KERNEL(k_max_f32, "v_max_f32 %0, %0, %4\n v_max_f32 %1, %1, %4\n v_max_f32 
 VALU_KERNEL(k_mad_u32_u24, "v_mad_u32_u24 %0, %0, %4, %5\n v_mad_u32_u24 %1, %1, %4, %5\n v_mad_u32_u24 %2, %2, %4, %5\n v_mad_u32_u24 %3, %3, %4, %5")
 VALU_KERNEL(k_dot2_f32_f16, "v_dot2_f32_f16 %0, %4, %5, %0\n v_dot2_f32_f16 %1, %4, %5, %1\n v_dot2_f32_f16 %2, %4, %5, %2\n v_dot2_f32_f16 %3, %4, %5, %3")
 
+VALU_KERNEL(k_cndmask_sgpr, "v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[20:21]\n v_cndmask_b32_e64 %3, %3, %4, s[20:21]")
+VALU_KERNEL(k_cmp_gt_f32, "v_cmp_gt_f32 vcc, %0, %4\n v_cmp_gt_f32 vcc, %1, %4\n v_cmp_gt_f32 vcc, %2, %4\n v_cmp_gt_f32 vcc, %3, %4")
+VALU_KERNEL(k_cmp_cnd_pair, "v_cmp_gt_f32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_cmp_gt_f32 vcc, %2, %4\n v_cndmask_b32 %3, %3, %4, vcc")
+VALU_KERNEL(k_max3_f32, "v_max3_f32 %0, %0, %4, %5\n v_max3_f32 %1, %1, %4, %5\n v_max3_f32 %2, %2, %4, %5\n v_max3_f32 %3, %3, %4, %5")
+VALU_KERNEL(k_fma_mix_f32, "v_fma_mix_f32 %0, %4, %5, %0 op_sel_hi:[1,1,0]\n v_fma_mix_f32 %1, %4, %5, %1 op_sel_hi:[1,1,0]\n v_fma_mix_f32 %2, %4, %5, %2 op_sel_hi:[1,1,0]\n v_fma_mix_f32 %3, %4, %5, %3 op_sel_hi:[1,1,0]")
+VALU_KERNEL(k_cvt_f16_f32, "v_cvt_f16_f32 %0, %0\n v_cvt_f16_f32 %1, %1\n v_cvt_f16_f32 %2, %2\n v_cvt_f16_f32 %3, %3")
+VALU_KERNEL(k_pack_b32_f16, "v_pack_b32_f16 %0, %0, %4\n v_pack_b32_f16 %1, %1, %4\n v_pack_b32_f16 %2, %2, %4\n v_pack_b32_f16 %3, %3, %4")
+VALU_KERNEL(k_perm_b32, "v_perm_b32 %0, %0, %4, %5\n v_perm_b32 %1, %1, %4, %5\n v_perm_b32 %2, %2, %4, %5\n v_perm_b32 %3, %3, %4, %5")
+VALU_KERNEL(k_lshl_add_u32, "v_lshl_add_u32 %0, %0, 2, %4\n v_lshl_add_u32 %1, %1, 2, %4\n v_lshl_add_u32 %2, %2, 2, %4\n v_lshl_add_u32 %3, %3, 2, %4")
+VALU_KERNEL(k_and_b32, "v_and_b32 %0, %0, %4\n v_and_b32 %1, %1, %4\n v_and_b32 %2, %2, %4\n v_and_b32 %3, %3, %4")
+VALU_KERNEL(k_mul_lo_u32, "v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4")
+VALU_KERNEL(k_max_f32_e64, "v_max_f32_e64 %0, %0, %4\n v_max_f32_e64 %1, %1, %4\n v_max_f32_e64 %2, %2, %4\n v_max_f32_e64 %3, %3, %4")
+VALU_KERNEL(k_fma_f32_neg, "v_fma_f32 %0, -%0, %4, %5\n v_fma_f32 %1, -%1, %4, %5\n v_fma_f32 %2, -%2, %4, %5\n v_fma_f32 %3, -%3, %4, %5")
+VALU_KERNEL(k_sub_f32, "v_sub_f32 %0, %0, %4\n v_sub_f32 %1, %1, %4\n v_sub_f32 %2, %2, %4\n v_sub_f32 %3, %3, %4")
+VALU_KERNEL(k_fmac_f32, "v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %4, %5\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %4, %5")
+VALU_KERNEL(k_rsq_f32, "v_rsq_f32 %0, %0\n v_rsq_f32 %1, %1\n v_rsq_f32 %2, %2\n v_rsq_f32 %3, %3")
+
 // packed f32: 64-bit register pairs
 __global__ __launch_bounds__(256) void k_pk_fma_f32(float *out, float seed) {
     double a0, a1, a2, a3, b0, b1;  // just 64-bit containers
@@ -196,6 +213,22 @@ int main() {
     R(k_mad_u32_u24);
     R(k_cndmask);
     R(k_max_f32);
+    R(k_cndmask_sgpr);
+    R(k_cmp_gt_f32);
+    R(k_cmp_cnd_pair);
+    R(k_max3_f32);
+    R(k_max_f32_e64);
+    R(k_fma_mix_f32);
+    R(k_cvt_f16_f32);
+    R(k_pack_b32_f16);
+    R(k_perm_b32);
+    R(k_lshl_add_u32);
+    R(k_and_b32);
+    R(k_mul_lo_u32);
+    R(k_fma_f32_neg);
+    R(k_sub_f32);
+    R(k_fmac_f32);
+    R(k_rsq_f32);
     const double nl = 64.0 * ITER / 4;
     run("ds_read_b32", k_ds_read_b32, out, nl, 4);
     run("ds_read_b64", k_ds_read_b64, out, nl, 8);
