@@ -539,6 +539,9 @@ struct SieveOut {
     int cell0 = 0;     // run-wide index of cell 0 of the launch
     float keep = 1.f;  // 1 - sieve tolerance
     hipEvent_t mid = nullptr;  // recorded between the two passes of a sampled launch pair (timing)
+    // overlapped passes: the column pass runs on its own stream behind ev_rows and signals ev_cols
+    hipStream_t cols_stream = nullptr;
+    hipEvent_t ev_rows = nullptr, ev_cols = nullptr;
 };
 
 // ---- fp32-arithmetic search kernels (bds_acq_f32.h): dispatch on the compile-time lengths --------------
@@ -551,8 +554,10 @@ static void launch_rows_f(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const 
     int nch = (G + ctx->tune.gchunk - 1) / ctx->tune.gchunk;
     int gc = (G + nch - 1) / nch;
     if (cl.bin) gc = cl.gc, nch = (G + cl.gc - 1) / cl.gc;  // a workgroup stays inside one PRN's cells
-    const RowsFArgs A{(const float2 *)pl.d_tw2, pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs};
-    hipLaunchKernelGGL((k_rows_inv_f<S, NC, ST>), dim3(pl.L1 * nch), dim3(rows_threads<S>()), lds, sr, A);
+    const int nvb = pl.L1 * nch;  // L1 % 8 == 0 on every specialised plan: virtual workgroup vb sits on XCD vb % 8
+    const RowsFArgs A{(const float2 *)pl.d_tw2, pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs, nvb};
+    const int grid = ctx->tune.rows_grid > 0 ? std::min(nvb, (ctx->tune.rows_grid + 7) / 8 * 8) : nvb;
+    hipLaunchKernelGGL((k_rows_inv_f<S, NC, ST>), dim3(grid), dim3(rows_threads<S>()), lds, sr, A);
 }
 template <int S, int T, int NC, class ST>
 static void launch_cols_ft(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1,
@@ -589,12 +594,19 @@ static void launch_fast_f(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const
         default: launch_rows_f<4096, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl); break;
     }
     if (so.mid) (void)hipEventRecord(so.mid, st_);
-    switch (pl.L1) {
-        case 256: launch_cols_f<256, NC, ST>(ctx, st_, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
-        case 512: launch_cols_f<512, NC, ST>(ctx, st_, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
-        case 768: launch_cols_f<768, NC, ST>(ctx, st_, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
-        default: launch_cols_f<1024, NC, ST>(ctx, st_, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
+    hipStream_t sc = st_;
+    if (so.cols_stream) {
+        sc = so.cols_stream;
+        (void)hipEventRecord(so.ev_rows, st_);
+        (void)hipStreamWaitEvent(sc, so.ev_rows, 0);
     }
+    switch (pl.L1) {
+        case 256: launch_cols_f<256, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
+        case 512: launch_cols_f<512, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
+        case 768: launch_cols_f<768, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
+        default: launch_cols_f<1024, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
+    }
+    if (so.cols_stream) (void)hipEventRecord(so.ev_cols, sc);
 }
 
 // ---- fp16-arithmetic search kernels ---------------------------------------------------------------
@@ -1079,13 +1091,32 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     // one group of cells of one PRN (consecutive bins b0 .. b0+nb-1, or one bin with lag ranges): both passes on the
     // main stream; cell0 = run-wide index of the first cell (overflow-list bookkeeping)
     bool mids = false;  // the sampled pairs carry a mid event (fp32-arithmetic kernels)
-    auto launch_cells = [&](int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2, int cell0, hipEvent_t mid) {
+    // Overlapped passes (BDS_ACQ_OVERLAP=1, fp32-arithmetic kernels): the row pass is HBM-bound, the column pass
+    // VALU / barrier-bound; group k's column pass runs on a second stream beside group k+1's row pass, the two
+    // working in different halves of the inter-pass buffer.
+    const bool overlap = fsearch && tune.overlap && !multiprn;
+    hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
+    if (overlap)
+        for (int i = 0; i < 2; ++i) {
+            BDS_HIP(ctx, evp.make(&ev_rows[i], hipEventDisableTiming));
+            BDS_HIP(ctx, evp.make(&ev_cols[i], hipEventDisableTiming));
+        }
+    const size_t half_bytes = (size_t)G * ncomp * pl.L * elem;  // one group of cells in the inter-pass buffer
+    long group_idx = 0;
+    auto launch_cells = [&](int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2, int cell0, hipEvent_t mid,
+                            int buf = -1) {
         const size_t cs_off = (size_t)a.cs_slot[prn] * ncomp * pl.L;
         SieveOut so1 = so;
         so1.recs = recs;
         so1.cell0 = cell0;
         so1.mid = mid;
         if (mid && fsearch) mids = true;
+        void *const Bw_ = buf > 0 ? (void *)((char *)a.d_Bw + half_bytes) : (void *)a.d_Bw;
+        if (buf >= 0) {
+            so1.cols_stream = (hipStream_t)ctx->stream2;
+            so1.ev_rows = ev_rows[buf];
+            so1.ev_cols = ev_cols[buf];
+        }
         if (hsearch) {
             const void *Ch = (const __half2 *)a.d_Cs + cs_off;
             if (ncomp == 2)
@@ -1095,15 +1126,15 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         } else if (fsearch && a.half) {
             const void *Ch = (const __half2 *)a.d_Cs + cs_off;
             if (ncomp == 2)
-                launch_fast_f<2, __half2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
+                launch_fast_f<2, __half2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
             else
-                launch_fast_f<1, __half2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
+                launch_fast_f<1, __half2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
         } else if (fsearch) {
             const void *Cf = a.d_Cs + cs_off;
             if (ncomp == 2)
-                launch_fast_f<2, float2>(ctx, s_main, pl, a.d_Xs, nb, b0, Cf, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
+                launch_fast_f<2, float2>(ctx, s_main, pl, a.d_Xs, nb, b0, Cf, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
             else
-                launch_fast_f<1, float2>(ctx, s_main, pl, a.d_Xs, nb, b0, Cf, a.d_Bw, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
+                launch_fast_f<1, float2>(ctx, s_main, pl, a.d_Xs, nb, b0, Cf, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
         } else {
             const float2 *Cs = a.d_Cs + cs_off;
             dim3 gr(pl.L1, nb), gc(pl.ntiles, nb);
@@ -1215,15 +1246,20 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         pair_idx = ng;
     } else {
         for (int pi = 0; pi < P; ++pi) {
-            for (int b0 = 0; b0 < D; b0 += G, ++pair_idx) {
+            for (int b0 = 0; b0 < D; b0 += G, ++pair_idx, ++group_idx) {
                 const int nb = std::min(G, D - b0);
-                const bool sample = nb == G && (pair_idx % sample_every) == 0 && nsamp < kSamples;
+                const int buf = overlap ? (int)(group_idx & 1) : -1;
+                // the row pass of group k re-uses the buffer half the column pass of group k-2 read
+                if (overlap && group_idx >= 2) BDS_HIP(ctx, hipStreamWaitEvent(s_main, ev_cols[buf], 0));
+                const bool sample = !overlap && nb == G && (pair_idx % sample_every) == 0 && nsamp < kSamples;
                 if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], st(ctx)));
                 launch_cells(prns[pi], b0, nb, a.d_recs + ((size_t)pi * D + b0) * pl.ntiles, 0, (int)a.N - 1, 1, 0, pi * D + b0,
-                             sample ? sm[nsamp] : nullptr);
+                             sample ? sm[nsamp] : nullptr, buf);
                 if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], st(ctx)));
             }
         }
+        if (overlap)  // join: everything after this is ordered on the main stream again
+            for (int i = 0; i < 2 && i < group_idx; ++i) BDS_HIP(ctx, hipStreamWaitEvent(s_main, ev_cols[i], 0));
     }
     BDS_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)(P * D)), dim3(256), 0, st(ctx), (const Rec *)a.d_recs,
@@ -1263,7 +1299,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             for (size_t i = 0; i < std::min<size_t>(8, a.h_rowmax.size()); ++i) fprintf(stderr, " %g", a.h_rowmax[i]);
             fprintf(stderr, "  (sX %g sC %g sB %g)\n", a.sX, a.sC, a.sB);
         }
-        if (a.half && (bad || tune.test_force_fallback)) return rerun(false, bad ? "non-finite row maximum" : "test hook");
+        if (a.half && ((bad && !tune.no_selfcheck) || tune.test_force_fallback)) return rerun(false, bad ? "non-finite row maximum" : "test hook");
         if (n_extra > kExtraCap && !a.no_fast_search) return rerun(true, "overflow list of the sieve ran over");
     }
     std::vector<Extra> h_extra((size_t)std::min(n_extra, kExtraCap));
@@ -1365,7 +1401,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             res[pi].codePhase = bc.lag + 1;
             // The sieve's maximum must agree with the f64 value to well inside the tolerance band it was
             // searched with; otherwise its error model does not hold for this input: redo with fp32 storage.
-            if (a.half && !cells[pi].empty() && std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
+            if (a.half && !tune.no_selfcheck && !cells[pi].empty() && std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
                 char why[160];
                 snprintf(why, sizeof(why), "PRN %d: sieve maximum %.9g vs f64 %.9g (rel %.3g > %.3g)", prns[pi], (double)max_of[pi], best,
                          std::fabs(best - (double)max_of[pi]) / best, 0.5 * kDelta);

@@ -19,6 +19,22 @@
 
 #include "bds_acq_fast.h"
 
+// Timing experiments (tools/exp_parts.sh; results are INVALID with any of these defined):
+//   BDS_EXP_NOBARRIER  __syncthreads() of the two search kernels compiled out
+//   BDS_EXP_ROWS_NOSTORE / BDS_EXP_COLS_NOLOAD  no inter-pass buffer traffic
+//   BDS_EXP_ROWS_OCC   launch bound (waves per SIMD) of the row pass
+#ifdef BDS_EXP_NOBARRIER
+#define BDS_SYNC() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define BDS_SYNC() __syncthreads()
+#endif
+// Row pass at 2 waves per SIMD: it needs ~216 VGPRs (two packed code-spectrum rows, the inter-pass twiddles and a
+// radix-16 butterfly with its twiddles live at once); squeezed into the 168 of a third wave it spills ~48 of them
+// to scratch inside the cell loop, which doubles the kernel's HBM reads (measured 2.4 ms vs 2.0 ms per 201 cells).
+#ifndef BDS_EXP_ROWS_OCC
+#define BDS_EXP_ROWS_OCC 2
+#endif
+
 namespace bds {
 
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -58,6 +74,7 @@ struct RowsFArgs {
     int NCH;            // = ceil(G / GC): workgroups per row
     const int *cell_bin;   // optional cell list: Doppler bin of cell g ...
     const long *cell_cs;   // ... and element offset of its code spectra from Cs
+    int nvb;               // virtual workgroups (= L1 * NCH); a launch with fewer workgroups strides over them
 };
 
 // ---- inverse row pass ------------------------------------------------------------------------------
@@ -78,7 +95,6 @@ __device__ __forceinline__ void rows_inv_f_body(const RowsFArgs &A, int vb, int 
     const int GC = A.GC, NCH = A.NCH;
     const int g0 = (m % NCH) * GC, k1 = (m / NCH) * 8 + xcd;
     const int g1 = g0 + GC < A.G ? g0 + GC : A.G;
-    if (k1 >= A.L1) return;
     const ST *Cs = (const ST *)A.Cs;
     if (A.cell_cs) Cs += A.cell_cs[g0];
     if (tid < MBL) s_a[tid] = A.twl.get<+1>((uint32_t)((long)k1 * NT * tid));
@@ -156,6 +172,9 @@ __device__ __forceinline__ void rows_inv_f_body(const RowsFArgs &A, int vb, int 
             };
             auto out = [&](int i, int q, int, int e, float2 v) {
                 const float2 t = cmul(v, wo[i][q]);
+#ifdef BDS_EXP_ROWS_NOSTORE
+                if (t.x == 1.2345f)
+#endif
                 if constexpr (HS)
                     *reinterpret_cast<uint32_t *>(dst + e) = f2_to_h2(t);
                 else
@@ -167,7 +186,7 @@ __device__ __forceinline__ void rows_inv_f_body(const RowsFArgs &A, int vb, int 
                 if (comp == NCOMP - 1 && g + 1 < g1) fetch_x(g + 1);
             };
             TPlan<S>::template run_hook<1, NT, +1>(ldsf, (const float2 *)tw_lds, tid, src, out, next);
-            if (comp + 1 < NCOMP || g + 1 < g1) __syncthreads();  // last-stage reads precede the next first-stage writes
+            if (comp + 1 < NCOMP || g + 1 < g1) BDS_SYNC();  // last-stage reads precede the next first-stage writes
         }
     }
 }
@@ -249,7 +268,11 @@ __device__ __forceinline__ void cols_inv_max_f_body(const ColsFArgs &A, int tb, 
         for (int i = 0; i < NI; ++i) {
             const int it = tid + i * NT;
             const int r = it / QG, cq = (it % QG) * 4;
+#ifdef BDS_EXP_COLS_NOLOAD
+            if (full_tile && A.w0 == 1.2345f) {
+#else
             if (full_tile) {
+#endif
                 if constexpr (HS)
                     pre[i] = *reinterpret_cast<const uint4 *>(src + (long)r * L2 + c0 + cq);
                 else
@@ -275,7 +298,7 @@ __device__ __forceinline__ void cols_inv_max_f_body(const ColsFArgs &A, int tb, 
                 for (int k = 0; k < 4; ++k) ldsf[(cq + k) * SP + pr] = pre[i].v[k];
             }
         }
-        __syncthreads();
+        BDS_SYNC();
         if (comp + 1 < NCOMP) fetch(comp + 1);  // in flight during the transform
         const float w = comp == 0 ? A.w0 : A.w1;
         // Output q of the last stage covers rows q*NSL .. q*NSL+NSL-1: a whole q beyond the searched lags
@@ -288,7 +311,7 @@ __device__ __forceinline__ void cols_inv_max_f_body(const ColsFArgs &A, int tb, 
             }
         };
         TPlan<S>::template run<T, NT, +1>(ldsf, (const float2 *)tw_lds, tid, LdsIO{}, out);
-        if (comp + 1 < NCOMP) __syncthreads();  // last-stage reads done before the tile is overwritten
+        if (comp + 1 < NCOMP) BDS_SYNC();  // last-stage reads done before the tile is overwritten
     }
     // lag of output (i, q): (bb + q NSL) L2 + c0 + j with b = tid + i NT, j = b / NSL, bb = b % NSL
     auto lag_of = [&](int i, int q) {
@@ -361,8 +384,13 @@ __device__ __forceinline__ void cols_inv_max_f_body(const ColsFArgs &A, int tb, 
 }
 
 template <int S, int NCOMP, class ST>
-__global__ __launch_bounds__(rows_threads<S>(), 3) void k_rows_inv_f(RowsFArgs A) {
-    rows_inv_f_body<S, NCOMP, ST>(A, (int)blockIdx.x, (int)threadIdx.x);
+__global__ __launch_bounds__(rows_threads<S>(), BDS_EXP_ROWS_OCC) void k_rows_inv_f(RowsFArgs A) {
+    // (a grid smaller than nvb makes the workgroups persistent: with the column pass of the previous group on a
+    //  second stream they then share every CU with it instead of queueing in front of it)
+    for (int vb = (int)blockIdx.x; vb < A.nvb; vb += (int)gridDim.x) {
+        rows_inv_f_body<S, NCOMP, ST>(A, vb, (int)threadIdx.x);
+        if (vb + (int)gridDim.x < A.nvb) BDS_SYNC();  // the next item rewrites the LDS tables
+    }
 }
 
 template <int S, int T, int NCOMP, bool MASKED, class ST>

@@ -52,6 +52,9 @@ Tuning tuning_from_env() {
     t.nofuse = has("BDS_ACQ_NOFUSE");
     t.fchunk = std::max(1, geti("BDS_ACQ_FCHUNK", 2));
     t.rows_occ2 = geti("BDS_ACQ_ROWS_OCC2", 0);
+    t.rows_grid = std::max(0, geti("BDS_ACQ_ROWS_GRID", 0));
+    t.overlap = has("BDS_ACQ_OVERLAP");
+    t.no_selfcheck = has("BDS_ACQ_NO_SELFCHECK");
     t.test_force_fallback = has("BDS_ACQ_TEST_FORCE_FALLBACK");
     t.verbose = has("BDS_VERBOSE");
     t.trk_chunk = std::max(0, geti("BDS_TRK_CHUNK", 0));

@@ -14,6 +14,12 @@
 
 #include "bds_fft.h"
 
+#ifdef BDS_EXP_NOBARRIER
+#define BDS_TSYNC() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define BDS_TSYNC() __syncthreads()
+#endif
+
 namespace bds {
 
 template <int S>
@@ -76,7 +82,7 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
             }
         }
     }
-    if constexpr (SRC_LDS && DST_LDS) __syncthreads();  // every read of this stage precedes its writes
+    if constexpr (SRC_LDS && DST_LDS) BDS_TSYNC();  // every read of this stage precedes its writes
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
         const int b = tid + i * NT;
@@ -133,7 +139,7 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
             }
         }
     }
-    if constexpr (DST_LDS) __syncthreads();
+    if constexpr (DST_LDS) BDS_TSYNC();
 }
 
 // All stages of a plan; the first stage takes Src, the last one Dst, everything between is LDS.

@@ -41,6 +41,9 @@ struct Tuning {
     bool fuse = false, nofuse = false;  // BDS_ACQ_FUSE / BDS_ACQ_NOFUSE (fp16-arithmetic kernels only)
     int fchunk = 2;                  // BDS_ACQ_FCHUNK
     int rows_occ2 = 0;               // BDS_ACQ_ROWS_OCC2: row pass built for 2 waves per SIMD (256 VGPRs)
+    int rows_grid = 0;                  // BDS_ACQ_ROWS_GRID: workgroups of the (then persistent) row pass; 0 = one per item
+    bool overlap = false;               // BDS_ACQ_OVERLAP: column pass of group k on a second stream beside the row pass of group k+1
+    bool no_selfcheck = false;          // BDS_ACQ_NO_SELFCHECK: timing experiments with invalid results (no re-run)
     bool test_force_fallback = false;   // BDS_ACQ_TEST_FORCE_FALLBACK: test hook, take the fp16 -> fp32 storage re-run
     bool verbose = false;            // BDS_VERBOSE
     int trk_chunk = 0;               // BDS_TRK_CHUNK: samples per correlate workgroup (0 = per-mode default)

@@ -17,7 +17,8 @@ TRACK_MODE = {"B2A": 0, "NB": 1, "WB": 2}
 CODE_KIND = {"data": 0, "pilot": 1, "data_boc11": 2, "pilot_boc11": 3, "pilot_boc61": 4, "pilot_secondary": 5}
 CODE_LEN = {0: 10230, 1: 10230, 2: 20460, 3: 20460, 4: 122760, 5: 1800}
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbds_mi355x.so")
+# BDS_LIB_PATH: load another build of the library (tools/exp_parts.sh timing variants); default = the in-tree build
+_LIB_PATH = os.environ.get("BDS_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbds_mi355x.so")
 
 
 class BdsError(RuntimeError):

@@ -18,4 +18,6 @@ FETCH_SIZE GRBM_GUI_ACTIVE
 WRITE_SIZE TCC_HIT TCC_MISS
 TA_TA_BUSY TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES
 SETS
-ls -la gpurun_out/pmc
+python tools/pmc_summary.py gpurun_out/pmc/pass*_results.db > gpurun_out/pmc_summary.txt 2>&1
+rm -rf gpurun_out/pmc
+grep -c "^==" gpurun_out/pmc_summary.txt
