@@ -302,6 +302,7 @@ struct AcqState {
     size_t extra_cap = 0;
     int *d_extra_count = nullptr;
     int n_extra_last = 0;            // entries of the last search (diagnostics)
+    std::map<int, std::vector<std::pair<int, long>>> last_cands;  // PRN -> (bin, lag) cells the last run refined in f64
     bool no_fast_search = false;     // this configuration fell back to the run-time-plan search kernels
     CorrJob *d_jobs = nullptr;
     double2 *d_jobout = nullptr;
@@ -1062,7 +1063,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     const bool hsearch = pl.fast && a.hmath && !a.no_fast_search;   // packed-fp16 arithmetic kernels (opt-in)
     // sieve tolerance: every lag within kDelta of a PRN's maximum is re-evaluated in f64.  fp32 storage errs by
     // ~1e-7 of the output RMS, fp16 storage by ~3e-4, fp16 arithmetic by ~1.3e-3 (tools/sieve_error.py)
-    const double kDelta = a.hmath ? 1e-2 : a.half ? 2e-3 : 2e-5;
+    const double kDelta = tune.kdelta > 0 ? tune.kdelta : a.hmath ? 1e-2 : a.half ? 2e-3 : 2e-5;
     // overflow list of the column pass: lags within kDelta of their tile's maximum (other than the tile's record)
     constexpr int kExtraCap = 1 << 22;
     {
@@ -1366,8 +1367,11 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             const int pi = e.cell / D, b = e.cell % D;
             if (pi >= 0 && pi < P && e.lag >= 0 && !(e.v < thr_of[pi])) add(pi, b, e.lag);
         }
+        a.last_cands.clear();
         for (int pi = 0; pi < P; ++pi) {
             cells[pi].assign(cs[pi].begin(), cs[pi].end());
+            auto &lc = a.last_cands[prns[pi]];
+            for (const Cell &c : cells[pi]) lc.push_back({c.b, c.lag});
             for (const Cell &c : cells[pi])
                 for (int comp = 0; comp < ncomp; ++comp) {
                     CorrJob j{};
@@ -1697,6 +1701,18 @@ extern "C" int bds_acq_grid(bds_ctx *ctx, float *row_max, int32_t *row_arg, int 
     for (int i = 0; i < n; ++i) {
         if (row_max) row_max[i] = a.h_rowmax[i];
         if (row_arg) row_arg[i] = a.h_rowarg[i] + 1;  // 1-based like the reference
+    }
+    return n;
+}
+
+extern "C" int bds_acq_candidates(bds_ctx *ctx, int prn, int32_t *bin, int64_t *lag, int cap) {
+    if (!ctx || !ctx->acq) return BDS_ERR_ARG;
+    auto it = ctx->acq->last_cands.find(prn);
+    if (it == ctx->acq->last_cands.end()) return 0;
+    const int n = (int)it->second.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (bin) bin[i] = it->second[(size_t)i].first + 1;   // 1-based like the reference's indices
+        if (lag) lag[i] = it->second[(size_t)i].second + 1;
     }
     return n;
 }

@@ -43,6 +43,7 @@ struct Tuning {
     int rows_occ2 = 0;               // BDS_ACQ_ROWS_OCC2: row pass built for 2 waves per SIMD (256 VGPRs)
     int rows_grid = 0;                  // BDS_ACQ_ROWS_GRID: workgroups of the (then persistent) row pass; 0 = one per item
     bool overlap = false;               // BDS_ACQ_OVERLAP: column pass of group k on a second stream beside the row pass of group k+1
+    double kdelta = 0;                  // BDS_ACQ_KDELTA: test hook, sieve tolerance override (0 = per-mode default)
     bool no_selfcheck = false;          // BDS_ACQ_NO_SELFCHECK: timing experiments with invalid results (no re-run)
     bool test_force_fallback = false;   // BDS_ACQ_TEST_FORCE_FALLBACK: test hook, take the fp16 -> fp32 storage re-run
     bool verbose = false;            // BDS_VERBOSE

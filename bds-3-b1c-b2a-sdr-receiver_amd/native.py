@@ -74,7 +74,7 @@ class Timing(C.Structure):
 
 EXPORTS = [
     "bds_create", "bds_destroy", "bds_reload_tuning", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_gen_code", "bds_acquire",
-    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_get_timing",
+    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_acq_candidates", "bds_get_timing",
     "bds_track", "bds_track_mem", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
     "bds_calc_weighing_factor", "bds_pre_run",
 ]
@@ -113,6 +113,7 @@ def lib():
     L.bds_acq_run.restype = i32
     L.bds_acq_run.argtypes = [vp, SP, _IP, i32, i32, _DP, _DP, _DP, _IP]
     L.bds_acq_grid.restype, L.bds_acq_grid.argtypes = i32, [vp, C.POINTER(C.c_float), _IP, i32]
+    L.bds_acq_candidates.restype, L.bds_acq_candidates.argtypes = i32, [vp, i32, _IP, C.POINTER(C.c_int64), i32]
     L.bds_acq_peaks.restype, L.bds_acq_peaks.argtypes = i32, [vp, i32, _DP, _DP, _IP]
     L.bds_get_timing.restype, L.bds_get_timing.argtypes = i32, [vp, C.POINTER(Timing)]
     L.bds_track.restype = i32
@@ -338,6 +339,15 @@ class Context:
         self._check(self._lib.bds_acq_grid(self._h, rm.ctypes.data_as(C.POINTER(C.c_float)),
                                            ra.ctypes.data_as(_IP), rm.size))
         return rm.reshape(n_prn, n_bins), ra.reshape(n_prn, n_bins)
+
+    def acq_candidates(self, prn):
+        """(bin, codePhase) cells of `prn` the last run refined in f64, 1-based: int array [n, 2]."""
+        n = self._check(self._lib.bds_acq_candidates(self._h, int(prn), None, None, 0))
+        b = np.zeros(max(n, 1), dtype=np.int32)
+        l = np.zeros(max(n, 1), dtype=np.int64)
+        self._check(self._lib.bds_acq_candidates(self._h, int(prn), b.ctypes.data_as(_IP),
+                                                 l.ctypes.data_as(C.POINTER(C.c_int64)), n))
+        return np.stack([b[:n].astype(np.int64), l[:n]], axis=1)
 
     def acq_peaks(self, max_prn):
         pk = np.zeros(max_prn)

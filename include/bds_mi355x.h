@@ -197,6 +197,10 @@ BDS_API int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *prn_
 BDS_API int bds_acq_grid(bds_ctx *ctx, float *row_max, int32_t *row_arg, int cap);
 /* Peak / second-peak (B2a) or peak / sigPower (B1C) of the last run, per PRN slot:
  * peak[max_prn], denom[max_prn], fbin[max_prn] (1-based frequency bin). */
+/* Diagnostics of the sieve: the (Doppler bin, code phase) cells of `prn` the last bds_acq_run re-evaluated in
+ * f64 (1-based, like the reference's indices into results(bin, codePhase)).  Returns their number (may exceed
+ * cap).  Tests use it to check that every cell within the sieve tolerance of the maximum was refined. */
+BDS_API int bds_acq_candidates(bds_ctx *ctx, int prn, int32_t *bin, int64_t *lag, int cap);
 BDS_API int bds_acq_peaks(bds_ctx *ctx, int max_prn, double *peak, double *denom, int32_t *fbin);
 BDS_API int bds_get_timing(bds_ctx *ctx, bds_timing *t);
 

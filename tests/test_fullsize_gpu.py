@@ -68,6 +68,45 @@ def test_b1c_full_grid(ctx):
         np.testing.assert_array_equal(getattr(a, f) + getattr(b2, f), getattr(res, f))
 
 
+def test_b1c_full_grid_absent_prn_against_the_whole_oracle_matrix(ctx):
+    """BASELINE.json configs[2], one PRN that is NOT in the block, against the oracle on ALL 201 Doppler bins
+    (201 x 1 987 500 results matrix, B1C/acquisition.m:191-222): the global argmax of a noise-only surface is the
+    hard case for the sieve -- no peak stands out, so a wrong tile record or a hidden near-tie would change
+    fbin / codePhase.  max(max(results)) (:229-235), its bin and its code phase must match exactly."""
+    s, x, sats, _ = bench.build_workload("b1c")
+    prn = 2
+    assert prn not in [sat.prn for sat in sats]
+    sub = s.copy(acqSatelliteList=[prn])
+    res = bds_amd.acquisition(x, sub, verbose=False)
+    tm = ctx.timing()
+    pk, dn, fb = ctx.acq_peaks(63)
+    rm, ra = ctx.acq_grid(1, 201)
+    cand = set(map(tuple, ctx.acq_candidates(prn).tolist()))
+    xf = x.astype(np.float64)
+    best, best_b, best_lag = -1.0, -1, -1
+    tol = {0: 1e-5, 1: 1e-3, 2: 5e-3}[tm["half_storage"]]  # kDelta / 2 of the mode
+    near = []
+    for b, row in oacq.b1c_coarse_rows(xf, sub, prn):
+        m = float(row.max())
+        np.testing.assert_allclose(rm[0, b], m, rtol=tol)  # the sieve's row maximum, within half its tolerance
+        if m > best:  # first maximal row / first maximal column, like max(max(results))
+            best, best_b, best_lag = m, b, int(np.argmax(row))
+        near.append((b, row))
+        near[-1] = (b, np.nonzero(row >= (1 - tol) * m)[0], row[row >= (1 - tol) * m])
+    assert fb[prn - 1] == best_b + 1
+    np.testing.assert_allclose(pk[prn - 1], best, rtol=1e-9)
+    assert (best_b + 1, best_lag + 1) in cand
+    # every cell of the whole matrix within kDelta / 2 of the global maximum was refined
+    for b, lags, vals in near:
+        for lag, v in zip(lags.tolist(), vals.tolist()):
+            if v >= (1 - tol) * best:
+                assert (b + 1, lag + 1) in cand, (b, lag, v, best)
+    # acqResults of the absent PRN: metric below threshold -> zeros, metric = peak / sigPower
+    sig_power = np.sqrt(np.var(xf[:993750], ddof=1) * 993750)
+    np.testing.assert_allclose(res.peakMetric[prn - 1], best / sig_power, rtol=1e-9)
+    assert res.carrFreq[prn - 1] == 0 and res.codePhase[prn - 1] == 0
+
+
 def test_argument_errors_are_reported(ctx):
     s = bds_amd.init_settings_b2a(acqSatelliteList=[5])
     x = np.zeros(1000, dtype=np.int8)
