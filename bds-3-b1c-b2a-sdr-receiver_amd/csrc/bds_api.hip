@@ -58,6 +58,7 @@ Tuning tuning_from_env() {
     t.no_selfcheck = has("BDS_ACQ_NO_SELFCHECK");
     t.test_force_fallback = has("BDS_ACQ_TEST_FORCE_FALLBACK");
     t.verbose = has("BDS_VERBOSE");
+    t.multi_force_rccl = has("BDS_MULTI_FORCE_RCCL");
     t.trk_chunk = std::max(0, geti("BDS_TRK_CHUNK", 0));
     return t;
 }

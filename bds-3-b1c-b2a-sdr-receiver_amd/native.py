@@ -72,11 +72,19 @@ class Timing(C.Structure):
                 ("rows_ms", C.c_double), ("cols_ms", C.c_double), ("n_extra", C.c_int64)]
 
 
+class AcqJob(C.Structure):
+    _fields_ = [("settings", C.POINTER(Settings)), ("samples", C.POINTER(C.c_int8)), ("n_samples", C.c_size_t),
+                ("is_complex", C.c_int32), ("max_prn", C.c_int32), ("carrFreq", _DP), ("codePhase", _DP),
+                ("peakMetric", _DP), ("detected", _IP)]
+
+
 EXPORTS = [
     "bds_create", "bds_destroy", "bds_reload_tuning", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_gen_code", "bds_acquire",
     "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_acq_candidates", "bds_get_timing",
     "bds_track", "bds_track_mem", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
     "bds_calc_weighing_factor", "bds_pre_run",
+    "bds_multi_create", "bds_multi_destroy", "bds_multi_last_error", "bds_multi_size", "bds_multi_ctx",
+    "bds_multi_rccl_ranks", "bds_acquire_multi", "bds_shard_jobs", "bds_acq_job_cost",
 ]
 
 _lib = None
@@ -103,6 +111,15 @@ def lib():
     L.bds_create.restype, L.bds_create.argtypes = vp, [i32]
     L.bds_destroy.restype, L.bds_destroy.argtypes = None, [vp]
     L.bds_reload_tuning.restype, L.bds_reload_tuning.argtypes = i32, [vp]
+    L.bds_multi_create.restype, L.bds_multi_create.argtypes = vp, [i32, _IP]
+    L.bds_multi_destroy.restype, L.bds_multi_destroy.argtypes = None, [vp]
+    L.bds_multi_last_error.restype, L.bds_multi_last_error.argtypes = C.c_char_p, [vp]
+    L.bds_multi_size.restype, L.bds_multi_size.argtypes = i32, [vp]
+    L.bds_multi_ctx.restype, L.bds_multi_ctx.argtypes = vp, [vp, i32]
+    L.bds_multi_rccl_ranks.restype, L.bds_multi_rccl_ranks.argtypes = i32, [vp]
+    L.bds_acquire_multi.restype, L.bds_acquire_multi.argtypes = i32, [vp, i32, C.POINTER(AcqJob)]
+    L.bds_shard_jobs.restype, L.bds_shard_jobs.argtypes = i32, [i32, _DP, i32, _IP]
+    L.bds_acq_job_cost.restype, L.bds_acq_job_cost.argtypes = C.c_double, [SP]
     L.bds_last_error.restype, L.bds_last_error.argtypes = C.c_char_p, [vp]
     L.bds_device_name.restype, L.bds_device_name.argtypes = i32, [vp, C.c_char_p, i32]
     L.bds_gen_code.restype, L.bds_gen_code.argtypes = i32, [i32, i32, i32, i8p, i32]
@@ -143,7 +160,9 @@ def lib():
 
 
 def pack_settings(s) -> Settings:
-    """MATLAB-style settings struct -> bds_settings (missing field -> error naming the field)."""
+    """MATLAB-style settings struct -> bds_settings.  Every field of SURVEY.md Appendix D that the selected
+    receiver's initSettings.m defines is REQUIRED (a missing or misspelt field is an error naming it, never a silent
+    default) -- the same rule as mex/bds_mex.c:pack_settings."""
     cs = Settings()
     sig = str(getattr(s, "signal", "")).upper()
     if sig not in SIGNAL:
@@ -155,43 +174,45 @@ def pack_settings(s) -> Settings:
             raise AttributeError(f"settings.{name} is missing")
         return getattr(s, name)
 
-    def opt(name, default):
-        return getattr(s, name, default)
-
-    dt = str(opt("dataType", "schar"))
     # the library rejects anything but int8 samples (BDS_ERR_UNSUPPORTED names the field)
-    cs.dataType = 0 if dt in ("schar", "int8") else 1
-    cs.fileType = int(opt("fileType", 1))
+    cs.dataType = 0 if str(need("dataType")) in ("schar", "int8") else 1
+    cs.fileType = int(need("fileType"))
     cs.samplingFreq = float(need("samplingFreq"))
     cs.IF = float(need("IF"))
     cs.codeFreqBasis = float(need("codeFreqBasis"))
-    cs.carrFreqBasis = float(opt("carrFreqBasis", 0.0))
+    cs.carrFreqBasis = float(need("carrFreqBasis"))
     cs.codeLength = int(need("codeLength"))
-    cs.numberOfChannels = int(opt("numberOfChannels", 0))
-    cs.skipNumberOfBytes = int(opt("skipNumberOfBytes", 0))
-    cs.msToProcess = float(opt("msToProcess", 0))
-    cs.acqSearchBand = float(opt("acqSearchBand", 0))
-    cs.acqStep = float(opt("acqStep", 1))
-    cs.acqThreshold = float(opt("acqThreshold", 0))
-    cs.acqCohT = float(opt("acqCohT", 10))
-    cs.pilotACQflag = int(opt("pilotACQflag", 1))
-    cs.fineNoncoh = int(opt("fineNoncoh", 15))
-    cs.resamplingThreshold = float(opt("resamplingThreshold", 0))
-    cs.resamplingflag = int(opt("resamplingflag", 0))
-    sats = [int(p) for p in np.atleast_1d(opt("acqSatelliteList", []))]
+    cs.numberOfChannels = int(need("numberOfChannels"))
+    cs.skipNumberOfBytes = int(need("skipNumberOfBytes"))
+    cs.msToProcess = float(need("msToProcess"))
+    cs.acqSearchBand = float(need("acqSearchBand"))
+    cs.acqStep = float(need("acqStep"))
+    cs.acqThreshold = float(need("acqThreshold"))
+    cs.resamplingThreshold = float(need("resamplingThreshold"))
+    cs.resamplingflag = int(need("resamplingflag"))
+    if sig == "B1C":  # B1C/initSettings.m:60,70,102
+        cs.acqCohT = float(need("acqCohT"))
+        cs.pilotACQflag = int(need("pilotACQflag"))
+        cs.FEBW = float(need("FEBW"))
+        cs.fineNoncoh = 1
+    else:  # B2a/initSettings.m:84
+        cs.fineNoncoh = int(need("fineNoncoh"))
+        cs.acqCohT = 10.0
+        cs.pilotACQflag = 1
+        cs.FEBW = 0.0
+    sats = [int(p) for p in np.atleast_1d(need("acqSatelliteList"))]
     if len(sats) > BDS_MAX_PRN:
         raise ValueError("settings.acqSatelliteList longer than 63")
     cs.n_acq = len(sats)
     for i, p in enumerate(sats):
         cs.acqSatelliteList[i] = p
-    cs.pilotTRKflag = int(opt("pilotTRKflag", 0))
-    cs.intTime = float(opt("intTime", 0.001))
-    cs.dllCorrelatorSpacing = float(opt("dllCorrelatorSpacing", 0.5))
-    cs.dllDampingRatio = float(opt("dllDampingRatio", 0.7))
-    cs.dllNoiseBandwidth = float(opt("dllNoiseBandwidth", 1))
-    cs.pllNoiseBandwidth = float(opt("pllNoiseBandwidth", 10))
-    cs.CNoInterval = int(opt("CNoInterval", 50))
-    cs.FEBW = float(opt("FEBW", 0))
+    cs.pilotTRKflag = int(need("pilotTRKflag"))
+    cs.intTime = float(need("intTime"))
+    cs.dllCorrelatorSpacing = float(need("dllCorrelatorSpacing"))
+    cs.dllDampingRatio = float(need("dllDampingRatio"))
+    cs.dllNoiseBandwidth = float(need("dllNoiseBandwidth"))
+    cs.pllNoiseBandwidth = float(need("pllNoiseBandwidth"))
+    cs.CNoInterval = int(need("CNoInterval"))
     return cs
 
 
@@ -217,6 +238,79 @@ def sync_pattern(signal: str, prn: int = 1) -> np.ndarray:
     if rc < 0:
         raise BdsError(rc, f"bds_sync_pattern({signal}, {prn})")
     return out[:rc].copy()
+
+
+def shard_jobs(costs, world: int) -> np.ndarray:
+    """bds_shard_jobs: rank of every job (longest-processing-time rule); host side, works without a GPU."""
+    c = np.ascontiguousarray(costs, dtype=np.float64)
+    out = np.zeros(c.size, dtype=np.int32)
+    rc = lib().bds_shard_jobs(int(c.size), c.ctypes.data_as(_DP), int(world), out.ctypes.data_as(_IP))
+    if rc < 0:
+        raise BdsError(rc, "bds_shard_jobs")
+    return out
+
+
+def acq_job_cost(settings) -> float:
+    """bds_acq_job_cost: relative cost of searching one PRN with these settings."""
+    cs = pack_settings(settings)
+    return float(lib().bds_acq_job_cost(C.byref(cs)))
+
+
+class MultiContext:
+    """bds_multi: one host process driving several GPUs (device_ids None = every visible device)."""
+
+    def __init__(self, device_ids=None):
+        self._lib = lib()
+        if device_ids is None:
+            self._h = self._lib.bds_multi_create(0, None)
+        else:
+            ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+            self._h = self._lib.bds_multi_create(int(ids.size), ids.ctypes.data_as(_IP))
+        if not self._h:
+            raise BdsError(-2, self._lib.bds_multi_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bds_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self) -> int:
+        return int(self._lib.bds_multi_size(self._h))
+
+    def rccl_ranks(self) -> int:
+        return int(self._lib.bds_multi_rccl_ranks(self._h))
+
+    def acquire(self, jobs):
+        """jobs: list of (settings, int8 samples, is_complex) -- one entry per signal.
+        Returns a list of (carrFreq, codePhase, peakMetric, detected), one per signal."""
+        n = len(jobs)
+        arr = (AcqJob * n)()
+        keep, outs = [], []
+        for i, (settings, samples, is_complex) in enumerate(jobs):
+            cs = pack_settings(settings)
+            a, p = _i8(samples)
+            max_prn = max(int(q) for q in np.atleast_1d(settings.acqSatelliteList))
+            carr, cph, pm = np.zeros(max_prn), np.zeros(max_prn), np.zeros(max_prn)
+            det = np.zeros(max_prn, dtype=np.int32)
+            arr[i].settings = C.pointer(cs)
+            arr[i].samples = p
+            arr[i].n_samples = a.size // (2 if is_complex else 1)
+            arr[i].is_complex = int(bool(is_complex))
+            arr[i].max_prn = max_prn
+            arr[i].carrFreq, arr[i].codePhase, arr[i].peakMetric = (v.ctypes.data_as(_DP) for v in (carr, cph, pm))
+            arr[i].detected = det.ctypes.data_as(_IP)
+            keep.append((cs, a))
+            outs.append((carr, cph, pm, det))
+        rc = self._lib.bds_acquire_multi(self._h, n, arr)
+        if rc < 0:
+            raise BdsError(rc, self._lib.bds_multi_last_error(self._h).decode())
+        return outs
 
 
 def gen_primary_code(signal: str, kind: str, prn: int) -> np.ndarray:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Acquisition throughput benchmark (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload b1c|b2a]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload b1c|b2a|joint]
 
 A *step* is one complete acquisition pass of the hot path over one synthetic IF
 block: forward transforms of every Doppler bin, the PRN x Doppler parallel
@@ -14,10 +14,13 @@ Workload at N=1 (default): BASELINE.json configs[2] -- BDS-3 B1C full acquisitio
 IF = 14.58 MHz -- the configuration the north star quotes its roofline target on.
 ``--workload b2a`` runs configs[1] (B2a, 63 PRNs x 26 bins).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the PRN list is
-sharded round-robin over ranks; every step ends with one RCCL all-reduce(SUM) of the
-three per-PRN result vectors (3 x 63 f64), the only exchange the path has.  Total
-work is fixed, so scaling is "strong".
+``--workload joint`` runs configs[4]: the B1C and the B2a block together, 126 (signal, PRN) jobs.
+
+N > 1 (one rank per GPU under torch.distributed.run; ``--gpus N`` without a launcher
+re-executes itself under it on 127.0.0.1): the (signal, PRN) jobs are spread over the ranks by
+cost (bds_shard_jobs, longest-processing-time rule; round-robin for one signal); every
+step ends with one RCCL all-reduce(SUM) per signal of the three per-PRN result vectors
+(3 x 63 f64), the only exchange the path has.  Total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line on rank 0.
 """
@@ -128,12 +131,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="b1c", choices=["b1c", "b2a"])
+    ap.add_argument("--workload", default="b1c", choices=["b1c", "b2a", "joint"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="skip the (untimed) tracking leg")
     ap.add_argument("--prns", type=int, default=63, help="tuning only: search PRNs 1..N instead of all 63")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: become N ranks, one per GPU, over RCCL (rendezvous on 127.0.0.1)
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,15 +160,25 @@ def main():
 
     import bds_amd
 
-    s, x, sats, label = build_workload(args.workload)
-    if args.prns != 63:
-        s.acqSatelliteList = list(range(1, args.prns + 1))
-        label += f" [TUNING RUN: PRNs 1..{args.prns} only]"
+    names = ["b1c", "b2a"] if args.workload == "joint" else [args.workload]
+    sigs = []  # per signal: settings, block, injected satellites, label, this rank's PRN shard, its context
+    for nm in names:
+        s, x, sats, label = build_workload(nm)
+        if args.prns != 63:
+            s.acqSatelliteList = list(range(1, args.prns + 1))
+            label += f" [TUNING RUN: PRNs 1..{args.prns} only]"
+        sigs.append(dict(name=nm, s=s, x=x, sats=sats, label=label))
+    shards = bds_amd.shard_joint([g["s"] for g in sigs], rank, world)  # (signal, PRN) jobs of this rank, by cost
+    for k, g in enumerate(sigs):
+        g["shard"] = shards[k]
+        # one context per signal: each keeps its IF block and code spectra resident in HBM across steps
+        g["ctx"] = bds_amd.get_context(local_rank) if k == 0 else bds_amd.native.Context(local_rank)
+        if g["shard"]:
+            g["ctx"].acq_load(g["s"], g["x"])
+            g["ctx"].acq_prepare(g["s"])
+    s, x, sats, label = sigs[0]["s"], sigs[0]["x"], sigs[0]["sats"], " + ".join(g["label"] for g in sigs)
     all_prns = [int(p) for p in s.acqSatelliteList]
-    shard = all_prns[rank::world]  # PRN shard of this rank (cost per PRN is uniform)
-    ctx = bds_amd.get_context(local_rank)
-    ctx.acq_load(s, x)
-    ctx.acq_prepare(s)
+    ctx = sigs[0]["ctx"]
 
     def barrier():
         if dist is not None:
@@ -164,12 +186,20 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        carr, cph, pm, det = ctx.acq_run(s, shard)
-        if dist is not None:
-            buf = torch.from_numpy(np.stack([carr, cph, pm])).cuda()
-            dist.all_reduce(buf)  # RCCL all-reduce(SUM) of 3 x max_prn f64: x + 0 is exact
-            carr, cph, pm = buf.cpu().numpy()
-        return carr, cph, pm
+        out = []
+        for g in sigs:
+            max_prn = max(int(p) for p in g["s"].acqSatelliteList)
+            if g["shard"]:
+                carr, cph, pm, det = g["ctx"].acq_run(g["s"], g["shard"])
+                g["tim"] = g["ctx"].timing()
+            else:  # no job of this signal on this rank: zeros into the exchange
+                carr = cph = pm = np.zeros(max_prn)
+            if dist is not None:
+                buf = torch.from_numpy(np.stack([carr, cph, pm])).cuda()
+                dist.all_reduce(buf)  # RCCL all-reduce(SUM) of 3 x max_prn f64 per signal: x + 0 is exact
+                carr, cph, pm = buf.cpu().numpy()
+            out.append((carr, cph, pm))
+        return out
 
     for _ in range(args.warmup):
         step()
@@ -177,8 +207,9 @@ def main():
     t0 = time.perf_counter()
     tim = []
     for _ in range(args.steps):
-        res = step()
-        tim.append(ctx.timing())
+        res_all = step()
+        res = res_all[0]
+        tim.append(sigs[0].get("tim") or ctx.timing())
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -190,20 +221,37 @@ def main():
     n_circ, n_bins, ncomp = tm["n_circ"], tm["n_bins"], tm["n_comp"]
     p_total = len(all_prns)
     ms_per_step = dt / args.steps * 1e3
-    cell_msps = n_circ * p_total * n_bins / (dt / args.steps) / 1e6
+
+    def sizes(st):  # N (circular correlation length), Doppler bins, components of one signal's search
+        spc = int(np.floor(st.samplingFreq / (st.codeFreqBasis / st.codeLength) + 0.5))
+        if st.signal.upper() == "B1C":
+            n = int(np.floor(spc / 10 * (10 + st.acqCohT) + 0.5))
+            nc = 2 if st.pilotACQflag == 1 else 1
+        else:
+            n, nc = 2 * spc, 2
+        return n, int(np.floor(st.acqSearchBand * 2 / st.acqStep + 0.5)) + 1, nc
+
+    cell_samples = 0.0  # IF samples through (PRN, bin) cells, all signals
+    b_alg = 0.0         # algorithmic bytes of the whole job
+    for g in sigs:
+        n_g, d_g, nc_g = sizes(g["s"])
+        p_g = len(set(int(p) for p in g["s"].acqSatelliteList))
+        cell_samples += float(n_g) * p_g * d_g
+        b_alg += 9.0 * n_g * d_g + 8.0 * (1 + nc_g) * n_g * p_g * d_g
+    assert (n_circ, n_bins, ncomp) == sizes(s)
+    cell_msps = cell_samples / (dt / args.steps) / 1e6
     # algorithmic bytes: per cell 8*(1+ncomp)*N (signal + code spectra, fp32 complex);
     # per bin 9*N (int8 in, spectrum out).  One launch pair (rows+cols kernels) = cells_per_pair cells.
     pair_ms = float(np.mean([t["cell_pair_ms"] for t in tim]))
     cells_per_pair = tm["cells_per_pair"]
     bytes_per_pair = cells_per_pair * 8 * (1 + ncomp) * n_circ
     achieved = bytes_per_pair / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
-    b_alg = 9 * n_circ * n_bins + 8 * (1 + ncomp) * n_circ * p_total * n_bins
 
     # HBM traffic per launch pair: measured separately with rocprofv3 --pmc (FETCH_SIZE x2 gfx950
     # correction + WRITE_SIZE, tools/pmc_run.sh) and committed under profiles/; null if no
     # measurement exists for this workload / cells-per-pair.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{names[0]}.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if int(tj.get("cells_per_pair", -1)) == int(cells_per_pair):
@@ -226,7 +274,10 @@ def main():
                          2: "f16 search (packed v_pk_*_f16, f32 magnitudes) + f64 refinement of every candidate"}[int(tm.get("half_storage", 0))],
         "data": "synthetic",
         "config": {"workload": label, "prns": p_total, "doppler_bins": n_bins, "n_circ": n_circ,
-                   "fft_len": tm["fft_len"], "components": ncomp, "parallelism": f"prn-shard x{world}",
+                   "fft_len": tm["fft_len"], "components": ncomp,
+                   "parallelism": f"(signal, PRN) job shard x{world}, LPT by cost; one all-reduce(SUM) of 3 x 63 f64 per signal",
+                   "jobs": sum(len(set(int(p) for p in g["s"].acqSatelliteList)) for g in sigs),
+                   "jobs_rank0": {g["name"]: len(g["shard"]) for g in sigs},
                    "satellites_injected": sorted(sat.prn for sat in sats), "satellites_detected": detected},
         "block_msps": n_circ / (dt / args.steps) / 1e6,
         "whole_job_algorithmic_GBps": b_alg / (dt / args.steps) / 1e9,
@@ -241,10 +292,13 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(s, x, args.workload)
+            out["cpu_baseline"] = cpu_baseline(s, x, names[0])
         else:
             out["cpu_baseline"] = None
-        out["tracking"] = tracking_leg(args.workload, local_rank, s) if world == 1 and not args.no_tracking else None
+        out["tracking"] = tracking_leg(names[0], local_rank, s) if world == 1 and not args.no_tracking else None
+        if len(sigs) > 1:
+            out["config"]["satellites_detected_per_signal"] = {g["name"]: sorted(int(p) for p in np.nonzero(r[0])[0] + 1)
+                                                                for g, r in zip(sigs, res_all)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -13,7 +13,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden
        -Wall -Wno-unused-result -I"$ROOT/include" -I"$SRC")
 mkdir -p "$PKG/build"
 objs=()
-for f in bds_codes.cpp bds_api.hip bds_acq.hip bds_track.hip bds_sync.hip; do
+for f in bds_codes.cpp bds_api.hip bds_acq.hip bds_track.hip bds_sync.hip bds_multi.hip; do
     o="$PKG/build/${f%.*}.o"
     # rebuild when the source or any header is newer than the object
     if [ ! -f "$o" ] || [ -n "$(find "$SRC/$f" "$SRC"/*.h "$ROOT/include"/*.h -newer "$o" 2>/dev/null)" ]; then
@@ -30,5 +30,5 @@ for f in bds_codes.cpp bds_api.hip bds_acq.hip bds_track.hip bds_sync.hip; do
     fi
     objs+=("$o")
 done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT" -Wl,-rpath,/opt/rocm/lib
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT" -ldl -Wl,-rpath,/opt/rocm/lib
 echo "built $OUT"

@@ -204,6 +204,37 @@ BDS_API int bds_acq_candidates(bds_ctx *ctx, int prn, int32_t *bin, int64_t *lag
 BDS_API int bds_acq_peaks(bds_ctx *ctx, int max_prn, double *peak, double *denom, int32_t *fbin);
 BDS_API int bds_get_timing(bds_ctx *ctx, bds_timing *t);
 
+/* ---- multi-device acquisition -------------------------------------------
+ * One host process drives N GPUs: what postProcessing.m's single acquisition() call (B1C/postProcessing.m:105-111,
+ * B2a/postProcessing.m:100) becomes on a multi-GPU node.  The (signal, PRN) jobs are spread over the devices by cost
+ * (bds_shard_jobs: longest-processing-time rule; bds_acq_job_cost: transform points x Doppler bins x components of
+ * one PRN), every device searches its shard with the whole IF block, and one RCCL all-reduce(SUM) of
+ * 3 x max_prn f64 per signal over xGMI leaves the complete acqResults everywhere (x + 0: bit-identical to one
+ * device).  Several signals in one call = BASELINE.json configs[4] (B1C + B2a jointly).
+ * Tracking needs no exchange: use bds_multi_ctx(m, i) with bds_track per device (replicas / channel shards). */
+typedef struct bds_multi bds_multi;
+typedef struct bds_acq_job {
+    const bds_settings *settings; /* one receiver's settings (signal, acqSatelliteList, ...)          */
+    const int8_t *samples;        /* its IF block (host), as for bds_acquire                           */
+    size_t n_samples;
+    int32_t is_complex;
+    int32_t max_prn;              /* >= max(acqSatelliteList), <= 63                                   */
+    double *carrFreq, *codePhase, *peakMetric; /* out: double[max_prn] each                            */
+    int32_t *detected;            /* out, optional: int32[max_prn]                                     */
+} bds_acq_job;
+/* n_devices <= 0: every visible device; device_ids NULL: 0 .. n_devices-1 */
+BDS_API bds_multi *bds_multi_create(int n_devices, const int *device_ids);
+BDS_API void bds_multi_destroy(bds_multi *m);
+BDS_API const char *bds_multi_last_error(const bds_multi *m); /* m may be NULL: creation errors */
+BDS_API int bds_multi_size(const bds_multi *m);
+BDS_API bds_ctx *bds_multi_ctx(bds_multi *m, int i);
+/* communicator size RCCL reported at the last all-reduce (0: none has run) */
+BDS_API int bds_multi_rccl_ranks(const bds_multi *m);
+BDS_API int bds_acquire_multi(bds_multi *m, int n_signals, const bds_acq_job *signals);
+/* rank_of_job[j] in 0..world-1 for jobs of relative cost[j] (no GPU needed) */
+BDS_API int bds_shard_jobs(int n_jobs, const double *cost, int world, int32_t *rank_of_job);
+BDS_API double bds_acq_job_cost(const bds_settings *s);
+
 /* ---- tracking -----------------------------------------------------------------
  * [trackResults, channel] = tracking(fid, channel, settings)
  *   B2a/tracking.m:1, B1C/NB_tracking.m:1, B1C/WB_tracking.m:1

@@ -16,74 +16,105 @@
  *   [XcorrResult, index] = bds_mex('frame_sync', signal, PRN, bits)   % one channel: second half of
  *       xcorr(sign(bits), pattern) and find(abs(.) >= 1799.5) (B1C) / find(abs(.) > 115) (B2a)
  * signal: 1 = B1C, 2 = B2a (the reference keeps one directory per receiver).
+ * Acquisition uses every GPU of the node (bds_multi_create(0, NULL); BDS_MEX_DEVICES=n limits it).
+ * tests/test_mex_syntax.py compiles this file with -fsyntax-only against a header that declares the MEX API
+ * (syntax evidence only: no MATLAB exists in the build image).
  */
+#include <stdlib.h>
 #include <string.h>
 
 #include "bds_mi355x.h"
 #include "mex.h"
 
-static bds_ctx *g_ctx = NULL;
+/* One bds_multi for the MATLAB session: every visible GPU (BDS_MEX_DEVICES=n limits the count).  Acquisition
+ * goes through bds_acquire_multi (PRN shards + RCCL all-reduce inside the library); tracking, frame sync and the
+ * converters run on device 0 of it (tracking needs no exchange: replicas only). */
+static bds_multi *g_multi = NULL;
 
 static void cleanup(void) {
-    if (g_ctx) bds_destroy(g_ctx);
-    g_ctx = NULL;
+    if (g_multi) bds_multi_destroy(g_multi);
+    g_multi = NULL;
 }
 
-static bds_ctx *ctx(void) {
-    if (!g_ctx) {
-        g_ctx = bds_create(0);
-        if (!g_ctx) mexErrMsgIdAndTxt("bds:create", "%s", bds_last_error(NULL));
+static bds_multi *multi(void) {
+    if (!g_multi) {
+        const char *e = getenv("BDS_MEX_DEVICES");
+        g_multi = bds_multi_create(e ? atoi(e) : 0, NULL);
+        if (!g_multi) mexErrMsgIdAndTxt("bds:create", "%s", bds_multi_last_error(NULL));
         mexAtExit(cleanup);
     }
-    return g_ctx;
+    return g_multi;
 }
 
-static double field(const mxArray *s, const char *name, int required, double dflt) {
+static bds_ctx *ctx(void) { return bds_multi_ctx(multi(), 0); }
+
+/* Every field of SURVEY.md Appendix D that the selected receiver's initSettings.m defines is REQUIRED: a settings
+ * struct with a misspelt or missing field is an error naming the field, never a silent default. */
+static const mxArray *need(const mxArray *s, const char *name) {
     const mxArray *f = mxGetField(s, 0, name);
-    if (!f) {
-        if (required) mexErrMsgIdAndTxt("bds:settings", "settings.%s is missing", name);
-        return dflt;
-    }
+    if (!f) mexErrMsgIdAndTxt("bds:settings", "settings.%s is missing", name);
+    return f;
+}
+static double num(const mxArray *s, const char *name) {
+    const mxArray *f = need(s, name);
+    if (!(mxIsNumeric(f) || mxIsLogical(f)) || mxGetNumberOfElements(f) != 1)
+        mexErrMsgIdAndTxt("bds:settings", "settings.%s must be a numeric scalar", name);
     return mxGetScalar(f);
 }
 
 static void pack_settings(const mxArray *s, int signal, bds_settings *o) {
-    const mxArray *lst;
+    const mxArray *lst, *dt;
+    char dts[32];
+    size_t n, i;
+    const double *p;
+    if (!mxIsStruct(s)) mexErrMsgIdAndTxt("bds:settings", "settings must be a struct");
+    if (signal != BDS_SIGNAL_B1C && signal != BDS_SIGNAL_B2A) mexErrMsgIdAndTxt("bds:settings", "signal must be 1 (B1C) or 2 (B2a)");
     memset(o, 0, sizeof(*o));
     o->signal = signal;
-    o->fileType = (int)field(s, "fileType", 0, 1);
-    o->samplingFreq = field(s, "samplingFreq", 1, 0);
-    o->IF = field(s, "IF", 1, 0);
-    o->codeFreqBasis = field(s, "codeFreqBasis", 1, 0);
-    o->carrFreqBasis = field(s, "carrFreqBasis", 0, 0);
-    o->codeLength = (int)field(s, "codeLength", 1, 0);
-    o->numberOfChannels = (int)field(s, "numberOfChannels", 0, 0);
-    o->skipNumberOfBytes = (int64_t)field(s, "skipNumberOfBytes", 0, 0);
-    o->msToProcess = field(s, "msToProcess", 0, 0);
-    o->acqSearchBand = field(s, "acqSearchBand", 0, 0);
-    o->acqStep = field(s, "acqStep", 0, 1);
-    o->acqThreshold = field(s, "acqThreshold", 0, 0);
-    o->acqCohT = field(s, "acqCohT", 0, 10);
-    o->pilotACQflag = (int)field(s, "pilotACQflag", 0, 1);
-    o->fineNoncoh = (int)field(s, "fineNoncoh", 0, 15);
-    o->resamplingThreshold = field(s, "resamplingThreshold", 0, 0);
-    o->resamplingflag = (int)field(s, "resamplingflag", 0, 0);
-    lst = mxGetField(s, 0, "acqSatelliteList");
-    if (lst) {
-        size_t n = mxGetNumberOfElements(lst), i;
-        const double *p = mxGetDoubles(lst);
-        if (n > BDS_MAX_PRN) mexErrMsgIdAndTxt("bds:settings", "settings.acqSatelliteList longer than 63");
-        o->n_acq = (int)n;
-        for (i = 0; i < n; ++i) o->acqSatelliteList[i] = (int)p[i];
+    /* both receivers (B1C/initSettings.m:48-151, B2a/initSettings.m:44-130) */
+    o->fileType = (int)num(s, "fileType");
+    o->samplingFreq = num(s, "samplingFreq");
+    o->IF = num(s, "IF");
+    o->codeFreqBasis = num(s, "codeFreqBasis");
+    o->carrFreqBasis = num(s, "carrFreqBasis");
+    o->codeLength = (int)num(s, "codeLength");
+    o->numberOfChannels = (int)num(s, "numberOfChannels");
+    o->skipNumberOfBytes = (int64_t)num(s, "skipNumberOfBytes");
+    o->msToProcess = num(s, "msToProcess");
+    o->acqSearchBand = num(s, "acqSearchBand");
+    o->acqStep = num(s, "acqStep");
+    o->acqThreshold = num(s, "acqThreshold");
+    o->resamplingThreshold = num(s, "resamplingThreshold");
+    o->resamplingflag = (int)num(s, "resamplingflag");
+    o->pilotTRKflag = (int)num(s, "pilotTRKflag");
+    o->intTime = num(s, "intTime");
+    o->dllCorrelatorSpacing = num(s, "dllCorrelatorSpacing");
+    o->dllDampingRatio = num(s, "dllDampingRatio");
+    o->dllNoiseBandwidth = num(s, "dllNoiseBandwidth");
+    o->pllNoiseBandwidth = num(s, "pllNoiseBandwidth");
+    o->CNoInterval = (int)num(s, "CNoInterval");
+    /* settings.dataType: the library reads int8 ('schar') records only (tracking.m:237-238) */
+    dt = need(s, "dataType");
+    if (!mxIsChar(dt) || mxGetString(dt, dts, sizeof(dts)) || strcmp(dts, "schar"))
+        mexErrMsgIdAndTxt("bds:settings", "settings.dataType must be 'schar' (int8 samples)");
+    o->dataType = 0;
+    if (signal == BDS_SIGNAL_B1C) { /* B1C/initSettings.m:60,70,102 */
+        o->acqCohT = num(s, "acqCohT");
+        o->pilotACQflag = (int)num(s, "pilotACQflag");
+        o->FEBW = num(s, "FEBW");
+        o->fineNoncoh = 1;
+    } else { /* B2a/initSettings.m:84 */
+        o->fineNoncoh = (int)num(s, "fineNoncoh");
+        o->acqCohT = 10;
+        o->pilotACQflag = 1;
     }
-    o->pilotTRKflag = (int)field(s, "pilotTRKflag", 0, 0);
-    o->intTime = field(s, "intTime", 0, 0.001);
-    o->dllCorrelatorSpacing = field(s, "dllCorrelatorSpacing", 0, 0.5);
-    o->dllDampingRatio = field(s, "dllDampingRatio", 0, 0.7);
-    o->dllNoiseBandwidth = field(s, "dllNoiseBandwidth", 0, 1);
-    o->pllNoiseBandwidth = field(s, "pllNoiseBandwidth", 0, 10);
-    o->CNoInterval = (int)field(s, "CNoInterval", 0, 50);
-    o->FEBW = field(s, "FEBW", 0, 0);
+    lst = need(s, "acqSatelliteList");
+    if (!mxIsDouble(lst)) mexErrMsgIdAndTxt("bds:settings", "settings.acqSatelliteList must be a double row vector");
+    n = mxGetNumberOfElements(lst);
+    p = mxGetDoubles(lst);
+    if (n > BDS_MAX_PRN) mexErrMsgIdAndTxt("bds:settings", "settings.acqSatelliteList longer than 63");
+    o->n_acq = (int)n;
+    for (i = 0; i < n; ++i) o->acqSatelliteList[i] = (int)p[i];
 }
 
 static void do_acquire(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
@@ -100,9 +131,21 @@ static void do_acquire(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[
     plhs[1] = mxCreateDoubleMatrix(1, max_prn, mxREAL);
     plhs[2] = mxCreateDoubleMatrix(1, max_prn, mxREAL);
     det = mxCreateNumericMatrix(1, max_prn, mxINT32_CLASS, mxREAL);
-    rc = bds_acquire(ctx(), &s, (const int8_t *)mxGetInt8s(prhs[1]), mxGetNumberOfElements(prhs[1]) / (iq ? 2 : 1), iq, max_prn,
-                     mxGetDoubles(plhs[0]), mxGetDoubles(plhs[1]), mxGetDoubles(plhs[2]), (int32_t *)mxGetInt32s(det));
-    if (rc) mexErrMsgIdAndTxt("bds:acquire", "%s", bds_last_error(g_ctx));
+    {
+        bds_acq_job job;
+        memset(&job, 0, sizeof(job));
+        job.settings = &s;
+        job.samples = (const int8_t *)mxGetInt8s(prhs[1]);
+        job.n_samples = mxGetNumberOfElements(prhs[1]) / (iq ? 2 : 1);
+        job.is_complex = iq;
+        job.max_prn = max_prn;
+        job.carrFreq = mxGetDoubles(plhs[0]);
+        job.codePhase = mxGetDoubles(plhs[1]);
+        job.peakMetric = mxGetDoubles(plhs[2]);
+        job.detected = (int32_t *)mxGetInt32s(det);
+        rc = bds_acquire_multi(multi(), 1, &job); /* all GPUs of the session: PRN shards + one RCCL all-reduce */
+    }
+    if (rc) mexErrMsgIdAndTxt("bds:acquire", "%s", bds_multi_last_error(g_multi));
     if (nlhs > 3)
         plhs[3] = det;
     else
@@ -168,7 +211,7 @@ static void do_track(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     /* the C arrays are channel-major [n_ch][n_epochs] == MATLAB column-major [n_epochs x n_ch] */
     rc = bds_track(ctx(), &s, path, n_ch, ch, &o);
     mxFree(ch);
-    if (rc) mexErrMsgIdAndTxt("bds:track", "%s", bds_last_error(g_ctx));
+    if (rc) mexErrMsgIdAndTxt("bds:track", "%s", bds_last_error(ctx()));
     plhs[0] = st;
 }
 
@@ -199,7 +242,7 @@ static void do_frame_sync(int nlhs, mxArray *plhs[], int nrhs, const mxArray *pr
     xc = (int32_t *)mxCalloc((size_t)M, sizeof(int32_t));
     idx = (int32_t *)mxCalloc((size_t)M, sizeof(int32_t));
     total = bds_frame_sync(ctx(), signal, 1, &prn, mxGetDoubles(prhs[3]), n, xc, idx, &cnt, M);
-    if (total < 0) mexErrMsgIdAndTxt("bds:frame_sync", "%s", bds_last_error(g_ctx));
+    if (total < 0) mexErrMsgIdAndTxt("bds:frame_sync", "%s", bds_last_error(ctx()));
     plhs[0] = mxCreateDoubleMatrix(1, M, mxREAL);
     p = mxGetDoubles(plhs[0]);
     for (i = 0; i < M; ++i) p[i] = xc[i];

@@ -143,3 +143,24 @@ def test_unsupported_branches_are_reported():
     assert lib.bds_gen_code(1, 2, 64, None, 0) < 0
     out = np.zeros(10, dtype=np.int8)
     assert lib.bds_gen_code(2, 4, 1, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)), 10) < 0  # BOC61 is B1C only
+
+
+def test_settings_fields_are_required_not_defaulted():
+    """a settings struct with a missing (or misspelt) field is an error naming the
+    field -- for the fields of the selected receiver only (B2a has no acqCohT, B1C no fineNoncoh)."""
+    import pytest
+
+    s2, s1 = bds_amd.init_settings_b2a(), bds_amd.init_settings_b1c()
+    native.pack_settings(s2), native.pack_settings(s1)
+    for s, fields in ((s2, ("dllNoiseBandwidth", "acqSearchBand", "fineNoncoh", "dataType", "carrFreqBasis", "CNoInterval")),
+                      (s1, ("acqCohT", "pilotACQflag", "FEBW", "pllNoiseBandwidth", "resamplingflag", "skipNumberOfBytes"))):
+        for f in fields:
+            d = dict(s.__dict__)
+            d.pop(f)
+            d[f + "x"] = 1  # the misspelt twin
+            with pytest.raises(AttributeError, match=f"settings.{f} is missing"):
+                native.pack_settings(bds_amd.Settings(**d))
+    # fields of the OTHER receiver are not required
+    d = dict(s2.__dict__)
+    assert "acqCohT" not in d and "FEBW" not in d
+    assert native.pack_settings(s2.copy(dataType="int16")).dataType == 1  # rejected by the library (BDS_ERR_UNSUPPORTED)

@@ -214,3 +214,10 @@ def test_every_specialised_plan_pair(ctx, monkeypatch, l1):
         assert got.carrFreq[18] != 0
     monkeypatch.delenv("BDS_ACQ_FORCE_L1L2")
     ctx.reload_tuning()
+
+
+def test_data_type_other_than_schar_is_rejected(ctx):
+    """settings.dataType (fread(fid, ..., settings.dataType), B2a/tracking.m:237-238): only int8 records."""
+    s, x, _ = cfg1_b2a()
+    with pytest.raises(bds_amd.native.BdsError, match="dataType"):
+        bds_amd.acquisition(x, s.copy(dataType="int16"), verbose=False)

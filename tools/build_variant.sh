@@ -8,7 +8,7 @@ mkdir -p "$ROOT/tools/variants"
 O="$ROOT/tools/variants/bds_acq_$1.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-result -I"$ROOT/include" -I"$PKG/csrc" \
     -ffp-contract=fast -fno-slp-vectorize $2 -c "$PKG/csrc/bds_acq.hip" -o "$O"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$PKG/build/bds_codes.o" "$PKG/build/bds_api.o" "$O" "$PKG/build/bds_track.o" "$PKG/build/bds_sync.o" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$PKG/build/bds_codes.o" "$PKG/build/bds_api.o" "$O" "$PKG/build/bds_track.o" "$PKG/build/bds_sync.o" "$PKG/build/bds_multi.o" -ldl \
     -o "$ROOT/tools/variants/libbds_$1.so" -Wl,-rpath,/opt/rocm/lib
 rm -f "$O"
 echo "built variant $1"
