@@ -59,6 +59,7 @@ Tuning tuning_from_env() {
     t.test_force_fallback = has("BDS_ACQ_TEST_FORCE_FALLBACK");
     t.verbose = has("BDS_VERBOSE");
     t.multi_force_rccl = has("BDS_MULTI_FORCE_RCCL");
+    t.trk_nblocks = std::max(0, geti("BDS_TRK_NBLOCKS", 0));
     t.trk_chunk = std::max(0, geti("BDS_TRK_CHUNK", 0));
     return t;
 }

@@ -48,6 +48,7 @@ struct Tuning {
     bool test_force_fallback = false;   // BDS_ACQ_TEST_FORCE_FALLBACK: test hook, take the fp16 -> fp32 storage re-run
     bool verbose = false;            // BDS_VERBOSE
     bool multi_force_rccl = false;      // BDS_MULTI_FORCE_RCCL: a single-device bds_multi still goes through RCCL (test hook)
+    int trk_nblocks = 0;                // BDS_TRK_NBLOCKS: test hook, correlate workgroups per channel (0 = sized from the code rate)
     int trk_chunk = 0;               // BDS_TRK_CHUNK: samples per correlate workgroup (0 = per-mode default)
 };
 Tuning tuning_from_env();

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 
 #include "bds_internal.h"
 
@@ -39,7 +40,8 @@ struct ChanState {
     double codeFreqBasis;  // channel.codeFreq (tracking.m:389)
     long long pos;         // sample offset of the next read: ftell / dataAdaptCoeff (tracking.m:226)
     int prn;               // 0 = channel unused
-    int active;            // 1 while the channel keeps tracking
+    int active;            // 1 while the channel keeps tracking; 0 stopped at a short read (end of file);
+                           // -2 its reads left the loaded window of the record (the host reloads the whole file)
     int completed;         // epochs finished
     int pad;
 };
@@ -55,6 +57,8 @@ struct TrkParams {
     double spacing;  // dllCorrelatorSpacing (earlyLateSpc)
     double tau1, tau2, pdi, pf1, pf2, pf3, factor;
     long long n_bytes;  // samples in the record: file bytes / dataAdaptCoeff
+    long long base;     // first sample of the record held in HBM (only the window the channels can touch is loaded)
+    long long win_end;  // one past the last sample held
 };
 
 struct TrkOut {  // device arrays [n_ch][n_epochs]
@@ -106,7 +110,7 @@ __device__ __forceinline__ EpochGeom epoch_geom(const ChanState &s, const TrkPar
 template <int MODE>
 __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data, const int8_t *__restrict__ prim_d,
                                                 const int8_t *__restrict__ prim_p, const TrkParams &p,
-                                                const EpochGeom &g, long k0, long k1, bool pilot, double *sums) {
+                                                const EpochGeom &g, long k0_first, long k_stride, bool pilot, double *sums) {
     constexpr double scale = MODE == BDS_TRACK_B2A ? 1.0 : 2.0;
     constexpr int UNITS = MODE == BDS_TRACK_B2A ? 1 : 2;
     const int NU = UNITS * p.code_len;
@@ -125,14 +129,19 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
         sincospi(2.0 * (dcyc - floor(dcyc)), &wi, &wr);
     }
     int it = 0;
+    const int8_t *__restrict__ dwin = data - (p.base * (p.cplx ? 2 : 1));  // data[] starts at sample p.base of the record
+    // chunk k0 .. k0+chunk of the block, then (only when blksize outgrew the grid the call was sized for:
+    // a code rate more than 2 % below the slowest channel's initial one) every k_stride-th chunk after it
+    for (long k0 = k0_first; k0 < g.blk; k0 += k_stride) {
+    const long k1 = min(g.blk, k0 + p.chunk);
     for (int k = (int)k0 + (int)threadIdx.x; k < (int)k1; k += (int)blockDim.x) {  // blksize < 2^31
         float raw, raw_q = 0.f;
         if (p.cplx) {  // rawSignal = data(1:2:end) + 1i*data(2:2:end)  (tracking.m:242-246)
-            const char2 v = reinterpret_cast<const char2 *>(data)[g.pos + k];
+            const char2 v = reinterpret_cast<const char2 *>(dwin)[g.pos + k];
             raw = (float)v.x;
             raw_q = (float)v.y;
         } else {
-            raw = (float)data[g.pos + k];
+            raw = (float)dwin[g.pos + k];
         }
         const double kd = (double)k;
         const double te = st_e + kd * inc, tl = st_l + kd * inc, tp = st_p + kd * inc;
@@ -188,6 +197,7 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
             }
         }
     }
+    }
     // wave reduction (f64 from here), then one LDS hop
     __shared__ double s_part[kTrkThreads / 64][kNSums];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -214,17 +224,17 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__r
     const int ch = blockIdx.y;
     const ChanState s = st[ch];
     double *out = part + ((long)ch * nblocks + blockIdx.x) * kNSums;
-    if (!s.active) return;
+    if (s.active != 1) return;
     const EpochGeom g = epoch_geom(s, p);
     const long k0 = (long)blockIdx.x * p.chunk;
-    if (k0 >= g.blk || g.pos + g.blk > p.n_bytes) {  // beyond the block, or short read (update kernel aborts)
+    // beyond the block; short read (the update kernel stops the channel); outside the loaded window (it flags it)
+    if (k0 >= g.blk || g.pos + g.blk > p.n_bytes || g.pos < p.base || g.pos + g.blk > p.win_end) {
         if (threadIdx.x < kNSums) out[threadIdx.x] = 0.0;
         return;
     }
-    const long k1 = min(g.blk, k0 + p.chunk);
     const int8_t *pd = prim + ((long)(s.prn - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
     const int8_t *pp = prim + ((long)(s.prn - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
-    correlate_slice<MODE>(data, pd, pp, p, g, k0, k1, p.pilot != 0, out);
+    correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
 }
 
 // Open-loop variant: geometry supplied by the caller (bds_track_correlate).
@@ -249,10 +259,9 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t
         if (threadIdx.x < kNSums) out[threadIdx.x] = 0.0;
         return;
     }
-    const long k1 = min(g.blk, k0 + p.chunk);
     const int8_t *pd = prim + ((long)(prn[ch] - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
     const int8_t *pp = prim + ((long)(prn[ch] - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
-    correlate_slice<MODE>(data, pd, pp, p, g, k0, k1, p.pilot != 0, out);
+    correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
 }
 
 __global__ void k_trk_reduce_open(const double *__restrict__ part, int nblocks, double *__restrict__ sums) {
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(kUpdThreads) void k_trk_update(TrkParams p, ChanSta
     __shared__ double s_sum[kNSums];
     __shared__ double s_grp[kUpdGroups][kNSums];
     ChanState s = st[ch];
-    if (!s.active) return;
+    if (s.active != 1) return;
     const EpochGeom g = epoch_geom(s, p);
     // fixed-order two-level sum over the correlate workgroups (bit-stable from run to run): group j
     // takes workgroups j, j+14, ...; the 14 group sums are then added in order.  (A single thread per
@@ -298,8 +307,15 @@ __global__ __launch_bounds__(kUpdThreads) void k_trk_update(TrkParams p, ChanSta
     __syncthreads();
     if (threadIdx.x != 0) return;
     const long e = (long)ch * p.n_epochs + epoch;
+    if (g.pos + g.blk <= p.n_bytes && (g.pos < p.base || g.pos + g.blk > p.win_end)) {
+        // inside the file but outside the part of it that was loaded: nothing of this epoch is valid;
+        // the host repeats the call with the whole record in HBM
+        s.active = -2;
+        st[ch] = s;
+        return;
+    }
     o.absoluteSample[e] = (double)s.pos;  // tracking.m:226 (assigned before the read)
-    if (g.pos + g.blk > p.n_bytes || g.blk > (long)nblocks * p.chunk) {
+    if (g.pos + g.blk > p.n_bytes) {
         // short read: message + return in the reference (tracking.m:250-254); partial results stay
         s.active = 0;
         st[ch] = s;
@@ -417,6 +433,7 @@ __global__ __launch_bounds__(kUpdThreads) void k_trk_update(TrkParams p, ChanSta
 struct TrackState {
     int8_t *d_data = nullptr;
     size_t data_cap = 0;
+    size_t loaded_bytes = 0;  // bytes of the record the last call copied to HBM (diagnostics)
     int8_t *d_prim = nullptr;
     int prim_signal = 0;
 };
@@ -593,8 +610,12 @@ __global__ __launch_bounds__(256) void k_trk_cno(TrkOut o, const ChanState *__re
     }
 }
 
-static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_bytes, size_t n_bytes, bool on_device,
-                    int n_ch, const bds_channel *channel, bds_track_out *out) {
+// Source of the IF record: copies bytes [off, off + n) of the file into device memory at dst.
+using RecordLoader = std::function<int(size_t off, size_t n, int8_t *dst)>;
+
+// whole_file: load every byte (second attempt after a channel's reads left the window of the first)
+static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &load, size_t n_bytes, int n_ch,
+                    const bds_channel *channel, bds_track_out *out, bool whole_file = false) {
     if (!ctx || !s || !channel || !out) return BDS_ERR_ARG;
     if (n_ch < 1 || out->n_ch != n_ch || out->n_epochs < 1) return fail(ctx, BDS_ERR_ARG, "bds_track: n_ch / n_epochs mismatch");
     if (!out->completed || !out->status || !out->absoluteSample || !out->I_P || !out->Q_P)
@@ -607,15 +628,6 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_byte
     int rc = fill_params(ctx, *s, p, n_epochs, n_bytes);
     if (rc) return rc;
     if ((rc = ensure_prim(ctx, t, s->signal))) return rc;
-    if (!on_device) {
-        if (t.data_cap < n_bytes) {
-            if (t.d_data) (void)hipFree(t.d_data), t.d_data = nullptr, t.data_cap = 0;
-            hipError_t e = hipMalloc((void **)&t.d_data, std::max<size_t>(n_bytes, 1));
-            if (e != hipSuccess) return fail(ctx, BDS_ERR_NOMEM, "IF record of %zu bytes does not fit in HBM: %s", n_bytes, hipGetErrorString(e));
-            t.data_cap = n_bytes;
-        }
-        BDS_HIP(ctx, hipMemcpyAsync(t.d_data, file_bytes, n_bytes, hipMemcpyHostToDevice, st(ctx)));
-    }
     // channel state (tracking.m:170-188)
     std::vector<ChanState> hs((size_t)n_ch);
     const double max_step_inv = 0;
@@ -637,9 +649,39 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_byte
         if (!(cs.codeFreq > 0)) return fail(ctx, BDS_ERR_ARG, "channel(%d).codeFreq must be > 0", c + 1);
         min_code_freq = std::min(min_code_freq, cs.codeFreq);
     }
-    // correlate grid: blksize stays near codeLength*fs/codeFreq; allow +-2 % code-rate excursions
+    // correlate grid: blksize stays near codeLength*fs/codeFreq; sized for code rates down to 2 % below the slowest
+    // channel's (a longer block is walked by the same workgroups in further strides)
     long max_blk = (long)std::ceil((double)s->codeLength / ((min_code_freq < 1e299 ? min_code_freq : s->codeFreqBasis) * 0.98 / s->samplingFreq)) + 2;
-    const int nblocks = (int)((max_blk + p.chunk - 1) / p.chunk);
+    const int nblocks = ctx->tune.trk_nblocks > 0 ? ctx->tune.trk_nblocks : (int)((max_blk + p.chunk - 1) / p.chunk);
+    // Only the part of the record the channels can touch goes to HBM: from the earliest start sample to the latest
+    // start + n_epochs blocks at a code rate 2 % low (the reference streams blksize samples per epoch with fread,
+    // tracking.m:237-240; a recording is usually far longer than msToProcess).  End-of-file is still judged against
+    // the real file size (p.n_bytes).
+    {
+        const long long coeff = p.cplx ? 2 : 1;
+        long long first = p.n_bytes, last = 0;
+        for (int c = 0; c < n_ch; ++c) {
+            if (!hs[c].active) continue;
+            const long blk_c = (long)std::ceil((double)s->codeLength / (hs[c].codeFreq * 0.98 / s->samplingFreq)) + 2;
+            first = std::min(first, hs[c].pos);
+            last = std::max(last, hs[c].pos + (long long)n_epochs * blk_c);
+        }
+        if (whole_file || first > last) first = 0, last = p.n_bytes;
+        first = std::max(0LL, std::min(first, p.n_bytes));
+        last = std::max(first, std::min(last, p.n_bytes));
+        p.base = first;
+        p.win_end = last;
+        const size_t wbytes = (size_t)((last - first) * coeff);
+        if (t.data_cap < wbytes || !t.d_data) {
+            if (t.d_data) (void)hipFree(t.d_data), t.d_data = nullptr, t.data_cap = 0;
+            hipError_t e = hipMalloc((void **)&t.d_data, std::max<size_t>(wbytes, 1));
+            if (e != hipSuccess)
+                return fail(ctx, BDS_ERR_NOMEM, "IF record window of %zu bytes does not fit in HBM: %s", wbytes, hipGetErrorString(e));
+            t.data_cap = std::max<size_t>(wbytes, 1);
+        }
+        if (wbytes && (rc = load((size_t)(first * coeff), wbytes, t.d_data))) return rc;
+        t.loaded_bytes = wbytes;
+    }
     // per-call device buffers, released on every exit path
     struct DevScope {
         std::vector<void *> p;
@@ -683,7 +725,7 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_byte
     BDS_HIP(ctx, hipEventCreate(&ev0));
     BDS_HIP(ctx, hipEventCreate(&ev1));
     BDS_HIP(ctx, hipEventRecord(ev0, st(ctx)));
-    const int8_t *data = on_device ? file_bytes : t.d_data;
+    const int8_t *data = t.d_data;
     dim3 gc(nblocks, n_ch);
     for (int k = 0; k < n_epochs; ++k) {
         switch (p.mode) {
@@ -712,6 +754,11 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const int8_t *file_byte
     ctx->timing.n_pairs = n_epochs;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
+    for (int c = 0; c < n_ch; ++c)
+        if (hs[c].active == -2) {  // a channel read past the loaded window (code rate > 2 % low): redo with the whole record
+            if (whole_file) return fail(ctx, BDS_ERR_HIP, "bds_track: channel %d left the loaded record", c + 1);
+            return do_track(ctx, s, load, n_bytes, n_ch, channel, out, true);
+        }
 
     // The reference tracks channels one after another and returns at the first short read
     // (tracking.m:250-254): that channel keeps its partial results, later ones are never started.
@@ -773,8 +820,12 @@ using namespace bds;
 
 extern "C" int bds_track_mem(bds_ctx *ctx, const bds_settings *s, const int8_t *file_bytes, size_t n_bytes, int n_ch,
                              const bds_channel *channel, bds_track_out *out) {
-    if (!file_bytes) return BDS_ERR_ARG;
-    return do_track(ctx, s, file_bytes, n_bytes, false, n_ch, channel, out);
+    if (!ctx || !file_bytes) return BDS_ERR_ARG;
+    const RecordLoader load = [&](size_t off, size_t n, int8_t *dst) -> int {
+        BDS_HIP(ctx, hipMemcpyAsync(dst, file_bytes + off, n, hipMemcpyHostToDevice, (hipStream_t)ctx->stream));
+        return BDS_OK;
+    };
+    return do_track(ctx, s, load, n_bytes, n_ch, channel, out);
 }
 
 extern "C" int bds_track(bds_ctx *ctx, const bds_settings *s, const char *path, int n_ch, const bds_channel *channel,
@@ -782,51 +833,39 @@ extern "C" int bds_track(bds_ctx *ctx, const bds_settings *s, const char *path, 
     if (!ctx || !path) return BDS_ERR_ARG;
     FILE *f = fopen(path, "rb");
     if (!f) return fail(ctx, BDS_ERR_IO, "Unable to read file %s", path);  // postProcessing.m:152-154
-    fseek(f, 0, SEEK_END);
-    const long long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    if (sz <= 0) {
-        fclose(f);
-        return fail(ctx, BDS_ERR_IO, "file %s is empty", path);
-    }
-    // stage through pinned memory in 256 MiB pieces straight into HBM
+    struct Closer {
+        FILE *f;
+        void *pin = nullptr;
+        ~Closer() {
+            fclose(f);
+            if (pin) (void)hipHostFree(pin);
+        }
+    } guard{f};
+    fseeko(f, 0, SEEK_END);
+    const long long sz = ftello(f);
+    if (sz <= 0) return fail(ctx, BDS_ERR_IO, "file %s is empty", path);
     BDS_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->trk) ctx->trk = new TrackState();
-    TrackState &t = *ctx->trk;
-    if (t.data_cap < (size_t)sz) {
-        if (t.d_data) (void)hipFree(t.d_data), t.d_data = nullptr, t.data_cap = 0;
-        hipError_t e = hipMalloc((void **)&t.d_data, (size_t)sz);
-        if (e != hipSuccess) {
-            fclose(f);
-            return fail(ctx, BDS_ERR_NOMEM, "IF record of %lld bytes does not fit in HBM: %s", sz, hipGetErrorString(e));
-        }
-        t.data_cap = (size_t)sz;
-    }
+    // the window of the record the channels can touch, staged through pinned memory in 256 MiB pieces
     const size_t piece = 256u << 20;
-    void *pin = nullptr;
-    if (hipHostMalloc(&pin, std::min<size_t>(piece, (size_t)sz), 0) != hipSuccess) {
-        fclose(f);
-        return fail(ctx, BDS_ERR_NOMEM, "pinned staging buffer");
-    }
-    size_t off = 0;
-    while (off < (size_t)sz) {
-        const size_t n = std::min(piece, (size_t)sz - off);
-        if (fread(pin, 1, n, f) != n) {
-            fclose(f);
-            (void)hipHostFree(pin);
-            return fail(ctx, BDS_ERR_IO, "short read on %s", path);
+    const RecordLoader load = [&](size_t off, size_t n, int8_t *dst) -> int {
+        if (!guard.pin && hipHostMalloc(&guard.pin, std::min<size_t>(piece, (size_t)sz), 0) != hipSuccess)
+            return fail(ctx, BDS_ERR_NOMEM, "pinned staging buffer");
+        if (fseeko(f, (off_t)off, SEEK_SET)) return fail(ctx, BDS_ERR_IO, "seek in %s failed", path);
+        size_t done = 0;
+        while (done < n) {
+            const size_t m = std::min(piece, n - done);
+            if (fread(guard.pin, 1, m, f) != m) return fail(ctx, BDS_ERR_IO, "short read on %s", path);
+            const hipError_t e = hipMemcpy(dst + done, guard.pin, m, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return fail(ctx, BDS_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+            done += m;
         }
-        hipError_t e = hipMemcpy(t.d_data + off, pin, n, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            fclose(f);
-            (void)hipHostFree(pin);
-            return fail(ctx, BDS_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
-        }
-        off += n;
-    }
-    fclose(f);
-    (void)hipHostFree(pin);
-    return do_track(ctx, s, t.d_data, (size_t)sz, true, n_ch, channel, out);
+        return BDS_OK;
+    };
+    return do_track(ctx, s, load, (size_t)sz, n_ch, channel, out);
+}
+
+extern "C" long long bds_track_loaded_bytes(bds_ctx *ctx) {
+    return (ctx && ctx->trk) ? (long long)ctx->trk->loaded_bytes : 0;
 }
 
 extern "C" int bds_track_correlate(bds_ctx *ctx, const bds_settings *s, const int8_t *file_bytes, size_t n_bytes,

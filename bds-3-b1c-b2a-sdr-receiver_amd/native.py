@@ -81,7 +81,7 @@ class AcqJob(C.Structure):
 EXPORTS = [
     "bds_create", "bds_destroy", "bds_reload_tuning", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_gen_code", "bds_acquire",
     "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_acq_candidates", "bds_get_timing",
-    "bds_track", "bds_track_mem", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
+    "bds_track", "bds_track_mem", "bds_track_loaded_bytes", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
     "bds_calc_weighing_factor", "bds_pre_run",
     "bds_multi_create", "bds_multi_destroy", "bds_multi_last_error", "bds_multi_size", "bds_multi_ctx",
     "bds_multi_rccl_ranks", "bds_acquire_multi", "bds_shard_jobs", "bds_acq_job_cost",
@@ -111,6 +111,7 @@ def lib():
     L.bds_create.restype, L.bds_create.argtypes = vp, [i32]
     L.bds_destroy.restype, L.bds_destroy.argtypes = None, [vp]
     L.bds_reload_tuning.restype, L.bds_reload_tuning.argtypes = i32, [vp]
+    L.bds_track_loaded_bytes.restype, L.bds_track_loaded_bytes.argtypes = C.c_longlong, [vp]
     L.bds_multi_create.restype, L.bds_multi_create.argtypes = vp, [i32, _IP]
     L.bds_multi_destroy.restype, L.bds_multi_destroy.argtypes = None, [vp]
     L.bds_multi_last_error.restype, L.bds_multi_last_error.argtypes = C.c_char_p, [vp]
@@ -489,6 +490,10 @@ class Context:
         arrays["completed"] = completed
         arrays["status"] = status
         return arrays
+
+    def track_loaded_bytes(self) -> int:
+        """Bytes of the record the last track() call copied to HBM (the window the channels can touch)."""
+        return int(self._lib.bds_track_loaded_bytes(self._h))
 
     def track_correlate(self, settings, file_bytes, prns, state6):
         cs = pack_settings(settings)

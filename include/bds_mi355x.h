@@ -250,6 +250,10 @@ BDS_API int bds_track(bds_ctx *ctx, const bds_settings *s, const char *path, int
 BDS_API int bds_track_mem(bds_ctx *ctx, const bds_settings *s, const int8_t *file_bytes,
                           size_t n_bytes, int n_ch, const bds_channel *channel,
                           bds_track_out *out);
+/* Bytes of the IF record the last bds_track / bds_track_mem call copied to HBM: only the window the channels can
+ * touch (earliest start sample .. latest start + msToProcess at a code rate 2 % low) is loaded, so a recording far
+ * longer than msToProcess (or than HBM) tracks fine; end-of-file is still judged against the real file size. */
+BDS_API long long bds_track_loaded_bytes(bds_ctx *ctx);
 /* Open-loop check entry: one correlate-and-dump epoch per channel with the caller's
  * NCO state (no loop update).  state: per channel {sample offset (0-based), blksize,
  * remCodePhase, codeFreq, remCarrPhase, carrFreq}; sums: [n_ch][18] raw correlator

@@ -93,3 +93,71 @@ def test_all_channels_idle(ctx):
         np.testing.assert_array_equal(g.I_P, r.I_P)
         np.testing.assert_array_equal(g.carrFreq, r.carrFreq)
         np.testing.assert_array_equal(g.absoluteSample, r.absoluteSample)
+
+
+@pytest.mark.parametrize("signal,mode", [("B2A", "B2A"), ("B1C", "NB")])
+def test_tracking_without_pilot(ctx, signal, mode):
+    """pilotTRKflag = 0: data-only discriminators, and the Pilot_* / PilotCNo / *_CNo fields are not created at all
+    (B2a/tracking.m:70-73,89-93; NB_tracking.m:78-81,98-102)."""
+    s, x, chans = track_case(signal, mode, 16)
+    s = s.copy(pilotTRKflag=0)
+    ref, _ = otrk.tracking(otrk.RawFile(x), chans, s, mode=mode)
+    got, _ = bds_amd.tracking(x, chans, s, mode=mode)
+    for r, g in zip(ref, got):
+        assert g.status == r.status == "T"
+        assert not hasattr(g, "Pilot_I_P") and not hasattr(r, "Pilot_I_P") and not hasattr(g, "PilotCNo")
+        np.testing.assert_array_equal(g.absoluteSample, r.absoluteSample)
+        p = np.hypot(r.I_P, r.Q_P).max()
+        for f in ("I_E", "I_P", "I_L", "Q_E", "Q_P", "Q_L"):
+            np.testing.assert_allclose(getattr(g, f), getattr(r, f), rtol=0, atol=1e-4 * p, err_msg=f)
+        np.testing.assert_allclose(g.carrFreq, r.carrFreq, rtol=0, atol=1e-3)
+        np.testing.assert_allclose(g.codeFreq, r.codeFreq, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(g.DataCNo, r.DataCNo, rtol=0, atol=1e-3)
+
+
+def test_only_the_window_of_a_long_record_is_loaded(ctx, tmp_path):
+    """The reference streams blksize samples per epoch (tracking.m:237-240); here only the window the channels can
+    touch goes to HBM, so a recording much longer than msToProcess costs nothing extra -- and skipNumberOfBytes moves
+    the window.  Results equal those on the short record; end of file is still the real end of the file."""
+    n_epochs = 20
+    s, x, chans = track_case("B2A", "B2A", n_epochs)
+    spc = 25000
+    rng = np.random.default_rng(9)
+    junk = lambda n: np.clip(np.rint(rng.normal(0, 20, n)), -127, 127).astype(np.int8)  # noqa: E731
+    skip = 7 * spc
+    long_rec = np.concatenate([junk(skip), x, junk(60 * spc)])
+    want, _ = bds_amd.tracking(x, chans, s, mode="B2A")
+    assert ctx.track_loaded_bytes() <= x.size
+    s_long = s.copy(skipNumberOfBytes=skip)
+    path = tmp_path / "long_record.bin"
+    long_rec.tofile(path)
+    for source in (long_rec, str(path)):
+        got, _ = bds_amd.tracking(source, chans, s_long, mode="B2A")
+        assert ctx.track_loaded_bytes() < 0.45 * long_rec.size  # ~ (n_epochs + delays) code periods of 90
+        for g, w in zip(got, want):
+            assert g.status == "T"
+            np.testing.assert_array_equal(g.absoluteSample, w.absoluteSample + skip)  # ftell-based offsets are absolute
+            for f in ("I_P", "Q_P", "carrFreq", "codeFreq", "remCodePhase", "DataCNo"):
+                np.testing.assert_array_equal(getattr(g, f), getattr(w, f), err_msg=f)
+
+
+def test_block_longer_than_the_correlate_grid(ctx, monkeypatch):
+    """The correlate grid is sized from the slowest channel's code rate; a block that outgrows it (a diverging DLL, an
+    odd channel.codeFreq) is walked by the same workgroups in further strides instead of being mistaken for a short
+    read.  Forced here with one workgroup per channel (test hook): results must not change."""
+    s, x, chans = track_case("B1C", "WB", 6)
+    want, _ = bds_amd.tracking(x, chans, s, mode="WB")
+    monkeypatch.setenv("BDS_TRK_NBLOCKS", "2")
+    ctx.reload_tuning()
+    try:
+        got, _ = bds_amd.tracking(x, chans, s, mode="WB")
+    finally:
+        monkeypatch.delenv("BDS_TRK_NBLOCKS")
+        ctx.reload_tuning()
+    for g, w in zip(got, want):
+        assert g.status == "T"
+        np.testing.assert_array_equal(g.absoluteSample, w.absoluteSample)
+        p = np.hypot(w.I_P, w.Q_P).max()
+        for f in ("I_P", "Q_P", "Pilot_I_P", "Pilot_Q_E"):  # fp32 partial sums over more samples per thread: 1e-6 of |P|
+            np.testing.assert_allclose(getattr(g, f), getattr(w, f), rtol=0, atol=2e-6 * p, err_msg=f)
+        np.testing.assert_allclose(g.carrFreq, w.carrFreq, rtol=0, atol=1e-4)
