@@ -97,23 +97,40 @@ def cpu_baseline(s, x, name, budget_s=20.0):
 def tracking_leg(name, local_rank, base):
     """Second half of the hot path, reported beside the headline metric (not part of `value`):
     closed-loop tracking of 12 channels at 99.375 MS/s on a synthetic int8 record resident in HBM
-    (BASELINE.json configs[3] shape, shortened): B1C wide-band, 10-ms epochs / B2a, 1-ms epochs."""
+    (BASELINE.json configs[3] shape, shortened): B1C wide-band, 10-ms epochs / B2a, 1-ms epochs.
+    The record carries the 12 satellites, so the loops LOCK: one block of whole code periods (Dopplers on the
+    fs / block grid: whole carrier cycles per block) is generated and repeated to the record's length."""
     from types import SimpleNamespace
 
     import bds_amd
+    from bds_amd import synth
 
     # same front end as the acquisition workload (fs = 99.375 MS/s)
     if name == "b1c":
-        epochs, mode = 60, "WB"
+        epochs, mode, periods = 60, "WB", 2
         s = base.copy(msToProcess=epochs * 10, numberOfChannels=12, pilotTRKflag=2)
+        dopplers = [-1500, -1000, -750, -500, -250, -100, 100, 250, 500, 750, 1000, 1500]  # 50-Hz grid (20-ms block)
+        macs = 2 + 2 * 9
     else:
-        epochs, mode = 600, "B2A"
+        epochs, mode, periods = 600, "B2A", 20
         s = base.copy(msToProcess=epochs, numberOfChannels=12)
+        # B2a/tracking.m has no code-rate aiding: its DLL only holds small Dopplers (tests/golden/make_long_tracking.py)
+        dopplers = [-100, -100, -50, -50, -50, 0, 0, 50, 50, 50, 100, 100]  # 50-Hz grid (20-ms block)
+        macs = 2 + 2 * 6
     spc = int(np.floor(s.samplingFreq / (s.codeFreqBasis / s.codeLength) + 0.5))
     rng = np.random.default_rng(1)
-    x = np.clip(np.rint(rng.normal(0, 20, (epochs + 2) * spc)), -127, 127).astype(np.int8)
-    ch = [SimpleNamespace(PRN=p, acquiredFreq=s.IF + 100.0 * i, codePhase=float(1000 * i + 1), codeFreq=s.codeFreqBasis,
-                          status="T") for i, p in enumerate(range(1, 13))]
+    prns = list(range(1, 13))
+    sats = [synth.Sat(p, float(d), float(rng.uniform(0.2, 0.8)), float(rng.uniform(0, 2 * np.pi)), 47.0) for p, d in zip(prns, dopplers)]
+    block = synth.make_if(s, sats, periods * spc, seed=7)
+    shift = 12345
+    n = (epochs + 3) * spc + shift
+    x = np.tile(np.roll(block, shift), -(-n // block.size))[:n]
+    ch = []
+    for sat in sats:
+        cf = s.IF + round(sat.doppler / 25) * 25
+        code_freq = s.codeFreqBasis - (cf - s.IF) / s.carrFreqBasis * s.codeFreqBasis if name == "b1c" else s.codeFreqBasis
+        ch.append(SimpleNamespace(PRN=sat.prn, acquiredFreq=float(cf), codePhase=float(shift + int(np.ceil(sat.delay)) + 1),
+                                  codeFreq=float(code_freq), status="T"))
     ctx = bds_amd.get_context(local_rank)
     bds_amd.tracking(x, ch, s, mode=mode)  # warm-up (H2D, code tables)
     res, _ = bds_amd.tracking(x, ch, s, mode=mode)
@@ -121,9 +138,15 @@ def tracking_leg(name, local_rank, base):
     samples = float(sum(np.diff(r.absoluteSample).sum() + spc for r in res))
     epoch_s = 0.010 if name == "b1c" else 0.001
     assert all(r.completed == epochs for r in res), [r.completed for r in res]
+    half = epochs // 2
+    locked = sum(bool(np.abs(r.I_P[half:]).mean() > 3 * np.abs(r.Q_P[half:]).mean()) for r in res)
     return {"mode": mode, "channels": 12, "epochs": epochs, "fs_MHz": s.samplingFreq / 1e6, "ms_per_epoch": dev_ms / epochs,
             "channel_Msamples_per_s": samples / dev_ms / 1e3, "x_realtime_12ch": epoch_s * epochs / (dev_ms * 1e-3),
-            "note": "device time of the epoch loop (two dependent launches per epoch, record in HBM); noise-only record"}
+            "int8_read_GBps": samples / (dev_ms * 1e-3) / 1e9,  # one byte per sample per channel (algorithmic)
+            "correlator_GMACs": samples * macs / (dev_ms * 1e-3) / 1e9, "macs_per_sample": macs,
+            "channels_locked": locked,
+            "note": "device time of the epoch loop (two dependent launches per epoch, record window in HBM); locked synthetic record "
+                    "(12 satellites at 47 dB-Hz, one block of whole code periods repeated)"}
 
 
 def main():

@@ -221,3 +221,38 @@ def test_data_type_other_than_schar_is_rejected(ctx):
     s, x, _ = cfg1_b2a()
     with pytest.raises(bds_amd.native.BdsError, match="dataType"):
         bds_amd.acquisition(x, s.copy(dataType="int16"), verbose=False)
+
+
+def test_b1c_guard_moves_a_late_twin_peak_back(ctx):
+    """B1C/acquisition.m:239-241: the 20-ms circular correlation has twin peaks one code period apart; when the
+    maximum is the LATE twin and its code period would run past the end of longSignal, codePhase is moved back by
+    samplesPerCode.  longSignal of 2*spc + 20 samples, seed chosen (with the oracle) so that the late twin wins."""
+    from bds_amd import synth
+    from helpers import spc_of
+
+    s = bds_amd.init_settings_b1c(samplingFreq=5e6, IF=1.2e6, acqSatelliteList=[7], acqSearchBand=100, acqStep=50)
+    spc = spc_of(s)
+    x = synth.make_if(s, [synth.Sat(7, 40.0, 0.55 * spc, 1.0, 47.0)], 2 * spc + 20, seed=3)
+    ref = oacq.acquisition_b1c(x.astype(np.float64), s)
+    got = bds_amd.acquisition(x, s, verbose=False)
+    assert ref.codePhase[6] == 27502  # the early twin's position ...
+    lags = ctx.acq_candidates(7)[:, 1]
+    assert 27502 + spc in lags  # ... although the search maximum sits one code period later: the guard fired
+    np.testing.assert_array_equal(got.codePhase, ref.codePhase)
+    np.testing.assert_array_equal(got.carrFreq, ref.carrFreq)
+    np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6)
+
+
+def test_fine_search_carrier_of_exactly_zero_becomes_one(ctx):
+    """acquisition.m:303-305 (B2a :333-335): carrFreq == 0 would read as "not detected", so it is stored as 1."""
+    from bds_amd import synth
+    from helpers import spc_of
+
+    s = bds_amd.init_settings_b1c(samplingFreq=5e6, IF=25.0, acqSatelliteList=[7], acqSearchBand=100, acqStep=50)
+    spc = spc_of(s)
+    x = synth.make_if(s, [synth.Sat(7, -25.0, 0.3 * spc, 0.4, 50.0)], 3 * spc, seed=4)  # carrier at 0 Hz
+    ref = oacq.acquisition_b1c(x.astype(np.float64), s)
+    got = bds_amd.acquisition(x, s, verbose=False)
+    assert ref.carrFreq[6] == 1.0 and got.carrFreq[6] == 1.0
+    np.testing.assert_array_equal(got.codePhase, ref.codePhase)
+    np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6)
