@@ -57,7 +57,8 @@ def test_full_horizon_closed_loop(ctx, name):
             want = z[f][c].astype(np.float64)  # stored as float32: 6e-8 of their magnitude, far inside the tolerances
             np.testing.assert_allclose(getattr(g, f)[:k], want[:k], rtol=0, atol=1e-4 * p, err_msg=f)
             np.testing.assert_allclose(getattr(g, f), want, rtol=0, atol=1e-2 * p, err_msg=f)
-        for f, tight, floor in (("carrFreq", 1e-3, 0.06), ("codeFreq", 1e-6, 0.02), ("remCodePhase", 1e-7, 5e-4), ("remCarrPhase", 1e-6, 5e-3)):
+        # (remCarrPhase: 2 pi x carrFreq tolerance x 10 ms = 6e-5 rad)
+        for f, tight, floor in (("carrFreq", 1e-3, 0.06), ("codeFreq", 1e-6, 0.02), ("remCodePhase", 1e-7, 5e-4), ("remCarrPhase", 1e-4, 5e-3)):
             np.testing.assert_allclose(getattr(g, f)[:k], z[f][c][:k], rtol=0, atol=tight, err_msg=f)
             np.testing.assert_allclose(getattr(g, f), z[f][c], rtol=0, atol=floor, err_msg=f)
         sig = "B2a_CNo" if mode == "B2A" else "B1C_CNo"
