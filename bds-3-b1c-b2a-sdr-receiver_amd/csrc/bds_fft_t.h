@@ -40,7 +40,10 @@ __host__ __device__ constexpr float stage_scale(int R) { return R == 16 ? 0.25f 
 // Twiddles: fp32 -- tw is the LDS copy of the W_S table (physical layout), the power-of-two
 // multiples are fetched and the rest built as products; fp16 -- tw is the LDS copy of the
 // per-stage tables [R][NS] (q-major) at offset TWOFF, already in the transform direction and pre-scaled.
-template <class C, int S, int T, int NT, int DIR, int NS, int R, int TWOFF, class Src, class Dst>
+// JFAST: butterfly slot b -> (transform j = b % T, butterfly bb = b / T) instead of (j = b / NB, bb = b % NB):
+// adjacent lanes then work on ADJACENT transforms (columns), which is what a first stage fed straight from a
+// row-major global tile wants (T must be a power of two).
+template <class C, int S, int T, int NT, int DIR, int NS, int R, int TWOFF, class Src, class Dst, bool JFAST = false>
 __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict__ tw, int tid, Src src, Dst dst) {
     constexpr int NB = S / R;
     constexpr int TOTAL = NB * T;
@@ -62,7 +65,7 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
     for (int i = 0; i < MB; ++i) {
         const int b = tid + i * NT;
         if (FULL || b < TOTAL) {
-            const int j = b / NB, bb = b - j * NB;
+            const int j = JFAST ? b % T : b / NB, bb = JFAST ? b / T : b - (b / NB) * NB;
             if constexpr (SRC_LDS) {
                 const C *sp = buf + j * SP + bb + (bb >> 4);
 #pragma unroll
@@ -148,21 +151,21 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
-template <class C, int S, int T, int NT, int DIR, int NS, int TWOFF, class Src, class Dst, class Hook, int R, int... REST>
+template <class C, int S, int T, int NT, int DIR, int NS, int TWOFF, bool JFAST, class Src, class Dst, class Hook, int R, int... REST>
 __device__ __forceinline__ void tfft_run(C *__restrict__ buf, const C *__restrict__ tw, int tid, Src src, Dst dst, Hook hook) {
     if constexpr (sizeof...(REST) == 0) {
-        tstage<C, S, T, NT, DIR, NS, R, TWOFF>(buf, tw, tid, src, dst);
+        tstage<C, S, T, NT, DIR, NS, R, TWOFF, Src, Dst, JFAST>(buf, tw, tid, src, dst);
         hook();
     } else {
-        tstage<C, S, T, NT, DIR, NS, R, TWOFF>(buf, tw, tid, src, LdsIO{});
+        tstage<C, S, T, NT, DIR, NS, R, TWOFF, Src, LdsIO, JFAST>(buf, tw, tid, src, LdsIO{});
         hook();
-        tfft_run<C, S, T, NT, DIR, NS * R, TWOFF + (NS > 1 ? NS * R : 0), LdsIO, Dst, NoHook, REST...>(buf, tw, tid, LdsIO{}, dst, NoHook{});
+        tfft_run<C, S, T, NT, DIR, NS * R, TWOFF + (NS > 1 ? NS * R : 0), false, LdsIO, Dst, NoHook, REST...>(buf, tw, tid, LdsIO{}, dst, NoHook{});
     }
 }
 
-// Entries of the W_S table a length-S plan can touch: all-16/8 plans only reach the first half.
+// Entries of the W_S table a length-S plan can touch (defined after the plans: the largest index any stage forms).
 template <int S>
-__host__ __device__ constexpr int twiddle_entries() { return (S == 256 || S == 2048 || S == 4096) ? S / 2 : S; }
+__host__ __device__ constexpr int twiddle_entries();
 
 // Cooperative copy of the twiddle table into LDS (visible after the caller's next barrier).
 template <int S, int NT>
@@ -183,11 +186,16 @@ struct TPlan;
     struct TPlan<S_> {                                                                             \
         template <int T, int NT, int DIR, class C, class Src, class Dst>                           \
         __device__ __forceinline__ static void run(C *buf, const C *tw, int tid, Src src, Dst dst) { \
-            tfft_run<C, S_, T, NT, DIR, 1, 0, Src, Dst, NoHook, __VA_ARGS__>(buf, tw, tid, src, dst, NoHook{}); \
+            tfft_run<C, S_, T, NT, DIR, 1, 0, false, Src, Dst, NoHook, __VA_ARGS__>(buf, tw, tid, src, dst, NoHook{}); \
+        }                                                                                          \
+        /* first stage with adjacent lanes on adjacent transforms (tstage JFAST) */                \
+        template <int T, int NT, int DIR, class C, class Src, class Dst, class Hook>               \
+        __device__ __forceinline__ static void run_jfast(C *buf, const C *tw, int tid, Src src, Dst dst, Hook hook) { \
+            tfft_run<C, S_, T, NT, DIR, 1, 0, true, Src, Dst, Hook, __VA_ARGS__>(buf, tw, tid, src, dst, hook); \
         }                                                                                          \
         template <int T, int NT, int DIR, class C, class Src, class Dst, class Hook>               \
         __device__ __forceinline__ static void run_hook(C *buf, const C *tw, int tid, Src src, Dst dst, Hook hook) { \
-            tfft_run<C, S_, T, NT, DIR, 1, 0, Src, Dst, Hook, __VA_ARGS__>(buf, tw, tid, src, dst, hook); \
+            tfft_run<C, S_, T, NT, DIR, 1, 0, false, Src, Dst, Hook, __VA_ARGS__>(buf, tw, tid, src, dst, hook); \
         }                                                                                          \
         static constexpr int kRadix[] = {__VA_ARGS__};                                             \
     };
@@ -200,6 +208,23 @@ BDS_TPLAN(2048, 16, 16, 8)
 BDS_TPLAN(3072, 16, 16, 4, 3)
 BDS_TPLAN(4096, 16, 16, 16)
 #undef BDS_TPLAN
+
+// A stage of radix R behind NS points reads W_S^(m k TWS), k < NS, TWS = S / (NS R), with m up to 8 (radix 16:
+// the power-of-two multiples), 4 (radix 8) or R - 1 (the other radices): the table only needs the entries up to
+// the largest such index (768 = 16 16 3: 511 of 768 entries; all-16/8 plans: under half).
+template <int S>
+__host__ __device__ constexpr int twiddle_entries() {
+    int ns = 1, top = 0;
+    for (int r : TPlan<S>::kRadix) {
+        if (ns > 1) {
+            const int m = r == 16 ? 8 : r == 8 ? 4 : r - 1;
+            const int idx = m * (ns - 1) * (S / (ns * r));
+            top = idx > top ? idx : top;
+        }
+        ns *= r;
+    }
+    return top + 1;
+}
 
 template <int S>
 __host__ __device__ constexpr int half_table_entries() {

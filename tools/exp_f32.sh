@@ -13,11 +13,4 @@ for l in sys.stdin:
 " "$*"
 }
 run BDS_X=0
-run BDS_LIB_PATH=tools/variants/libbds_occ2.so
-run BDS_LIB_PATH=tools/variants/libbds_occ2.so BDS_ACQ_ROWS_GRID=512
-run BDS_LIB_PATH=tools/variants/libbds_occ2.so BDS_ACQ_OVERLAP=1 BDS_ACQ_ROWS_GRID=256
-run BDS_LIB_PATH=tools/variants/libbds_occ2.so BDS_ACQ_OVERLAP=1 BDS_ACQ_ROWS_GRID=512
-run BDS_LIB_PATH=tools/variants/libbds_occ2.so BDS_ACQ_OVERLAP=1 BDS_ACQ_ROWS_GRID=512 BDS_ACQ_LOGT=2
-run BDS_ACQ_OVERLAP=1 BDS_ACQ_ROWS_GRID=512
-run BDS_ACQ_OVERLAP=1 BDS_ACQ_ROWS_GRID=768
-run BDS_ACQ_OVERLAP=1 BDS_ACQ_ROWS_GRID=512 BDS_ACQ_GROUP=67
+run BDS_LIB_PATH=tools/variants/libbds_lean3.so
