@@ -149,6 +149,31 @@ def tracking_leg(name, local_rank, base):
                     "(12 satellites at 47 dB-Hz, one block of whole code periods repeated)"}
 
 
+def fast_path_leg(local_rank, s, x, n_cells_samples):
+    """Extra key, never `value`: the same call with the opt-in packed-fp16 search arithmetic (BDS_ACQ_HMATH=1; the f64
+    refinement still decides every result).  Narrower arithmetic than the reference's, so it earns no headline."""
+    import bds_amd
+
+    os.environ["BDS_ACQ_HMATH"] = "1"
+    try:
+        c = bds_amd.native.Context(local_rank)  # the knobs are read once, at context creation
+    finally:
+        del os.environ["BDS_ACQ_HMATH"]
+    try:
+        c.acq_load(s, x)
+        c.acq_prepare(s)
+        c.acq_run(s)
+        t0 = time.perf_counter()
+        c.acq_run(s)
+        dt = time.perf_counter() - t0
+        tm = c.timing()
+    finally:
+        c.close()
+    return {"dtype": "f16", "half_storage": int(tm["half_storage"]), "ms_per_step": dt * 1e3, "value": n_cells_samples / dt / 1e6,
+            "unit": "Msamples/s", "pair_ms": tm["cell_pair_ms"],
+            "note": "packed v_pk_*_f16 search arithmetic + f64 refinement; NOT the headline (narrower than the reference's single/double)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +182,7 @@ def main():
     ap.add_argument("--workload", default="b1c", choices=["b1c", "b2a", "joint"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="skip the (untimed) tracking leg")
+    ap.add_argument("--no-fast-path", action="store_true", help="skip the extra (never the headline) packed-fp16 sieve timing")
     ap.add_argument("--prns", type=int, default=63, help="tuning only: search PRNs 1..N instead of all 63")
     args = ap.parse_args()
 
@@ -319,6 +345,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["tracking"] = tracking_leg(names[0], local_rank, s) if world == 1 and not args.no_tracking else None
+        out["fast_path"] = (fast_path_leg(local_rank, s, x, float(n_circ) * p_total * n_bins)
+                            if world == 1 and len(sigs) == 1 and not args.no_fast_path else None)
         if len(sigs) > 1:
             out["config"]["satellites_detected_per_signal"] = {g["name"]: sorted(int(p) for p in np.nonzero(r[0])[0] + 1)
                                                                 for g, r in zip(sigs, res_all)}

@@ -6,7 +6,7 @@ P=${PRNS:-6}
 W=${WORKLOAD:-b1c}
 for m in "BDS_X=0" "BDS_ACQ_FP16=0" "BDS_ACQ_HMATH=1"; do
   echo "== mode: $m $*"
-  env $m "$@" timeout 600 python bench.py --workload $W --prns $P --steps 2 --warmup 1 --no-cpu-baseline --no-tracking 2>&1 | python -c "
+  env $m "$@" timeout 600 python bench.py --workload $W --prns $P --steps 2 --warmup 1 --no-cpu-baseline --no-tracking --no-fast-path 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""profiles/traffic_<workload>.json from a PMC summary (tools/pmc_run.sh -> gpurun_out/pmc_summary.txt): HBM bytes of one
+launch pair (row pass + column pass of the default fp32-arithmetic search kernels) = FETCH_SIZE x 2 (gfx950: the
+counter tallies 128-B requests as 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, averaged per dispatch.
+    python tools/make_traffic.py gpurun_out/pmc_summary.txt b1c 201 profiles/r02_b1c_pmc.txt
+"""
+import json
+import re
+import shutil
+import sys
+
+src, workload, cells, keep = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+txt = open(src).read()
+blocks = {b.split("\n")[0]: b for b in re.split(r"^== ", txt, flags=re.M) if b.strip()}
+
+
+def counters(prefix):
+    for name, b in blocks.items():
+        if name.startswith(prefix):
+            d = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+([\d.]+)", b, re.M)}
+            return name, d
+    raise SystemExit(f"no kernel {prefix} in {src}")
+
+
+rn, r = counters("k_rows_inv_f")
+cn, c = counters("k_cols_inv_max_f")
+total = 1024.0 * (2 * r["FETCH_SIZE"] + r["WRITE_SIZE"] + 2 * c["FETCH_SIZE"] + c["WRITE_SIZE"])
+out = {"workload": workload, "cells_per_pair": cells, "bytes_per_pair": total,
+       "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_run.sh), avg per dispatch of {rn} + {cn} "
+                 f"(one dispatch pair = {cells} (PRN, bin) cells); FETCH_SIZE doubled per the gfx950 correction "
+                 f"(MI355X_MICROARCH.md, HBM); see {keep}",
+       "rows": {"FETCH_SIZE_KiB": r["FETCH_SIZE"], "WRITE_SIZE_KiB": r["WRITE_SIZE"], "duration_us": r["~duration_ns"] / 1e3},
+       "cols": {"FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"], "duration_us": c["~duration_ns"] / 1e3},
+       "per_cell_MB": total / cells / 1e6}
+json.dump(out, open(f"profiles/traffic_{workload}.json", "w"), indent=1)
+shutil.copy(src, keep)
+print(json.dumps(out, indent=1))
