@@ -8,7 +8,7 @@
 //   k_trk_correlate  grid (blocks, channels): every block re-derives the epoch geometry
 //                    (blksize, code / carrier NCO start values) from the channel's f64 loop
 //                    state, walks its slice of the block of samples and emits 6/12/18 partial
-//                    correlator sums (per-thread fp32 over <= 16 samples, f64 from there on;
+//                    correlator sums (per-thread fp32 over <= 32 samples, f64 from there on;
 //                    wave reduction by DPP shuffles, one LDS hop per workgroup)
 //   k_trk_update     one workgroup per channel: fixed-order sum of the partials, the
 //                    discriminators and loop filters in f64 exactly in the reference's
