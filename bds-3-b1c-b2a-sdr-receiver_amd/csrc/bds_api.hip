@@ -51,7 +51,6 @@ Tuning tuning_from_env() {
     t.fuse = has("BDS_ACQ_FUSE");
     t.nofuse = has("BDS_ACQ_NOFUSE");
     t.fchunk = std::max(1, geti("BDS_ACQ_FCHUNK", 2));
-    t.rows_occ2 = geti("BDS_ACQ_ROWS_OCC2", 0);
     t.rows_grid = std::max(0, geti("BDS_ACQ_ROWS_GRID", 0));
     t.overlap = has("BDS_ACQ_OVERLAP");
     if (const char *e = std::getenv("BDS_ACQ_KDELTA")) t.kdelta = std::max(0.0, std::min(0.9, std::atof(e)));

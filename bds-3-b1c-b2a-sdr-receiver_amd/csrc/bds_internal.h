@@ -40,7 +40,6 @@ struct Tuning {
     double pbcap_gb = 8.0;           // BDS_ACQ_PBCAP_GB
     bool fuse = false, nofuse = false;  // BDS_ACQ_FUSE / BDS_ACQ_NOFUSE (fp16-arithmetic kernels only)
     int fchunk = 2;                  // BDS_ACQ_FCHUNK
-    int rows_occ2 = 0;               // BDS_ACQ_ROWS_OCC2: row pass built for 2 waves per SIMD (256 VGPRs)
     int rows_grid = 0;                  // BDS_ACQ_ROWS_GRID: workgroups of the (then persistent) row pass; 0 = one per item
     bool overlap = false;               // BDS_ACQ_OVERLAP: column pass of group k on a second stream beside the row pass of group k+1
     double kdelta = 0;                  // BDS_ACQ_KDELTA: test hook, sieve tolerance override (0 = per-mode default)
