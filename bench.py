@@ -201,11 +201,19 @@ def main():
     import torch
 
     dist = None
+    xdev = "cuda"  # where the exchanged tensors live
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("BDS_BENCH_TEST_ONE_DEVICE"):
+            # test hook (tests/test_bench_gpu.py): every rank on device 0 of a one-GPU box, exchange over gloo --
+            # exercises the launcher, the job shards and the exchange; RCCL refuses two ranks on one device
+            local_rank, xdev = 0, "cpu"
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import bds_amd
 
@@ -244,7 +252,7 @@ def main():
             else:  # no job of this signal on this rank: zeros into the exchange
                 carr = cph = pm = np.zeros(max_prn)
             if dist is not None:
-                buf = torch.from_numpy(np.stack([carr, cph, pm])).cuda()
+                buf = torch.from_numpy(np.stack([carr, cph, pm])).to(xdev)
                 dist.all_reduce(buf)  # RCCL all-reduce(SUM) of 3 x max_prn f64 per signal: x + 0 is exact
                 carr, cph, pm = buf.cpu().numpy()
             out.append((carr, cph, pm))
@@ -262,7 +270,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -1,0 +1,62 @@
+"""bench.py end to end: the one JSON line of the contract at N = 1, and the N > 1 path (self-spawn under
+torch.distributed.run, (signal, PRN) job shards, one exchange per signal, max-over-ranks timing) with two ranks
+sharing the one GPU of the test box over gloo (BDS_BENCH_TEST_ONE_DEVICE: RCCL refuses two ranks on one device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+FAST = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-tracking", "--no-fast-path"]
+
+
+def run_bench(args, extra_env=None, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env,
+                       cwd=ROOT, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def check_line(d, n_gpus, prns=63):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["unit"] == "Msamples/s" and d["value"] > 0 and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert d["config"]["satellites_detected"] == [p for p in d["config"]["satellites_injected"] if p <= prns]
+
+
+def test_bench_line_single():
+    d = run_bench(["--workload", "b2a"] + FAST)
+    check_line(d, 1)
+    assert d["config"]["jobs_rank0"] == {"b2a": 63}
+
+
+def test_bench_two_ranks_self_spawn():
+    one = run_bench(["--workload", "b2a"] + FAST)
+    two = run_bench(["--workload", "b2a", "--gpus", "2"] + FAST, {"BDS_BENCH_TEST_ONE_DEVICE": "1"})
+    check_line(two, 2)
+    assert 0 < two["config"]["jobs_rank0"]["b2a"] < 63 and two["config"]["jobs"] == 63
+    assert two["config"]["satellites_detected"] == one["config"]["satellites_detected"]
+    assert two["cpu_baseline"] is None  # rank 0 at N = 1 only
+
+
+def test_bench_joint_two_ranks():
+    d = run_bench(["--workload", "joint", "--gpus", "2", "--prns", "6"] + FAST, {"BDS_BENCH_TEST_ONE_DEVICE": "1"})
+    check_line(d, 2, prns=6)
+    assert d["config"]["jobs"] == 12
+    per = d["config"]["satellites_detected_per_signal"]
+    assert set(per) == {"b1c", "b2a"}
