@@ -393,8 +393,11 @@ __global__ __launch_bounds__(rows_threads<S>(), BDS_EXP_ROWS_OCC) void k_rows_in
     }
 }
 
+#ifndef BDS_COLS_MINW
+#define BDS_COLS_MINW 4
+#endif
 template <int S, int T, int NCOMP, bool MASKED, class ST>
-__global__ __launch_bounds__((cols_threads<S, T>()), 4) void k_cols_inv_max_f(ColsFArgs A) {
+__global__ __launch_bounds__((cols_threads<S, T>()), BDS_COLS_MINW) void k_cols_inv_max_f(ColsFArgs A) {
     cols_inv_max_f_body<S, T, NCOMP, MASKED, ST>(A, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)threadIdx.x);
 }
 

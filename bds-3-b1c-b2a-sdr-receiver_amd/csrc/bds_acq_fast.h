@@ -23,13 +23,16 @@ __device__ __forceinline__ void st_c(__half2 *p, long i, float2 v) { p[i] = __fl
 
 template <int S>
 __host__ __device__ constexpr int rows_threads() { return S / 16 < 64 ? 64 : ((S / 16 + 63) / 64) * 64; }
+#ifndef BDS_COLS768X8_NT
+#define BDS_COLS768X8_NT 512
+#endif
 template <int S, int T>
 __host__ __device__ constexpr int cols_threads() {
     // 16 points per thread; 768 x 4 takes 256 so that its radix-3 stage (256 butterflies per column)
     // maps one column per unroll step with no index arithmetic (the radix-16 stages idle one wave)
     // (768 x 8 likewise takes 512: three items per thread, the occupancy of the 4-column kernel, and two
     // adjacent lanes share each 32-byte piece of a tile row)
-    if (S == 768) return T == 4 ? 256 : 512;
+    if (S == 768) return T == 4 ? 256 : BDS_COLS768X8_NT;
     return S * T / 16;
 }
 
