@@ -60,6 +60,7 @@ Tuning tuning_from_env() {
     t.multi_force_rccl = has("BDS_MULTI_FORCE_RCCL");
     t.trk_nblocks = std::max(0, geti("BDS_TRK_NBLOCKS", 0));
     t.trk_chunk = std::max(0, geti("BDS_TRK_CHUNK", 0));
+    t.trk_persample = has("BDS_TRK_PERSAMPLE");
     return t;
 }
 

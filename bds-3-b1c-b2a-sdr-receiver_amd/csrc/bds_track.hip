@@ -32,6 +32,7 @@ namespace bds {
 // 1-ms B2a epochs (measured on 12 channels at 99.375 MS/s, us per epoch: B1C WB 148 / 93 / 84 / 82 and
 // B2a 23.3 / 20.2 / 21.7 / 29.7 at 1024 / 2048 / 4096 / 8192)
 static constexpr int kTrkThreads = 256;
+static constexpr size_t kDataSlack = 256;  // bytes past the record a segment's aligned dword reads may touch
 static constexpr int kNSums = 18;      // I_E,Q_E,I_P,Q_P,I_L,Q_L x {data, pilot BOC11 / B2a pilot, pilot BOC61}
 
 struct ChanState {
@@ -51,6 +52,7 @@ struct TrkParams {
     int pilot;       // pilot correlators on
     int cplx;        // fileType 2: the record is interleaved I/Q int8 pairs (tracking.m:132-136,242-246)
     int chunk;       // samples per correlate workgroup
+    int runs;        // 1: run-based correlator (correlate_runs), chunk = kTrkThreads * 8 or * 16
     int code_len;    // 10230
     int n_epochs;
     double fs, inv_fs;
@@ -215,6 +217,325 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
     }
 }
 
+
+// ---- run-based correlator ---------------------------------------------------------------------
+// The replica codes are piecewise constant: at 99.375 MS/s a BOC(1,1) half-chip lasts 48.6 samples,
+// a BOC(6,1) twelfth 8.1, a B2a chip 9.7.  With S(k) = the running sum of the carrier-wiped samples,
+//     sum_k x[k] c[idx(k)]  =  c[idx(last)] S(end)  -  sum over index steps u (c[u] - c[u-1]) S(k_u),
+// k_u = the first sample whose index reaches u.  The per-sample index of the reference,
+// ceil(fl(st + fl(k inc))) (x 6 for BOC(6,1), WB_tracking.m:298), is monotone in k, so k_u is found
+// from a division and confirmed with the reference's own expression on k_u - 1 and k_u: every sample gets
+// exactly the index the per-sample evaluation gives it, at two exact evaluations per code unit instead
+// of one per sample and replica.
+//   phase 1  thread t wipes the carrier off SEG consecutive samples (per-thread f64 phasor x a table
+//            of the SEG per-sample rotations), writes the exclusive fp32 prefix sums of its segment to
+//            LDS; the segment totals are scanned in f64 over the workgroup (segment bases)
+//   phase 2  the index steps of the six (E/P/L x {code, BOC(6,1)}) sequences are spread over the
+//            threads; each finds its k_u, reads S(k_u) = base + local prefix and adds its term in f64
+static constexpr int kCap1 = 256, kCap6 = 1280;  // code / BOC(6,1) table entries of a wave's pass staged in LDS
+template <int R6>
+__device__ __forceinline__ double code_arg(double st, double inc, int k) {
+    double v = st + (double)k * inc;  // two roundings (-ffp-contract=off), as the reference's colon vector
+    if (R6) v = v * 6;
+    return v;
+}
+template <int R6>
+__device__ __forceinline__ int code_idx(double st, double inc, int k) { return (int)ceil(code_arg<R6>(st, inc, k)); }
+
+// first k in (k_lo, k_hi] with ceil(arg(k)) >= u, given ceil(arg(k_lo)) < u <= ceil(arg(k_hi))
+template <int R6>
+__device__ __forceinline__ int first_sample_of(double st, double inc, double inv_inc, int u, int k_lo, int k_hi) {
+    const double thr = (double)(u - 1);  // ceil(v) >= u  <=>  v > u - 1
+    const double tgt = R6 ? thr * (1.0 / 6.0) : thr;  // a prediction only: confirmed below with the exact expression
+    int kc = (int)floor((tgt - st) * inv_inc) + 1;
+    kc = max(k_lo + 1, min(kc, k_hi));
+    while (kc > k_lo + 1 && code_arg<R6>(st, inc, kc - 1) > thr) --kc;
+    while (kc < k_hi && !(code_arg<R6>(st, inc, kc) > thr)) ++kc;
+    return kc;
+}
+
+// LDS of one wave of correlate_runs<., SEG>: prefix sums, segment bases, rotation table, code-table slices
+__host__ __device__ constexpr size_t runs_wave_lds(int seg) {
+    return (size_t)(64 * seg + 64) * 8 + 64 * 16 + (size_t)seg * 8 + (size_t)kCap1 * 2 + kCap6;
+}
+static inline size_t runs_lds_bytes(int seg) {
+    return std::max<size_t>(runs_wave_lds(seg) * (kTrkThreads / 64), sizeof(double) * (kTrkThreads / 64) * kNSums);
+}
+__device__ __forceinline__ void wave_sync() {  // LDS written by this wave is read by other lanes of this wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 64-lane inclusive f64 add-scan on the DPP network (row shifts inside the 16-lane rows, then the row
+// broadcasts): 3 instructions per step instead of two LDS-pipe permutes; lane 63 ends up with the total
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, BOUND);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, BOUND);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_scan_incl(double v) {
+    v += dpp_f64<0x111, 0xf, true>(v);   // row_shr:1
+    v += dpp_f64<0x112, 0xf, true>(v);   // row_shr:2
+    v += dpp_f64<0x114, 0xf, true>(v);   // row_shr:4
+    v += dpp_f64<0x118, 0xf, true>(v);   // row_shr:8
+    v += dpp_f64<0x142, 0xa, false>(v);  // row_bcast:15 into rows 1, 3
+    v += dpp_f64<0x143, 0xc, false>(v);  // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ double lane_f64(double v, int l) {  // broadcast of lane l (compile-time constant)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// The waves of a workgroup work independently (wave w on samples k0 + w 64 SEG .. of each chunk, its own LDS
+// slice, no workgroup barrier before the final reduction): the kernel is bound by latency -- HBM reads,
+// dependent f64 evaluations -- and independent waves hide it where barrier-separated phases cannot.
+template <int MODE, int SEG>
+__device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, const int8_t *__restrict__ prim_d,
+                                               const int8_t *__restrict__ prim_p, const TrkParams &p,
+                                               const EpochGeom &g, long k0_first, long k_stride, bool pilot, double *sums) {
+    constexpr int NT = kTrkThreads, NW = NT / 64, WCH = 64 * SEG;
+    constexpr double scale = MODE == BDS_TRACK_B2A ? 1.0 : 2.0;
+    constexpr int UNITS = MODE == BDS_TRACK_B2A ? 1 : 2;
+    constexpr int NWD = SEG / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char trk_lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned char *wl = trk_lds + runs_wave_lds(SEG) * wave;
+    float2 *s_loc = reinterpret_cast<float2 *>(wl);                                 // [WCH + 64]: position i at i + i / SEG
+    double2 *s_base = reinterpret_cast<double2 *>(wl + (size_t)(WCH + 64) * 8);     // [64] segment bases
+    float2 *s_w = reinterpret_cast<float2 *>(wl + (size_t)(WCH + 64) * 8 + 64 * 16);  // [SEG]
+    char2 *s_t1 = reinterpret_cast<char2 *>(wl + (size_t)(WCH + 64) * 8 + 64 * 16 + (size_t)SEG * 8);  // [kCap1]
+    int8_t *s_t6 = reinterpret_cast<int8_t *>(s_t1 + kCap1);                                            // [kCap6]
+    const int NU = UNITS * p.code_len, n6 = 12 * p.code_len;
+    const double inc = g.step * scale, inv_inc = 1.0 / inc;
+    const double st3[3] = {(g.rem - p.spacing) * scale, g.rem * scale, (g.rem + p.spacing) * scale};  // E, P, L
+    const double two_pi = 6.283185307179586476925286766559;
+    const double cyc0 = g.remCarr / two_pi;
+    const int coeff = p.cplx ? 2 : 1;
+    const int nwd = p.cplx ? 2 * NWD : NWD;
+    const int8_t *__restrict__ dwin = data - p.base * coeff;
+    double acc[kNSums];
+#pragma unroll
+    for (int i = 0; i < kNSums; ++i) acc[i] = 0.0;
+    if (lane < SEG) {  // rotation of sample j of a segment against its first sample
+        const double cyc = g.carrFreq * ((double)lane * p.inv_fs);
+        double sn, cs;
+        sincospi(2.0 * (cyc - floor(cyc)), &sn, &cs);
+        s_w[lane] = make_float2((float)cs, (float)sn);
+    }
+    // the segment's bytes (I/Q pairs: 2 SEG bytes), whole aligned dwords around it
+    uint32_t raw[2 * NWD + 1];
+    auto fetch = [&](long kw) {
+        const long kb = kw + (long)lane * SEG;
+        if (kb < g.blk) {
+            const uintptr_t a = (uintptr_t)(dwin + (g.pos + kb) * coeff);
+            const uint32_t *__restrict__ q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+#pragma unroll
+            for (int i = 0; i <= 2 * NWD; ++i) raw[i] = i <= nwd ? q[i] : 0u;
+        }
+    };
+    const long kw_first = k0_first + (long)wave * WCH;
+    if (kw_first < g.blk) fetch(kw_first);
+    // carrier at this lane's first sample of the first pass (tracking.m:303-304); every further pass is k_stride
+    // samples on: one f64 rotation instead of a sincospi per pass
+    double bs, bc, rs, rc;
+    {
+        const double cyc = g.carrFreq * ((double)(kw_first + (long)lane * SEG) * p.inv_fs) + cyc0;
+        sincospi(2.0 * (cyc - floor(cyc)), &bs, &bc);
+        const double cyr = g.carrFreq * ((double)k_stride * p.inv_fs);
+        sincospi(2.0 * (cyr - floor(cyr)), &rs, &rc);
+    }
+    for (long kwl = kw_first; kwl < g.blk; kwl += k_stride) {
+        const int k0 = (int)kwl, k1 = (int)min(g.blk, kwl + WCH);  // blksize < 2^31
+        wave_sync();  // s_w written / the previous pass's phase 2 done with the LDS slice
+        // ---- index ranges of this pass's E/P/L replicas and their slice of the code tables (phase 2 then reads LDS
+        // instead of issuing dependent global loads; longer ranges -- low sampling rates -- stay in global memory)
+        int ua1[3], ub1[3], ua6[3], ub6[3];
+        {  // the twelve range ends are wave-uniform: lane 3 e + ph (+ 6 for BOC(6,1)) evaluates one, readlane spreads them
+            const int ph = lane % 3, end = (lane / 3) & 1, r6 = (lane / 6) & 1;
+            const double stl = ph == 0 ? st3[0] : ph == 1 ? st3[1] : st3[2];
+            double v = stl + (double)(end ? k1 - 1 : k0) * inc;  // two roundings, as code_arg
+            if (r6) v = v * 6;
+            const int idx = (int)ceil(v);
+#pragma unroll
+            for (int ph2 = 0; ph2 < 3; ++ph2) {
+                ua1[ph2] = __builtin_amdgcn_readlane(idx, ph2), ub1[ph2] = __builtin_amdgcn_readlane(idx, 3 + ph2);
+                ua6[ph2] = __builtin_amdgcn_readlane(idx, 6 + ph2), ub6[ph2] = __builtin_amdgcn_readlane(idx, 9 + ph2);
+            }
+        }
+        const int lo1 = min(ua1[0], min(ua1[1], ua1[2])), hi1 = max(ub1[0], max(ub1[1], ub1[2])) + 1;
+        const int lo6 = min(ua6[0], min(ua6[1], ua6[2])), hi6 = max(ub6[0], max(ub6[1], ub6[2])) + 1;
+        const bool use1 = hi1 - lo1 < kCap1, use6 = MODE == BDS_TRACK_WB && pilot && hi6 - lo6 < kCap6;
+        if (use1)
+            for (int i = lane; i <= hi1 - lo1; i += 64) s_t1[i] = tab2_at(prim_d, NU, lo1 + i);
+        if (use6)
+            for (int i = lane; i <= hi6 - lo6; i += 64) s_t6[i] = (int8_t)tab_at(prim_p, n6, lo6 + i);
+        // ---- phase 1: wipe the carrier off this lane's SEG samples, exclusive prefix sums of the segment to LDS
+        const int kb = k0 + lane * SEG;
+        const int n_here = max(0, min(SEG, k1 - kb));
+        float run_i = 0.f, run_q = 0.f;
+        if (n_here > 0) {
+            uint32_t wr[2 * NWD];
+            {
+                const uint32_t sh = (uint32_t)((uintptr_t)(dwin + (g.pos + kb) * coeff) & 3);
+#pragma unroll
+                for (int i = 0; i < 2 * NWD; ++i) wr[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], sh);
+            }
+            const float bcf = (float)bc, bsf = (float)bs;
+            const int lbase = lane * SEG + lane;
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) {
+                float rw, rw_q = 0.f;
+                if (p.cplx) {
+                    const uint32_t w = wr[j >> 1];
+                    rw = (float)(int8_t)(w >> ((j & 1) * 16));
+                    rw_q = (float)(int8_t)(w >> ((j & 1) * 16 + 8));
+                } else {
+                    rw = (float)(int8_t)(wr[j >> 2] >> ((j & 3) * 8));
+                }
+                const float2 w = s_w[j];
+                const float c2 = bcf * w.x - bsf * w.y, s2 = bsf * w.x + bcf * w.y;
+                float ib, qb;
+                if (MODE == BDS_TRACK_B2A) {  // exp(+j th): q = real, i = imag (tracking.m:309-314)
+                    qb = rw * c2 - rw_q * s2;
+                    ib = rw * s2 + rw_q * c2;
+                } else {  // exp(-j th): i = real, q = imag (NB_tracking.m:320-325)
+                    ib = rw * c2 + rw_q * s2;
+                    qb = rw_q * c2 - rw * s2;
+                }
+                s_loc[lbase + j] = make_float2(run_i, run_q);
+                if (j < n_here) run_i += ib, run_q += qb;
+            }
+        }
+        if (kwl + k_stride < g.blk) {
+            fetch(kwl + k_stride);  // next pass's bytes: in flight during the scan and phase 2
+            const double nc = bc * rc - bs * rs;
+            bs = bs * rc + bc * rs;
+            bc = nc;
+        }
+        // exclusive f64 scan of the segment totals over the wave
+        const double vi = wave_scan_incl((double)run_i), vq = wave_scan_incl((double)run_q);
+        s_base[lane] = make_double2(vi - (double)run_i, vq - (double)run_q);
+        const double ti = lane_f64(vi, 63), tq = lane_f64(vq, 63);  // pass totals
+        wave_sync();
+        // ---- phase 2
+        auto prefix = [&](int kk) -> double2 {  // sum of the wiped samples k0 .. kk-1, kk in (k0, k1)
+            const int pos = kk - k0, seg = pos / SEG;
+            const double2 b = s_base[seg];
+            const float2 l = s_loc[pos + seg];
+            return make_double2(b.x + (double)l.x, b.y + (double)l.y);
+        };
+        {  // code (and pilot code) at the look-up's own resolution: E, P, L steps of one rank together
+            const int lo = lo1;
+            auto at1 = [&](int i1) -> char2 { return use1 ? s_t1[i1 - lo] : tab2_at(prim_d, NU, i1); };
+            const int nmax = max(ub1[0] - ua1[0], max(ub1[1] - ua1[1], ub1[2] - ua1[2]));
+            for (int r = lane; r < nmax; r += 64) {
+                int kk[3], uu[3];
+                bool val[3], bad = false;
+#pragma unroll
+                for (int ph = 0; ph < 3; ++ph) {
+                    uu[ph] = ua1[ph] + 1 + r;
+                    val[ph] = uu[ph] <= ub1[ph];
+                    const double thr = (double)(uu[ph] - 1);
+                    int kc = (int)floor((thr - st3[ph]) * inv_inc) + 1;  // a prediction, confirmed with the exact expression
+                    kc = max(k0 + 1, min(kc, k1 - 1));
+                    const bool good = !(code_arg<0>(st3[ph], inc, kc - 1) > thr) && code_arg<0>(st3[ph], inc, kc) > thr;
+                    bad |= val[ph] && !good;
+                    kk[ph] = val[ph] ? kc : k0 + 1;
+                }
+                if (bad) {
+#pragma unroll
+                    for (int ph = 0; ph < 3; ++ph)
+                        if (val[ph]) kk[ph] = first_sample_of<0>(st3[ph], inc, inv_inc, uu[ph], k0, k1 - 1);
+                }
+#pragma unroll
+                for (int ph = 0; ph < 3; ++ph) {
+                    const double2 S = prefix(kk[ph]);
+                    const int u = val[ph] ? uu[ph] : ua1[ph];  // (u, u + 1) inside the staged range
+                    const char2 cn = at1(u + 1), co = at1(u);
+                    const double dd = val[ph] ? (double)((int)cn.x - (int)co.x) : 0.0;
+                    acc[2 * ph] -= dd * S.x;
+                    acc[2 * ph + 1] -= dd * S.y;
+                    if (pilot) {
+                        const double dp = val[ph] ? (double)((int)cn.y - (int)co.y) : 0.0;
+                        acc[6 + 2 * ph] -= dp * S.x;
+                        acc[7 + 2 * ph] -= dp * S.y;
+                    }
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int ph = 0; ph < 3; ++ph) {
+                    const char2 cl = at1(ub1[ph] + 1);
+                    acc[2 * ph] += (double)cl.x * ti;
+                    acc[2 * ph + 1] += (double)cl.x * tq;
+                    if (pilot) {
+                        acc[6 + 2 * ph] += (double)cl.y * ti;
+                        acc[7 + 2 * ph] += (double)cl.y * tq;
+                    }
+                }
+            }
+        }
+        if (MODE == BDS_TRACK_WB && pilot) {  // pilotBOC61(ceil(tcode*6)+1)  (WB_tracking.m:298,311,324)
+            const int lo = lo6;
+            auto at6 = [&](int i1) -> float { return use6 ? (float)s_t6[i1 - lo] : tab_at(prim_p, n6, i1); };
+            const int nmax = max(ub6[0] - ua6[0], max(ub6[1] - ua6[1], ub6[2] - ua6[2]));
+            for (int r = lane; r < nmax; r += 64) {
+                int kk[3], uu[3];
+                bool val[3], bad = false;
+#pragma unroll
+                for (int ph = 0; ph < 3; ++ph) {
+                    uu[ph] = ua6[ph] + 1 + r;
+                    val[ph] = uu[ph] <= ub6[ph];
+                    const double thr = (double)(uu[ph] - 1);
+                    int kc = (int)floor((thr * (1.0 / 6.0) - st3[ph]) * inv_inc) + 1;
+                    kc = max(k0 + 1, min(kc, k1 - 1));
+                    const bool good = !(code_arg<1>(st3[ph], inc, kc - 1) > thr) && code_arg<1>(st3[ph], inc, kc) > thr;
+                    bad |= val[ph] && !good;
+                    kk[ph] = val[ph] ? kc : k0 + 1;
+                }
+                if (bad) {
+#pragma unroll
+                    for (int ph = 0; ph < 3; ++ph)
+                        if (val[ph]) kk[ph] = first_sample_of<1>(st3[ph], inc, inv_inc, uu[ph], k0, k1 - 1);
+                }
+#pragma unroll
+                for (int ph = 0; ph < 3; ++ph) {
+                    const double2 S = prefix(kk[ph]);
+                    const int u = val[ph] ? uu[ph] : ua6[ph];
+                    const double d6 = val[ph] ? (double)(at6(u + 1) - at6(u)) : 0.0;
+                    acc[12 + 2 * ph] -= d6 * S.x;
+                    acc[13 + 2 * ph] -= d6 * S.y;
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int ph = 0; ph < 3; ++ph) {
+                    const double cl = (double)at6(ub6[ph] + 1);
+                    acc[12 + 2 * ph] += cl * ti;
+                    acc[13 + 2 * ph] += cl * tq;
+                }
+            }
+        }
+    }
+    // workgroup reduction
+    __syncthreads();
+    double(*s_part)[kNSums] = reinterpret_cast<double(*)[kNSums]>(trk_lds);
+#pragma unroll
+    for (int i = 0; i < kNSums; ++i) {
+        const double v = wave_scan_incl(acc[i]);
+        if (lane == 63) s_part[wave][i] = v;
+    }
+    __syncthreads();
+    if (t < kNSums) {
+        double v = 0;
+        for (int w = 0; w < NW; ++w) v += s_part[w][t];
+        sums[t] = v;
+    }
+}
+
 // grid (nblocks, n_ch); part: [n_ch][nblocks][18]
 template <int MODE>
 __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__restrict__ data,
@@ -234,7 +555,12 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__r
     }
     const int8_t *pd = prim + ((long)(s.prn - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
     const int8_t *pp = prim + ((long)(s.prn - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
-    correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    if (p.runs == 16)
+        correlate_runs<MODE, 16>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    else if (p.runs == 8)
+        correlate_runs<MODE, 8>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    else
+        correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
 }
 
 // Open-loop variant: geometry supplied by the caller (bds_track_correlate).
@@ -261,7 +587,12 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t
     }
     const int8_t *pd = prim + ((long)(prn[ch] - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
     const int8_t *pp = prim + ((long)(prn[ch] - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
-    correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    if (p.runs == 16)
+        correlate_runs<MODE, 16>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    else if (p.runs == 8)
+        correlate_runs<MODE, 8>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    else
+        correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
 }
 
 __global__ void k_trk_reduce_open(const double *__restrict__ part, int nblocks, double *__restrict__ sums) {
@@ -511,8 +842,16 @@ static int fill_params(bds_ctx *ctx, const bds_settings &s, TrkParams &p, int n_
     p.pdi = s.intTime;                                                                   // :107
     p.factor = p.mode == BDS_TRACK_WB ? bds_calc_weighing_factor(&s) : 0.0;              // WB_tracking.m:138
     p.cplx = s.fileType == 2;
-    p.chunk = s.signal == BDS_SIGNAL_B2A ? 2048 : 8192;
-    if (ctx->tune.trk_chunk > 0) p.chunk = std::max(256, ctx->tune.trk_chunk);
+    if (ctx->tune.trk_persample) {  // per-sample correlator (the round-1 kernel; A/B and cross-check)
+        p.chunk = s.signal == BDS_SIGNAL_B2A ? 2048 : 8192;
+        if (ctx->tune.trk_chunk > 0) p.chunk = std::max(256, ctx->tune.trk_chunk);
+        p.runs = 0;
+    } else {  // run-based correlator: 8 or 16 consecutive samples per thread
+        p.runs = s.signal == BDS_SIGNAL_B2A ? 8 : 16;
+        if (ctx->tune.trk_chunk == 2048) p.runs = 8;
+        if (ctx->tune.trk_chunk == 4096) p.runs = 16;
+        p.chunk = kTrkThreads * p.runs;
+    }
     p.n_bytes = (long long)(n_bytes / (p.cplx ? 2 : 1));  // whole samples an fread can deliver
     return BDS_OK;
 }
@@ -652,7 +991,19 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &loa
     // correlate grid: blksize stays near codeLength*fs/codeFreq; sized for code rates down to 2 % below the slowest
     // channel's (a longer block is walked by the same workgroups in further strides)
     long max_blk = (long)std::ceil((double)s->codeLength / ((min_code_freq < 1e299 ? min_code_freq : s->codeFreqBasis) * 0.98 / s->samplingFreq)) + 2;
-    const int nblocks = ctx->tune.trk_nblocks > 0 ? ctx->tune.trk_nblocks : (int)((max_blk + p.chunk - 1) / p.chunk);
+    int nblocks = (int)((max_blk + p.chunk - 1) / p.chunk);
+    if (p.runs && n_ch > 0) {
+        // run-based correlator: every wave pays a fixed cost per launch (tables, first carrier, the 18-sum reduction), so
+        // the grid is sized to fill the chip about once (3 workgroups per CU) and each wave walks several passes
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const int want = std::max(1, 3 * cus / n_ch);
+        if (nblocks > want) {
+            const int passes = (nblocks + want - 1) / want;
+            nblocks = (nblocks + passes - 1) / passes;
+        }
+    }
+    if (ctx->tune.trk_nblocks > 0) nblocks = ctx->tune.trk_nblocks;
     // Only the part of the record the channels can touch goes to HBM: from the earliest start sample to the latest
     // start + n_epochs blocks at a code rate 2 % low (the reference streams blksize samples per epoch with fread,
     // tracking.m:237-240; a recording is usually far longer than msToProcess).  End-of-file is still judged against
@@ -674,7 +1025,7 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &loa
         const size_t wbytes = (size_t)((last - first) * coeff);
         if (t.data_cap < wbytes || !t.d_data) {
             if (t.d_data) (void)hipFree(t.d_data), t.d_data = nullptr, t.data_cap = 0;
-            hipError_t e = hipMalloc((void **)&t.d_data, std::max<size_t>(wbytes, 1));
+            hipError_t e = hipMalloc((void **)&t.d_data, wbytes + kDataSlack);
             if (e != hipSuccess)
                 return fail(ctx, BDS_ERR_NOMEM, "IF record window of %zu bytes does not fit in HBM: %s", wbytes, hipGetErrorString(e));
             t.data_cap = std::max<size_t>(wbytes, 1);
@@ -730,15 +1081,15 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &loa
     for (int k = 0; k < n_epochs; ++k) {
         switch (p.mode) {
             case BDS_TRACK_B2A:
-                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_B2A>, gc, dim3(kTrkThreads), 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
+                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_B2A>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
                 hipLaunchKernelGGL(k_trk_update<BDS_TRACK_B2A>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
                 break;
             case BDS_TRACK_NB:
-                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_NB>, gc, dim3(kTrkThreads), 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
+                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_NB>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
                 hipLaunchKernelGGL(k_trk_update<BDS_TRACK_NB>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
                 break;
             default:
-                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_WB>, gc, dim3(kTrkThreads), 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
+                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_WB>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
                 hipLaunchKernelGGL(k_trk_update<BDS_TRACK_WB>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
                 break;
         }
@@ -887,7 +1238,7 @@ extern "C" int bds_track_correlate(bds_ctx *ctx, const bds_settings *s, const in
     int8_t *d_data = nullptr;
     int *d_prn = nullptr;
     double *d_s6 = nullptr, *d_part = nullptr, *d_sums = nullptr;
-    BDS_HIP(ctx, hipMalloc((void **)&d_data, std::max<size_t>(n_bytes, 1)));
+    BDS_HIP(ctx, hipMalloc((void **)&d_data, n_bytes + kDataSlack));
     BDS_HIP(ctx, hipMalloc((void **)&d_prn, sizeof(int) * n_ch));
     BDS_HIP(ctx, hipMalloc((void **)&d_s6, sizeof(double) * 6 * n_ch));
     BDS_HIP(ctx, hipMalloc((void **)&d_part, sizeof(double) * (size_t)n_ch * nblocks * kNSums));
@@ -898,13 +1249,13 @@ extern "C" int bds_track_correlate(bds_ctx *ctx, const bds_settings *s, const in
     dim3 gc(nblocks, n_ch);
     switch (p.mode) {
         case BDS_TRACK_B2A:
-            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_B2A>, gc, dim3(kTrkThreads), 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
+            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_B2A>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
             break;
         case BDS_TRACK_NB:
-            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_NB>, gc, dim3(kTrkThreads), 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
+            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_NB>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
             break;
         default:
-            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_WB>, gc, dim3(kTrkThreads), 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
+            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_WB>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
             break;
     }
     hipLaunchKernelGGL(k_trk_reduce_open, dim3(n_ch), dim3(64), 0, st(ctx), (const double *)d_part, nblocks, d_sums);
