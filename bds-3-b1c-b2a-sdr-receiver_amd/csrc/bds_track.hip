@@ -292,7 +292,7 @@ __device__ __forceinline__ double lane_f64(double v, int l) {  // broadcast of l
 // The waves of a workgroup work independently (wave w on samples k0 + w 64 SEG .. of each chunk, its own LDS
 // slice, no workgroup barrier before the final reduction): the kernel is bound by latency -- HBM reads,
 // dependent f64 evaluations -- and independent waves hide it where barrier-separated phases cannot.
-template <int MODE, int SEG>
+template <int MODE, int SEG, bool CPLX>
 __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, const int8_t *__restrict__ prim_d,
                                                const int8_t *__restrict__ prim_p, const TrkParams &p,
                                                const EpochGeom &g, long k0_first, long k_stride, bool pilot, double *sums) {
@@ -313,8 +313,8 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
     const double st3[3] = {(g.rem - p.spacing) * scale, g.rem * scale, (g.rem + p.spacing) * scale};  // E, P, L
     const double two_pi = 6.283185307179586476925286766559;
     const double cyc0 = g.remCarr / two_pi;
-    const int coeff = p.cplx ? 2 : 1;
-    const int nwd = p.cplx ? 2 * NWD : NWD;
+    constexpr int coeff = CPLX ? 2 : 1;
+    constexpr int nwd = CPLX ? 2 * NWD : NWD;  // dwords of a segment
     const int8_t *__restrict__ dwin = data - p.base * coeff;
     double acc[kNSums];
 #pragma unroll
@@ -326,14 +326,14 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
         s_w[lane] = make_float2((float)cs, (float)sn);
     }
     // the segment's bytes (I/Q pairs: 2 SEG bytes), whole aligned dwords around it
-    uint32_t raw[2 * NWD + 1];
+    uint32_t raw[nwd + 1];
     auto fetch = [&](long kw) {
         const long kb = kw + (long)lane * SEG;
         if (kb < g.blk) {
             const uintptr_t a = (uintptr_t)(dwin + (g.pos + kb) * coeff);
             const uint32_t *__restrict__ q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
 #pragma unroll
-            for (int i = 0; i <= 2 * NWD; ++i) raw[i] = i <= nwd ? q[i] : 0u;
+            for (int i = 0; i <= nwd; ++i) raw[i] = q[i];
         }
     };
     const long kw_first = k0_first + (long)wave * WCH;
@@ -377,18 +377,19 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
         const int n_here = max(0, min(SEG, k1 - kb));
         float run_i = 0.f, run_q = 0.f;
         if (n_here > 0) {
-            uint32_t wr[2 * NWD];
+            uint32_t wr[nwd];
             {
                 const uint32_t sh = (uint32_t)((uintptr_t)(dwin + (g.pos + kb) * coeff) & 3);
 #pragma unroll
-                for (int i = 0; i < 2 * NWD; ++i) wr[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], sh);
+                for (int i = 0; i < nwd; ++i) wr[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], sh);
             }
             const float bcf = (float)bc, bsf = (float)bs;
             const int lbase = lane * SEG + lane;
-#pragma unroll
-            for (int j = 0; j < SEG; ++j) {
+            // sample j of the segment, carrier-wiped: (ib, qb).  The carrier is base x table entry in fp32 with
+            // explicit FMAs (the exact two-rounding rule of the build only matters for the code index)
+            auto wiped = [&](int j, float &ib, float &qb) {
                 float rw, rw_q = 0.f;
-                if (p.cplx) {
+                if (CPLX) {  // rawSignal = data(1:2:end) + 1i*data(2:2:end)  (tracking.m:242-246)
                     const uint32_t w = wr[j >> 1];
                     rw = (float)(int8_t)(w >> ((j & 1) * 16));
                     rw_q = (float)(int8_t)(w >> ((j & 1) * 16 + 8));
@@ -396,17 +397,31 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
                     rw = (float)(int8_t)(wr[j >> 2] >> ((j & 3) * 8));
                 }
                 const float2 w = s_w[j];
-                const float c2 = bcf * w.x - bsf * w.y, s2 = bsf * w.x + bcf * w.y;
-                float ib, qb;
+                const float c2 = fmaf(bcf, w.x, -(bsf * w.y)), s2 = fmaf(bsf, w.x, bcf * w.y);
                 if (MODE == BDS_TRACK_B2A) {  // exp(+j th): q = real, i = imag (tracking.m:309-314)
-                    qb = rw * c2 - rw_q * s2;
-                    ib = rw * s2 + rw_q * c2;
+                    qb = CPLX ? fmaf(rw, c2, -(rw_q * s2)) : rw * c2;
+                    ib = CPLX ? fmaf(rw, s2, rw_q * c2) : rw * s2;
                 } else {  // exp(-j th): i = real, q = imag (NB_tracking.m:320-325)
-                    ib = rw * c2 + rw_q * s2;
-                    qb = rw_q * c2 - rw * s2;
+                    ib = CPLX ? fmaf(rw, c2, rw_q * s2) : rw * c2;
+                    qb = CPLX ? fmaf(rw_q, c2, -(rw * s2)) : -(rw * s2);
                 }
-                s_loc[lbase + j] = make_float2(run_i, run_q);
-                if (j < n_here) run_i += ib, run_q += qb;
+            };
+            if (n_here == SEG) {  // every segment but the last one of the block
+#pragma unroll
+                for (int j = 0; j < SEG; ++j) {
+                    float ib, qb;
+                    wiped(j, ib, qb);
+                    s_loc[lbase + j] = make_float2(run_i, run_q);
+                    run_i += ib, run_q += qb;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < SEG; ++j) {
+                    float ib, qb;
+                    wiped(j, ib, qb);
+                    s_loc[lbase + j] = make_float2(run_i, run_q);
+                    run_i += j < n_here ? ib : 0.f, run_q += j < n_here ? qb : 0.f;
+                }
             }
         }
         if (kwl + k_stride < g.blk) {
@@ -555,10 +570,14 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__r
     }
     const int8_t *pd = prim + ((long)(s.prn - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
     const int8_t *pp = prim + ((long)(s.prn - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
-    if (p.runs == 16)
-        correlate_runs<MODE, 16>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    if (p.runs == 16 && !p.cplx)
+        correlate_runs<MODE, 16, false>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    else if (p.runs == 16)
+        correlate_runs<MODE, 16, true>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    else if (p.runs == 8 && !p.cplx)
+        correlate_runs<MODE, 8, false>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
     else if (p.runs == 8)
-        correlate_runs<MODE, 8>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+        correlate_runs<MODE, 8, true>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
     else
         correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
 }
@@ -587,10 +606,14 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t
     }
     const int8_t *pd = prim + ((long)(prn[ch] - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
     const int8_t *pp = prim + ((long)(prn[ch] - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
-    if (p.runs == 16)
-        correlate_runs<MODE, 16>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    if (p.runs == 16 && !p.cplx)
+        correlate_runs<MODE, 16, false>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    else if (p.runs == 16)
+        correlate_runs<MODE, 16, true>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    else if (p.runs == 8 && !p.cplx)
+        correlate_runs<MODE, 8, false>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
     else if (p.runs == 8)
-        correlate_runs<MODE, 8>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+        correlate_runs<MODE, 8, true>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
     else
         correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
 }

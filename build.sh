@@ -25,6 +25,7 @@ for f in bds_codes.cpp bds_api.hip bds_acq.hip bds_track.hip bds_sync.hip bds_mu
             # the search: FMA contraction on; SLP packing off (v_pk_* f32 runs at the scalar rate on
             # gfx950 and costs register shuffles: measured -4.6 % on the cell pair)
             [ "$f" = bds_acq.hip ] && contract="fast -fno-slp-vectorize"
+            [ "$f" = bds_track.hip ] && contract="off -fno-slp-vectorize"
             "$HIPCC" "${FLAGS[@]}" -ffp-contract=$contract -c "$SRC/$f" -o "$o" ${BDS_HIPCC_EXTRA:-}
         fi
     fi

@@ -8,7 +8,7 @@ mkdir -p "$ROOT/tools/variants"
 F="${VFILE:-bds_acq}"   # VFILE=bds_track: rebuild the tracking object instead (contraction off, as build.sh)
 O="$ROOT/tools/variants/${F}_$1.o"
 BASE="${3:--ffp-contract=fast -fno-slp-vectorize}"
-[ "$F" = bds_track ] && BASE="-ffp-contract=off"
+[ "$F" = bds_track ] && BASE="-ffp-contract=off -fno-slp-vectorize"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-result -I"$ROOT/include" -I"$PKG/csrc" \
     $BASE $2 -c "$PKG/csrc/$F.hip" -o "$O"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$PKG/build/bds_codes.o" "$PKG/build/bds_api.o" $([ "$F" = bds_acq ] && echo "$O" || echo "$PKG/build/bds_acq.o") $([ "$F" = bds_track ] && echo "$O" || echo "$PKG/build/bds_track.o") "$PKG/build/bds_sync.o" \
