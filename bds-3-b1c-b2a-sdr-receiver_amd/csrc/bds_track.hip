@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <type_traits>
 
 #include "bds_internal.h"
 
@@ -471,12 +472,12 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
                     const int u = val[ph] ? uu[ph] : ua1[ph];  // (u, u + 1) inside the staged range
                     const char2 cn = at1(u + 1), co = at1(u);
                     const double dd = val[ph] ? (double)((int)cn.x - (int)co.x) : 0.0;
-                    acc[2 * ph] -= dd * S.x;
-                    acc[2 * ph + 1] -= dd * S.y;
+                    acc[2 * ph] = fma(-dd, S.x, acc[2 * ph]);
+                    acc[2 * ph + 1] = fma(-dd, S.y, acc[2 * ph + 1]);
                     if (pilot) {
                         const double dp = val[ph] ? (double)((int)cn.y - (int)co.y) : 0.0;
-                        acc[6 + 2 * ph] -= dp * S.x;
-                        acc[7 + 2 * ph] -= dp * S.y;
+                        acc[6 + 2 * ph] = fma(-dp, S.x, acc[6 + 2 * ph]);
+                        acc[7 + 2 * ph] = fma(-dp, S.y, acc[7 + 2 * ph]);
                     }
                 }
             }
@@ -521,8 +522,8 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
                     const double2 S = prefix(kk[ph]);
                     const int u = val[ph] ? uu[ph] : ua6[ph];
                     const double d6 = val[ph] ? (double)(at6(u + 1) - at6(u)) : 0.0;
-                    acc[12 + 2 * ph] -= d6 * S.x;
-                    acc[13 + 2 * ph] -= d6 * S.y;
+                    acc[12 + 2 * ph] = fma(-d6, S.x, acc[12 + 2 * ph]);
+                    acc[13 + 2 * ph] = fma(-d6, S.y, acc[13 + 2 * ph]);
                 }
             }
             if (lane == 0) {
@@ -552,7 +553,9 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
 }
 
 // grid (nblocks, n_ch); part: [n_ch][nblocks][18]
-template <int MODE>
+// One kernel per (tracker, correlator variant, record type): a kernel holding all variants ran out of SGPRs
+// (150 spilled in wide-band mode, each a lane write + read on the vector unit).
+template <int MODE, int SEG, bool CPLX>
 __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__restrict__ data,
                                                               const int8_t *__restrict__ prim, TrkParams p,
                                                               const ChanState *__restrict__ st,
@@ -570,20 +573,14 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__r
     }
     const int8_t *pd = prim + ((long)(s.prn - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
     const int8_t *pp = prim + ((long)(s.prn - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
-    if (p.runs == 16 && !p.cplx)
-        correlate_runs<MODE, 16, false>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
-    else if (p.runs == 16)
-        correlate_runs<MODE, 16, true>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
-    else if (p.runs == 8 && !p.cplx)
-        correlate_runs<MODE, 8, false>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
-    else if (p.runs == 8)
-        correlate_runs<MODE, 8, true>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
-    else
+    if constexpr (SEG > 0)  // run-based correlator, SEG samples per lane and pass
+        correlate_runs<MODE, SEG, CPLX>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    else  // per-sample correlator (reads p.cplx itself)
         correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
 }
 
 // Open-loop variant: geometry supplied by the caller (bds_track_correlate).
-template <int MODE>
+template <int MODE, int SEG, bool CPLX>
 __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t *__restrict__ data,
                                                                    const int8_t *__restrict__ prim, TrkParams p,
                                                                    const int *__restrict__ prn,
@@ -606,17 +603,27 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t
     }
     const int8_t *pd = prim + ((long)(prn[ch] - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
     const int8_t *pp = prim + ((long)(prn[ch] - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
-    if (p.runs == 16 && !p.cplx)
-        correlate_runs<MODE, 16, false>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
-    else if (p.runs == 16)
-        correlate_runs<MODE, 16, true>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
-    else if (p.runs == 8 && !p.cplx)
-        correlate_runs<MODE, 8, false>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
-    else if (p.runs == 8)
-        correlate_runs<MODE, 8, true>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
-    else
+    if constexpr (SEG > 0)  // run-based correlator, SEG samples per lane and pass
+        correlate_runs<MODE, SEG, CPLX>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+    else  // per-sample correlator (reads p.cplx itself)
         correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
 }
+
+// launch k<MODE, SEG, CPLX> for the run-time (mode, runs, cplx) of p
+#define BDS_TRK_LAUNCH(KERN, grid, lds, stream, ...)                                                        \
+    do {                                                                                                    \
+        auto go = [&](auto mode_c) {                                                                        \
+            constexpr int M = decltype(mode_c)::value;                                                      \
+            if (p.runs == 16 && !p.cplx) hipLaunchKernelGGL((KERN<M, 16, false>), grid, dim3(kTrkThreads), lds, stream, __VA_ARGS__); \
+            else if (p.runs == 16) hipLaunchKernelGGL((KERN<M, 16, true>), grid, dim3(kTrkThreads), lds, stream, __VA_ARGS__);       \
+            else if (p.runs == 8 && !p.cplx) hipLaunchKernelGGL((KERN<M, 8, false>), grid, dim3(kTrkThreads), lds, stream, __VA_ARGS__); \
+            else if (p.runs == 8) hipLaunchKernelGGL((KERN<M, 8, true>), grid, dim3(kTrkThreads), lds, stream, __VA_ARGS__);         \
+            else hipLaunchKernelGGL((KERN<M, 0, false>), grid, dim3(kTrkThreads), lds, stream, __VA_ARGS__);                          \
+        };                                                                                                  \
+        if (p.mode == BDS_TRACK_B2A) go(std::integral_constant<int, BDS_TRACK_B2A>{});                      \
+        else if (p.mode == BDS_TRACK_NB) go(std::integral_constant<int, BDS_TRACK_NB>{});                   \
+        else go(std::integral_constant<int, BDS_TRACK_WB>{});                                               \
+    } while (0)
 
 __global__ void k_trk_reduce_open(const double *__restrict__ part, int nblocks, double *__restrict__ sums) {
     const int ch = blockIdx.x;
@@ -1102,17 +1109,15 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &loa
     const int8_t *data = t.d_data;
     dim3 gc(nblocks, n_ch);
     for (int k = 0; k < n_epochs; ++k) {
+        BDS_TRK_LAUNCH(k_trk_correlate, gc, (p.runs ? runs_lds_bytes(p.runs) : 0), st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
         switch (p.mode) {
             case BDS_TRACK_B2A:
-                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_B2A>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
                 hipLaunchKernelGGL(k_trk_update<BDS_TRACK_B2A>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
                 break;
             case BDS_TRACK_NB:
-                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_NB>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
                 hipLaunchKernelGGL(k_trk_update<BDS_TRACK_NB>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
                 break;
             default:
-                hipLaunchKernelGGL(k_trk_correlate<BDS_TRACK_WB>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
                 hipLaunchKernelGGL(k_trk_update<BDS_TRACK_WB>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
                 break;
         }
@@ -1270,17 +1275,8 @@ extern "C" int bds_track_correlate(bds_ctx *ctx, const bds_settings *s, const in
     BDS_HIP(ctx, hipMemcpyAsync(d_prn, prn, sizeof(int) * n_ch, hipMemcpyHostToDevice, st(ctx)));
     BDS_HIP(ctx, hipMemcpyAsync(d_s6, state6, sizeof(double) * 6 * n_ch, hipMemcpyHostToDevice, st(ctx)));
     dim3 gc(nblocks, n_ch);
-    switch (p.mode) {
-        case BDS_TRACK_B2A:
-            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_B2A>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
-            break;
-        case BDS_TRACK_NB:
-            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_NB>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
-            break;
-        default:
-            hipLaunchKernelGGL(k_trk_correlate_open<BDS_TRACK_WB>, gc, dim3(kTrkThreads), p.runs ? runs_lds_bytes(p.runs) : 0, st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p, (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
-            break;
-    }
+    BDS_TRK_LAUNCH(k_trk_correlate_open, gc, (p.runs ? runs_lds_bytes(p.runs) : 0), st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p,
+                   (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
     hipLaunchKernelGGL(k_trk_reduce_open, dim3(n_ch), dim3(64), 0, st(ctx), (const double *)d_part, nblocks, d_sums);
     BDS_HIP(ctx, hipGetLastError());
     BDS_HIP(ctx, hipMemcpyAsync(sums18, d_sums, sizeof(double) * (size_t)n_ch * kNSums, hipMemcpyDeviceToHost, st(ctx)));
