@@ -80,7 +80,7 @@ def resample_b1c(iq=False):
     return s, x, sats
 
 
-def track_case(signal, mode, n_epochs, seed=21, iq=False):
+def track_case(signal, mode, n_epochs, seed=21, iq=False, fs=None, IF=None):
     """Synthetic record + channels for the tracking tests at a reduced sampling rate.
 
     Returns (settings, file_bytes int8, channels) with channels filled the way preRun
@@ -88,13 +88,13 @@ def track_case(signal, mode, n_epochs, seed=21, iq=False):
     from types import SimpleNamespace
 
     if signal == "B2A":
-        s = bds_amd.init_settings_b2a(samplingFreq=25e6, IF=6.5e6, msToProcess=n_epochs, numberOfChannels=3,
+        s = bds_amd.init_settings_b2a(samplingFreq=fs or 25e6, IF=IF or 6.5e6, msToProcess=n_epochs, numberOfChannels=3,
                                       CNoInterval=20, fileType=2 if iq else 1)
         sat_list = [synth.Sat(9, -1230.0, 12345.6, 2.0, 50.0), synth.Sat(19, 2210.0, 3001.2, 0.4, 47.0),
                     synth.Sat(33, 355.0, 20111.9, 1.3, 45.0)]
     else:
         flag = {"NB": 1, "WB": 2}[mode]
-        s = bds_amd.init_settings_b1c(samplingFreq=12.5e6, IF=3.5e6, msToProcess=n_epochs * 10, numberOfChannels=3,
+        s = bds_amd.init_settings_b1c(samplingFreq=fs or 12.5e6, IF=IF or 3.5e6, msToProcess=n_epochs * 10, numberOfChannels=3,
                                       pilotTRKflag=flag, CNoInterval=10, FEBW=10e6, fileType=2 if iq else 1)
         sat_list = [synth.Sat(3, 230.0, 40000.3, 1.0, 48.0), synth.Sat(12, -410.0, 99000.8, 2.0, 45.0),
                     synth.Sat(27, 1800.0, 7000.5, 0.2, 46.0)]

@@ -161,3 +161,30 @@ def test_block_longer_than_the_correlate_grid(ctx, monkeypatch):
         for f in ("I_P", "Q_P", "Pilot_I_P", "Pilot_Q_E"):  # fp32 partial sums over more samples per thread: 1e-6 of |P|
             np.testing.assert_allclose(getattr(g, f), getattr(w, f), rtol=0, atol=2e-6 * p, err_msg=f)
         np.testing.assert_allclose(g.carrFreq, w.carrFreq, rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("signal,mode,fs,IF", [("B2A", "B2A", 12e6, 3e6), ("B1C", "WB", 7.5e6, 2e6), ("B1C", "WB", 3.1e6, 0.8e6)])
+def test_low_sampling_rates_and_both_correlators(ctx, monkeypatch, signal, mode, fs, IF):
+    """The run-based correlator stages a pass's slice of the code tables in LDS when it fits (every other case of this
+    file); at low sampling rates a pass spans more code units than the slice holds (look-ups stay in global memory) and,
+    below the BOC(6,1) rate, a sample step skips units (several index steps share one first sample).  Open-loop sums
+    against the oracle, and against the per-sample correlator (BDS_TRK_PERSAMPLE) on the same states."""
+    n_epochs = 6 if signal == "B1C" else 20
+    s, x, chans = track_case(signal, mode, n_epochs, fs=fs, IF=IF)
+    trace = []
+    otrk.tracking(otrk.RawFile(x), chans, s, mode=mode, trace=trace)
+    rows = [t for t in trace if t["k"] in (1, n_epochs)]
+    prn = [chans[t["ch"]].PRN for t in rows]
+    st = [[t["pos"], t["blk"], t["rem"], t["codeFreq"], t["remCarr"], t["carrFreq"]] for t in rows]
+    got = ctx.track_correlate(s, x, prn, st)
+    monkeypatch.setenv("BDS_TRK_PERSAMPLE", "1")
+    ctx.reload_tuning()
+    try:
+        per_sample = ctx.track_correlate(s, x, prn, st)
+    finally:
+        monkeypatch.delenv("BDS_TRK_PERSAMPLE")
+        ctx.reload_tuning()
+    for g, q, t in zip(got, per_sample, rows):
+        p = np.hypot(t["sums"][2], t["sums"][3])
+        np.testing.assert_allclose(g, t["sums"], rtol=0, atol=1e-6 * p)
+        np.testing.assert_allclose(g, q, rtol=0, atol=1e-6 * p)
