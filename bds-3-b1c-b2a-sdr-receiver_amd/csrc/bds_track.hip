@@ -443,6 +443,49 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
             const float2 l = s_loc[pos + seg];
             return make_double2(b.x + (double)l.x, b.y + (double)l.y);
         };
+        if (MODE != BDS_TRACK_B2A) {
+            // B1C: ~21 half-chip steps per replica and pass -- one lane per (replica, step), the three replicas laid
+            // end to end (63-66 items: one iteration as a rule), instead of three searches on a third of the lanes
+            const int lo = lo1;
+            auto at1 = [&](int i1) -> char2 { return use1 ? s_t1[i1 - lo] : tab2_at(prim_d, NU, i1); };
+            const int n0 = ub1[0] - ua1[0], n1 = ub1[1] - ua1[1], n2 = ub1[2] - ua1[2];
+            for (int r = lane; r < n0 + n1 + n2; r += 64) {
+                const int ph = r < n0 ? 0 : r < n0 + n1 ? 1 : 2;
+                const int u = (ph == 0 ? ua1[0] + r : ph == 1 ? ua1[1] + (r - n0) : ua1[2] + (r - n0 - n1)) + 1;
+                const double st = ph == 0 ? st3[0] : ph == 1 ? st3[1] : st3[2];
+                const double thr = (double)(u - 1);
+                int kk = (int)floor((thr - st) * inv_inc) + 1;  // a prediction, confirmed with the exact expression
+                kk = max(k0 + 1, min(kk, k1 - 1));
+                if (!(!(code_arg<0>(st, inc, kk - 1) > thr) && code_arg<0>(st, inc, kk) > thr))
+                    kk = first_sample_of<0>(st, inc, inv_inc, u, k0, k1 - 1);
+                const double2 S = prefix(kk);
+                const char2 cn = at1(u + 1), co = at1(u);
+                const double dd = (double)((int)cn.x - (int)co.x), dp = (double)((int)cn.y - (int)co.y);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double d = ph == q ? dd : 0.0;
+                    acc[2 * q] = fma(-d, S.x, acc[2 * q]);
+                    acc[2 * q + 1] = fma(-d, S.y, acc[2 * q + 1]);
+                    if (pilot) {
+                        const double e = ph == q ? dp : 0.0;
+                        acc[6 + 2 * q] = fma(-e, S.x, acc[6 + 2 * q]);
+                        acc[7 + 2 * q] = fma(-e, S.y, acc[7 + 2 * q]);
+                    }
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int ph = 0; ph < 3; ++ph) {
+                    const char2 cl = at1(ub1[ph] + 1);
+                    acc[2 * ph] += (double)cl.x * ti;
+                    acc[2 * ph + 1] += (double)cl.x * tq;
+                    if (pilot) {
+                        acc[6 + 2 * ph] += (double)cl.y * ti;
+                        acc[7 + 2 * ph] += (double)cl.y * tq;
+                    }
+                }
+            }
+        } else
         {  // code (and pilot code) at the look-up's own resolution: E, P, L steps of one rank together
             const int lo = lo1;
             auto at1 = [&](int i1) -> char2 { return use1 ? s_t1[i1 - lo] : tab2_at(prim_d, NU, i1); };
