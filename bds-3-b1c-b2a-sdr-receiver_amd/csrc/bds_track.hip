@@ -341,12 +341,14 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
     if (kw_first < g.blk) fetch(kw_first);
     // carrier at this lane's first sample of the first pass (tracking.m:303-304); every further pass is k_stride
     // samples on: one f64 rotation instead of a sincospi per pass
-    double bs, bc, rs, rc;
+    double bs, bc, rs = 0.0, rc = 1.0;
     {
         const double cyc = g.carrFreq * ((double)(kw_first + (long)lane * SEG) * p.inv_fs) + cyc0;
         sincospi(2.0 * (cyc - floor(cyc)), &bs, &bc);
-        const double cyr = g.carrFreq * ((double)k_stride * p.inv_fs);
-        sincospi(2.0 * (cyr - floor(cyr)), &rs, &rc);
+        if (kw_first + k_stride < g.blk) {  // (wave-uniform) a second pass exists
+            const double cyr = g.carrFreq * ((double)k_stride * p.inv_fs);
+            sincospi(2.0 * (cyr - floor(cyr)), &rs, &rc);
+        }
     }
     for (long kwl = kw_first; kwl < g.blk; kwl += k_stride) {
         const int k0 = (int)kwl, k1 = (int)min(g.blk, kwl + WCH);  // blksize < 2^31
@@ -584,6 +586,10 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
     double(*s_part)[kNSums] = reinterpret_cast<double(*)[kNSums]>(trk_lds);
 #pragma unroll
     for (int i = 0; i < kNSums; ++i) {
+        if (i >= 12 && MODE != BDS_TRACK_WB) {  // no BOC(6,1) correlators outside wide-band mode
+            if (lane == 63) s_part[wave][i] = 0.0;
+            continue;
+        }
         const double v = wave_scan_incl(acc[i]);
         if (lane == 63) s_part[wave][i] = v;
     }
