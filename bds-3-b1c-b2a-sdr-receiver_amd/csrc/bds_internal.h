@@ -49,6 +49,7 @@ struct Tuning {
     bool multi_force_rccl = false;      // BDS_MULTI_FORCE_RCCL: a single-device bds_multi still goes through RCCL (test hook)
     int trk_nblocks = 0;                // BDS_TRK_NBLOCKS: test hook, correlate workgroups per channel (0 = sized from the code rate)
     int trk_chunk = 0;               // BDS_TRK_CHUNK: samples per correlate workgroup (0 = per-mode default)
+    bool trk_nofuse_update = false;  // BDS_TRK_NOFUSE_UPDATE: loop update as its own launch per epoch instead of at the head of the next correlate launch
     bool trk_persample = false;      // BDS_TRK_PERSAMPLE: per-sample tracking correlator instead of the run-based one
 };
 Tuning tuning_from_env();

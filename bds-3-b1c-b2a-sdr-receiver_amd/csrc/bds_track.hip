@@ -602,15 +602,28 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
 }
 
 // grid (nblocks, n_ch); part: [n_ch][nblocks][18]
+template <int MODE>
+__device__ __forceinline__ void apply_update(const TrkParams &p, ChanState &s, const double *__restrict__ part, int ch,
+                                             int nblocks, int epoch, const TrkOut &o, bool store);
+
 // One kernel per (tracker, correlator variant, record type): a kernel holding all variants ran out of SGPRs
 // (150 spilled in wide-band mode, each a lane write + read on the vector unit).
+// With `part_prev` the kernel first applies the loop update of the previous epoch: every workgroup of a channel
+// recomputes it from that epoch's partial sums (fixed summation order: the same bits everywhere), so no workgroup has to
+// wait for another and an epoch is one launch instead of two (the update as its own kernel costs ~5 us, mostly the
+// floor of a small dependent launch).  State and partial sums ping-pong between two buffers; workgroup 0 of the channel
+// writes the results of the previous epoch and the state the current one starts from.
 template <int MODE, int SEG, bool CPLX>
 __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__restrict__ data,
                                                               const int8_t *__restrict__ prim, TrkParams p,
-                                                              const ChanState *__restrict__ st,
-                                                              double *__restrict__ part, int nblocks) {
+                                                              const ChanState *__restrict__ st_in, ChanState *__restrict__ st_out,
+                                                              const double *__restrict__ part_prev, double *__restrict__ part,
+                                                              int nblocks, int epoch, const TrkOut *__restrict__ op) {
     const int ch = blockIdx.y;
-    const ChanState s = st[ch];
+    ChanState s = st_in[ch];
+    // (the table of result arrays comes by pointer: 21 pointers by value cost this kernel 40 SGPRs it does not have)
+    if (part_prev && s.active == 1) apply_update<MODE>(p, s, part_prev, ch, nblocks, epoch - 1, *op, blockIdx.x == 0);
+    if (st_out != st_in && blockIdx.x == 0 && threadIdx.x == 0) st_out[ch] = s;  // the state this epoch runs with
     double *out = part + ((long)ch * nblocks + blockIdx.x) * kNSums;
     if (s.active != 1) return;
     const EpochGeom g = epoch_geom(s, p);
@@ -687,15 +700,15 @@ __global__ void k_trk_reduce_open(const double *__restrict__ part, int nblocks, 
 // thread 0 then runs the loop filters
 static constexpr int kUpdGroups = 14;
 static constexpr int kUpdThreads = 256;  // >= kUpdGroups * kNSums
+// Loop update of one channel, run by a whole workgroup (>= kUpdGroups * 18 threads): `s` is the state the epoch was
+// correlated with, `part` that epoch's partial sums; every thread returns with the next state in `s`.  The result
+// arrays of the epoch are written only if `store` (one workgroup per channel).
 template <int MODE>
-__global__ __launch_bounds__(kUpdThreads) void k_trk_update(TrkParams p, ChanState *__restrict__ st,
-                                                   const double *__restrict__ part, int nblocks, int epoch,
-                                                   TrkOut o) {
-    const int ch = blockIdx.x;
+__device__ __forceinline__ void apply_update(const TrkParams &p, ChanState &s, const double *__restrict__ part, int ch,
+                                             int nblocks, int epoch, const TrkOut &o, bool store) {
     __shared__ double s_sum[kNSums];
     __shared__ double s_grp[kUpdGroups][kNSums];
-    ChanState s = st[ch];
-    if (s.active != 1) return;
+    __shared__ ChanState s_next;
     const EpochGeom g = epoch_geom(s, p);
     // fixed-order two-level sum over the correlate workgroups (bit-stable from run to run): group j
     // takes workgroups j, j+14, ...; the 14 group sums are then added in order.  (A single thread per
@@ -715,41 +728,9 @@ __global__ __launch_bounds__(kUpdThreads) void k_trk_update(TrkParams p, ChanSta
         s_sum[threadIdx.x] = v;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    const long e = (long)ch * p.n_epochs + epoch;
-    if (g.pos + g.blk <= p.n_bytes && (g.pos < p.base || g.pos + g.blk > p.win_end)) {
-        // inside the file but outside the part of it that was loaded: nothing of this epoch is valid;
-        // the host repeats the call with the whole record in HBM
-        s.active = -2;
-        st[ch] = s;
-        return;
-    }
-    o.absoluteSample[e] = (double)s.pos;  // tracking.m:226 (assigned before the read)
-    if (g.pos + g.blk > p.n_bytes) {
-        // short read: message + return in the reference (tracking.m:250-254); partial results stay
-        s.active = 0;
-        st[ch] = s;
-        return;
-    }
     const double two_pi = 6.283185307179586476925286766559;
     const double pi = 3.14159265358979323846;
     const double L = (double)p.code_len;
-    o.remCodePhase[e] = s.remCodePhase;  // :258
-    o.remCarrPhase[e] = s.remCarrPhase;  // :300
-    // remCodePhase = tcode(blksize) + codePhaseStep - codeLength  (:295; B1C: tcode/2, WB:327)
-    double rem_next;
-    if (MODE == BDS_TRACK_B2A) {
-        const double tp_last = g.rem + (double)(g.blk - 1) * g.step;
-        rem_next = (tp_last + g.step) - L;
-    } else {
-        const double tp_last = g.rem * 2.0 + (double)(g.blk - 1) * (g.step * 2.0);
-        rem_next = tp_last / 2 + g.step - L;
-    }
-    // remCarrPhase = rem(trigarg(blksize+1), 2*pi)  (:303-305)
-    const double t_end = (double)g.blk / p.fs;
-    const double trig_end = ((s.carrFreq * 2.0 * pi) * t_end) + s.remCarrPhase;
-    const double carr_next = fmod(trig_end, two_pi);
-
     const double I_E = s_sum[0], Q_E = s_sum[1], I_P = s_sum[2], Q_P = s_sum[3], I_L = s_sum[4], Q_L = s_sum[5];
     double pI_E = s_sum[6], pQ_E = s_sum[7], pI_P = s_sum[8], pQ_P = s_sum[9], pI_L = s_sum[10], pQ_L = s_sum[11];
     double cI_E = 0, cQ_E = 0, cI_P = 0, cQ_P = 0, cI_L = 0, cQ_L = 0;
@@ -762,41 +743,100 @@ __global__ __launch_bounds__(kUpdThreads) void k_trk_update(TrkParams p, ChanSta
         cI_L = -a * s_sum[16] + b * pQ_L;
         cQ_L = -a * s_sum[17] - b * pI_L;
     }
-    // ---- PLL discriminator (true division: I = 0 -> +-pi/2, 0/0 -> NaN, as MATLAB) ----------
-    double carrError = atan(Q_P / I_P) / two_pi;  // :337
-    if (p.pilot) {
-        if (MODE == BDS_TRACK_B2A) {
-            // QI = (pI + j pQ) * exp(-j pi/2); atan(imag/real)  (:345-348)
-            const double cr = cos(-pi / 2), sr = sin(-pi / 2);  // exp(-1i*pi/2) as MATLAB evaluates it
-            const double re = pI_P * cr - pQ_P * sr, im = pI_P * sr + pQ_P * cr;
-            const double cq = atan(im / re) / two_pi;
-            carrError = (carrError + cq) / 2;  // :352
-        } else if (MODE == BDS_TRACK_NB) {
-            const double cq = atan(-pI_P / pQ_P) / two_pi;  // NB:357
-            carrError = (carrError * 11 + cq * 29) / 40;    // NB:360
+    // The update is a chain of dependent f64 operations (two atan, up to six sqrt, an fmod, divisions: ~3 us on one
+    // thread, and at the head of a correlate launch every workgroup waits for it).  Its independent pieces run on four
+    // waves of the workgroup (different SIMDs), one lane each, with exactly the expressions of the serial form; thread 0
+    // then combines them in the reference's order.
+    __shared__ double s_x[6];  // data atan, pilot atan, data (E-L)/(E+L), pilot (E-L)/(E+L), next code phase, next carrier phase
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) {
+        const int w = threadIdx.x >> 6;
+        if (w == 0) {
+            s_x[0] = atan(Q_P / I_P) / two_pi;  // :337 (true division: I = 0 -> +-pi/2, 0/0 -> NaN, as MATLAB)
+        } else if (w == 1) {
+            double cq = 0.0;
+            if (p.pilot) {
+                if (MODE == BDS_TRACK_B2A) {
+                    // QI = (pI + j pQ) * exp(-j pi/2); atan(imag/real)  (:345-348)
+                    const double cr = cos(-pi / 2), sr = sin(-pi / 2);  // exp(-1i*pi/2) as MATLAB evaluates it
+                    const double re = pI_P * cr - pQ_P * sr, im = pI_P * sr + pQ_P * cr;
+                    cq = atan(im / re) / two_pi;
+                } else if (MODE == BDS_TRACK_NB) {
+                    cq = atan(-pI_P / pQ_P) / two_pi;  // NB:357
+                } else {
+                    cq = atan(cQ_P / cI_P) / two_pi;  // WB:392
+                }
+            }
+            s_x[1] = cq;
+        } else if (w == 2) {
+            const double eE = sqrt(I_E * I_E + Q_E * Q_E), eL = sqrt(I_L * I_L + Q_L * Q_L);
+            s_x[2] = (eE - eL) / (eE + eL);  // :366
+            double pce = 0.0;
+            if (p.pilot) {
+                double pE, pL;
+                if (MODE == BDS_TRACK_WB) {
+                    pE = sqrt(cI_E * cI_E + cQ_E * cQ_E);
+                    pL = sqrt(cI_L * cI_L + cQ_L * cQ_L);
+                } else {
+                    pE = sqrt(pI_E * pI_E + pQ_E * pQ_E);
+                    pL = sqrt(pI_L * pI_L + pQ_L * pQ_L);
+                }
+                pce = (pE - pL) / (pE + pL);
+            }
+            s_x[3] = pce;
         } else {
-            const double cq = atan(cQ_P / cI_P) / two_pi;  // WB:392
-            carrError = (carrError * 1 + cq * 3) / 4;      // WB:395
+            // remCodePhase = tcode(blksize) + codePhaseStep - codeLength  (:295; B1C: tcode/2, WB:327)
+            if (MODE == BDS_TRACK_B2A) {
+                const double tp_last = g.rem + (double)(g.blk - 1) * g.step;
+                s_x[4] = (tp_last + g.step) - L;
+            } else {
+                const double tp_last = g.rem * 2.0 + (double)(g.blk - 1) * (g.step * 2.0);
+                s_x[4] = tp_last / 2 + g.step - L;
+            }
+            // remCarrPhase = rem(trigarg(blksize+1), 2*pi)  (:303-305)
+            const double t_end = (double)g.blk / p.fs;
+            const double trig_end = ((s.carrFreq * 2.0 * pi) * t_end) + s.remCarrPhase;
+            s_x[5] = fmod(trig_end, two_pi);
         }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        [&] {
+    const long e = (long)ch * p.n_epochs + epoch;
+    if (g.pos + g.blk <= p.n_bytes && (g.pos < p.base || g.pos + g.blk > p.win_end)) {
+        // inside the file but outside the part of it that was loaded: nothing of this epoch is valid;
+        // the host repeats the call with the whole record in HBM
+        s.active = -2;
+        return;
+    }
+    if (store) o.absoluteSample[e] = (double)s.pos;  // tracking.m:226 (assigned before the read)
+    if (g.pos + g.blk > p.n_bytes) {
+        // short read: message + return in the reference (tracking.m:250-254); partial results stay
+        s.active = 0;
+        return;
+    }
+    if (store) o.remCodePhase[e] = s.remCodePhase;  // :258
+    if (store) o.remCarrPhase[e] = s.remCarrPhase;  // :300
+    const double rem_next = s_x[4], carr_next = s_x[5];
+    // ---- PLL discriminator ----------------------------------------------------------------------
+    double carrError = s_x[0];
+    if (p.pilot) {
+        const double cq = s_x[1];
+        if (MODE == BDS_TRACK_B2A)
+            carrError = (carrError + cq) / 2;  // :352
+        else if (MODE == BDS_TRACK_NB)
+            carrError = (carrError * 11 + cq * 29) / 40;  // NB:360
+        else
+            carrError = (carrError * 1 + cq * 3) / 4;  // WB:395
     }
     s.d2CarrError = s.d2CarrError + carrError * p.pf3;                    // :356
     s.dCarrError = s.d2CarrError + carrError * p.pf2 + s.dCarrError;      // :357
     const double carrNco = s.dCarrError + carrError * p.pf1;              // :358
-    o.carrFreq[e] = s.carrFreq;                                           // :361
+    if (store) o.carrFreq[e] = s.carrFreq;                                           // :361
     // ---- DLL discriminator ---------------------------------------------------------------------
-    const double eE = sqrt(I_E * I_E + Q_E * Q_E), eL = sqrt(I_L * I_L + Q_L * Q_L);
-    double codeError = (eE - eL) / (eE + eL);  // :366
+    double codeError = s_x[2];  // :366
     if (MODE != BDS_TRACK_B2A) codeError = codeError * (1 - p.spacing);  // WB:409-410
     if (p.pilot) {
-        double pE, pL;
-        if (MODE == BDS_TRACK_WB) {
-            pE = sqrt(cI_E * cI_E + cQ_E * cQ_E);
-            pL = sqrt(cI_L * cI_L + cQ_L * cQ_L);
-        } else {
-            pE = sqrt(pI_E * pI_E + pQ_E * pQ_E);
-            pL = sqrt(pI_L * pI_L + pQ_L * pQ_L);
-        }
-        const double pce = (pE - pL) / (pE + pL);
+        const double pce = s_x[3];
         if (MODE == BDS_TRACK_B2A)
             codeError = (codeError + pce) / 2;  // :377
         else if (MODE == BDS_TRACK_NB)
@@ -807,28 +847,28 @@ __global__ __launch_bounds__(kUpdThreads) void k_trk_update(TrkParams p, ChanSta
     const double codeNco = s.oldCodeNco + (p.tau2 / p.tau1) * (codeError - s.oldCodeError) + codeError * (p.pdi / p.tau1);  // :381
     s.oldCodeNco = codeNco;
     s.oldCodeError = codeError;
-    o.codeFreq[e] = s.codeFreq;  // :387
-    o.dllDiscr[e] = codeError;
-    o.dllDiscrFilt[e] = codeNco;
-    o.pllDiscr[e] = carrError;
-    o.pllDiscrFilt[e] = carrNco;
-    o.I_E[e] = I_E;
-    o.I_P[e] = I_P;
-    o.I_L[e] = I_L;
-    o.Q_E[e] = Q_E;
-    o.Q_P[e] = Q_P;
-    o.Q_L[e] = Q_L;
+    if (store) o.codeFreq[e] = s.codeFreq;  // :387
+    if (store) o.dllDiscr[e] = codeError;
+    if (store) o.dllDiscrFilt[e] = codeNco;
+    if (store) o.pllDiscr[e] = carrError;
+    if (store) o.pllDiscrFilt[e] = carrNco;
+    if (store) o.I_E[e] = I_E;
+    if (store) o.I_P[e] = I_P;
+    if (store) o.I_L[e] = I_L;
+    if (store) o.Q_E[e] = Q_E;
+    if (store) o.Q_P[e] = Q_P;
+    if (store) o.Q_L[e] = Q_L;
     if (p.pilot) {
         if (MODE == BDS_TRACK_WB) {
-            o.Pilot_I_E[e] = cI_E;
-            o.Pilot_Q_E[e] = cQ_E;
-            o.Pilot_I_P[e] = cI_P;
-            o.Pilot_Q_P[e] = cQ_P;
-            o.Pilot_I_L[e] = cI_L;
-            o.Pilot_Q_L[e] = cQ_L;
+            if (store) o.Pilot_I_E[e] = cI_E;
+            if (store) o.Pilot_Q_E[e] = cQ_E;
+            if (store) o.Pilot_I_P[e] = cI_P;
+            if (store) o.Pilot_Q_P[e] = cQ_P;
+            if (store) o.Pilot_I_L[e] = cI_L;
+            if (store) o.Pilot_Q_L[e] = cQ_L;
         } else {
-            o.Pilot_I_P[e] = pI_P;
-            o.Pilot_Q_P[e] = pQ_P;
+            if (store) o.Pilot_I_P[e] = pI_P;
+            if (store) o.Pilot_Q_P[e] = pQ_P;
         }
     }
     s.carrFreq = s.carrFreqBasis + carrNco;   // :363
@@ -837,7 +877,22 @@ __global__ __launch_bounds__(kUpdThreads) void k_trk_update(TrkParams p, ChanSta
     s.remCarrPhase = carr_next;
     s.pos += g.blk;
     s.completed = epoch + 1;
-    st[ch] = s;
+        }();
+        s_next = s;
+    }
+    __syncthreads();
+    s = s_next;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kUpdThreads) void k_trk_update(TrkParams p, ChanState *__restrict__ st,
+                                                   const double *__restrict__ part, int nblocks, int epoch,
+                                                   TrkOut o) {
+    const int ch = blockIdx.x;
+    ChanState s = st[ch];
+    if (s.active != 1) return;
+    apply_update<MODE>(p, s, part, ch, nblocks, epoch, o, true);
+    if (threadIdx.x == 0) st[ch] = s;
 }
 
 struct TrackState {
@@ -1121,11 +1176,15 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &loa
                 if (q) (void)hipFree(q);
         }
     } scope;
+    // state and partial sums ping-pong between two buffers when the loop update rides at the head of the next epoch's
+    // correlate launch (default); with BDS_TRK_NOFUSE_UPDATE both halves are the same buffer and the update is its own launch
+    const bool fuse = !ctx->tune.trk_nofuse_update;
     ChanState *d_st = nullptr;
     double *d_part = nullptr;
-    BDS_HIP(ctx, hipMalloc((void **)&d_st, sizeof(ChanState) * n_ch));
+    BDS_HIP(ctx, hipMalloc((void **)&d_st, sizeof(ChanState) * n_ch * 2));
     scope.add(d_st);
-    BDS_HIP(ctx, hipMalloc((void **)&d_part, sizeof(double) * (size_t)n_ch * nblocks * kNSums));
+    const size_t part_n = (size_t)n_ch * nblocks * kNSums;
+    BDS_HIP(ctx, hipMalloc((void **)&d_part, sizeof(double) * part_n * 2));
     scope.add(d_part);
     BDS_HIP(ctx, hipMemcpyAsync(d_st, hs.data(), sizeof(ChanState) * n_ch, hipMemcpyHostToDevice, st(ctx)));
     // device result arrays, initialised like the reference template (tracking.m:48-82)
@@ -1157,23 +1216,43 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &loa
     BDS_HIP(ctx, hipEventRecord(ev0, st(ctx)));
     const int8_t *data = t.d_data;
     dim3 gc(nblocks, n_ch);
-    for (int k = 0; k < n_epochs; ++k) {
-        BDS_TRK_LAUNCH(k_trk_correlate, gc, (p.runs ? runs_lds_bytes(p.runs) : 0), st(ctx), data, (const int8_t *)t.d_prim, p, (const ChanState *)d_st, d_part, nblocks);
+    TrkOut *d_out = nullptr;  // the table of result arrays, for the correlate launches that carry the previous epoch's update
+    BDS_HIP(ctx, hipMalloc((void **)&d_out, sizeof(TrkOut)));
+    scope.add(d_out);
+    BDS_HIP(ctx, hipMemcpyAsync(d_out, &d, sizeof(TrkOut), hipMemcpyHostToDevice, st(ctx)));
+    auto launch_update = [&](ChanState *stp, const double *partp, int k) {
         switch (p.mode) {
             case BDS_TRACK_B2A:
-                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_B2A>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
+                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_B2A>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, stp, partp, nblocks, k, d);
                 break;
             case BDS_TRACK_NB:
-                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_NB>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
+                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_NB>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, stp, partp, nblocks, k, d);
                 break;
             default:
-                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_WB>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, d_st, (const double *)d_part, nblocks, k, d);
+                hipLaunchKernelGGL(k_trk_update<BDS_TRACK_WB>, dim3(n_ch), dim3(kUpdThreads), 0, st(ctx), p, stp, partp, nblocks, k, d);
                 break;
+        }
+    };
+    ChanState *st_final = d_st;  // where the state ends up
+    for (int k = 0; k < n_epochs; ++k) {
+        if (fuse) {
+            const int cur = k & 1;
+            ChanState *st_in = d_st + (size_t)cur * n_ch, *st_out = d_st + (size_t)(cur ^ 1) * n_ch;
+            const double *part_prev = k > 0 ? d_part + (size_t)(cur ^ 1) * part_n : nullptr;
+            double *part_cur = d_part + (size_t)cur * part_n;
+            BDS_TRK_LAUNCH(k_trk_correlate, gc, (p.runs ? runs_lds_bytes(p.runs) : 0), st(ctx), data, (const int8_t *)t.d_prim, p,
+                           (const ChanState *)st_in, st_out, part_prev, part_cur, nblocks, k, (const TrkOut *)d_out);
+            st_final = st_out;
+            if (k == n_epochs - 1) launch_update(st_final, part_cur, k);  // the last epoch's update has no next launch to ride on
+        } else {
+            BDS_TRK_LAUNCH(k_trk_correlate, gc, (p.runs ? runs_lds_bytes(p.runs) : 0), st(ctx), data, (const int8_t *)t.d_prim, p,
+                           (const ChanState *)d_st, d_st, (const double *)nullptr, d_part, nblocks, k, (const TrkOut *)d_out);
+            launch_update(d_st, d_part, k);
         }
     }
     BDS_HIP(ctx, hipGetLastError());
     BDS_HIP(ctx, hipEventRecord(ev1, st(ctx)));
-    BDS_HIP(ctx, hipMemcpyAsync(hs.data(), d_st, sizeof(ChanState) * n_ch, hipMemcpyDeviceToHost, st(ctx)));
+    BDS_HIP(ctx, hipMemcpyAsync(hs.data(), st_final, sizeof(ChanState) * n_ch, hipMemcpyDeviceToHost, st(ctx)));
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
     float ms = 0;
     BDS_HIP(ctx, hipEventElapsedTime(&ms, ev0, ev1));
