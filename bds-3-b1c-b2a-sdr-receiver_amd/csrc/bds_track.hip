@@ -4,15 +4,17 @@
 // BDS-3_B1C/WB_tracking.m:114-488 (the per-channel, per-epoch MATLAB loops), plus the
 // C/N0 + lock-detector post-pass of include/Calc_CNo_PLD.m.
 //
-// Structure: the IF record lives in HBM (int8).  Every epoch is two launches on one stream:
-//   k_trk_correlate  grid (blocks, channels): every block re-derives the epoch geometry
-//                    (blksize, code / carrier NCO start values) from the channel's f64 loop
-//                    state, walks its slice of the block of samples and emits 6/12/18 partial
-//                    correlator sums (per-thread fp32 over <= 32 samples, f64 from there on;
-//                    wave reduction by DPP shuffles, one LDS hop per workgroup)
-//   k_trk_update     one workgroup per channel: fixed-order sum of the partials, the
-//                    discriminators and loop filters in f64 exactly in the reference's
-//                    operation order, result arrays at epoch k, next NCO state
+// Structure: the window of the IF record the channels can touch lives in HBM (int8).  Every epoch is ONE launch:
+//   k_trk_correlate  grid (workgroups, channels).  Head: every workgroup applies the loop update of the previous
+//                    epoch to the channel state (apply_update: fixed-order sum of that epoch's partial sums, the
+//                    discriminators and loop filters in f64 exactly in the reference's operation order; workgroup 0
+//                    writes the result arrays and the new state; state and partial sums ping-pong between buffers).
+//                    Body: the workgroup re-derives the epoch geometry (blksize, code / carrier NCO start values)
+//                    from the f64 state and emits its 6/12/18 partial correlator sums -- correlate_runs (default:
+//                    prefix sums of the carrier-wiped samples + an exact search of the code-index steps) or
+//                    correlate_slice (per sample, BDS_TRK_PERSAMPLE)
+//   k_trk_update     apply_update as its own launch: closes the last epoch (and every epoch with
+//                    BDS_TRK_NOFUSE_UPDATE)
 // The host enqueues all epochs back to back and never synchronises inside the loop: the
 // sequential dependence (next blksize / phases depend on this epoch's discriminators) is
 // carried entirely by device memory.

@@ -145,7 +145,7 @@ def tracking_leg(name, local_rank, base):
             "int8_read_GBps": samples / (dev_ms * 1e-3) / 1e9,  # one byte per sample per channel (algorithmic)
             "correlator_GMACs": samples * macs / (dev_ms * 1e-3) / 1e9, "macs_per_sample": macs,
             "channels_locked": locked,
-            "note": "device time of the epoch loop (two dependent launches per epoch, record window in HBM); locked synthetic record "
+            "note": "device time of the epoch loop (one launch per epoch: correlate + the previous epoch's loop update; record window in HBM); locked synthetic record "
                     "(12 satellites at 47 dB-Hz, one block of whole code periods repeated)"}
 
 
