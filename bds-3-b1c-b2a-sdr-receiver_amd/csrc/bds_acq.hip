@@ -46,6 +46,7 @@ struct Plan2D {
     size_t lds_cols = 0, lds_rows = 0;
     bool fast = false;  // both lengths have compile-time specialised search kernels (bds_acq_fast.h)
     float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_hi = nullptr, *d_lo = nullptr;
+    float2 *d_ftab1 = nullptr, *d_ftab2 = nullptr;  // fp32 stage-twiddle tables of the inverse column / row transform
     h2 *d_htab1 = nullptr, *d_htab2 = nullptr;  // fp16 stage-twiddle tables of the column / row transform
     double hscale1 = 1, hscale2 = 1;            // product of the stage scales folded into them
 };
@@ -150,7 +151,7 @@ static int threads_for(const Plan1D &p, int T) {
 }
 
 static void plan_free(Plan2D &pl) {
-    for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo})
+    for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo, &pl.d_ftab1, &pl.d_ftab2})
         if (*p) (void)hipFree(*p), *p = nullptr;
     for (h2 **p : {&pl.d_htab1, &pl.d_htab2})
         if (*p) (void)hipFree(*p), *p = nullptr;
@@ -181,6 +182,26 @@ static int upload_half_tables(bds_ctx *ctx, const Plan1D &p, h2 **dptr, double *
     if (h.empty()) h.push_back(h2{(_Float16)1, (_Float16)0});
     BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(h2) * h.size()));
     BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(h2) * h.size(), hipMemcpyHostToDevice));
+    return BDS_OK;
+}
+
+// fp32 stage tables of an inverse transform: the layout of the fp16 ones, entries exp(+2 pi j q k / (NS R)) unscaled
+static int upload_stage_tables_f32(bds_ctx *ctx, const Plan1D &p, float2 **dptr) {
+    std::vector<float2> h;
+    int ns = 1;
+    for (int s = 0; s < p.nstage; ++s) {
+        const int R = p.radix[s];
+        if (ns > 1)
+            for (int q = 0; q < R; ++q)
+                for (int k = 0; k < ns; ++k) {
+                    const double a = 2.0 * kPi * (double)((long)q * k) / (double)((long)ns * R);
+                    h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+                }
+        ns *= R;
+    }
+    if (h.empty()) h.push_back(make_float2(1.f, 0.f));
+    BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * h.size()));
+    BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
     return BDS_OK;
 }
 
@@ -241,6 +262,8 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
     if (pl.fast) {
         if ((rc = upload_half_tables(ctx, pl.p1, &pl.d_htab1, &pl.hscale1))) return rc;
         if ((rc = upload_half_tables(ctx, pl.p2, &pl.d_htab2, &pl.hscale2))) return rc;
+        if ((rc = upload_stage_tables_f32(ctx, pl.p1, &pl.d_ftab1))) return rc;
+        if ((rc = upload_stage_tables_f32(ctx, pl.p2, &pl.d_ftab2))) return rc;
     }
     pl.p1.tw = pl.d_tw1;
     pl.p2.tw = pl.d_tw2;
@@ -549,22 +572,22 @@ struct SieveOut {
 template <int S, int NC, class ST>
 static void launch_rows_f(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs,
                           void *Bw, float out_scale, const CellList &cl) {
-    const size_t lds = sizeof(float2) * (tspan<S>() + lds_span(twiddle_entries<S>()));
+    const size_t lds = sizeof(float2) * (tspan<S>() + f32_tw_span<S, kF32TabRows>());
     want_lds(ctx, k_rows_inv_f<S, NC, ST>, lds);
     // balanced chunks of at most tune.gchunk cells
     int nch = (G + ctx->tune.gchunk - 1) / ctx->tune.gchunk;
     int gc = (G + nch - 1) / nch;
     if (cl.bin) gc = cl.gc, nch = (G + cl.gc - 1) / cl.gc;  // a workgroup stays inside one PRN's cells
     const int nvb = pl.L1 * nch;  // L1 % 8 == 0 on every specialised plan: virtual workgroup vb sits on XCD vb % 8
-    const RowsFArgs A{(const float2 *)pl.d_tw2, pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs, nvb};
+    const RowsFArgs A{(const float2 *)(kF32TabRows ? pl.d_ftab2 : pl.d_tw2), pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs, nvb};
     const int grid = ctx->tune.rows_grid > 0 ? std::min(nvb, (ctx->tune.rows_grid + 7) / 8 * 8) : nvb;
     hipLaunchKernelGGL((k_rows_inv_f<S, NC, ST>), dim3(grid), dim3(rows_threads<S>()), lds, sr, A);
 }
 template <int S, int T, int NC, class ST>
 static void launch_cols_ft(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1,
                            int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl) {
-    const size_t lds = sizeof(float2) * (T * tspan<S>() + lds_span(twiddle_entries<S>()));
-    const ColsFArgs A{(const float2 *)pl.d_tw1, pl.L2, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, so.recs, pl.ntiles, cl.rng,
+    const size_t lds = sizeof(float2) * (T * tspan<S>() + f32_tw_span<S, f32_tab_cols<S>()>());
+    const ColsFArgs A{(const float2 *)(f32_tab_cols<S>() ? pl.d_ftab1 : pl.d_tw1), pl.L2, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, so.recs, pl.ntiles, cl.rng,
                       so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep};
     const bool masked = cl.rng || !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
     if (masked) {

@@ -37,6 +37,30 @@
 
 namespace bds {
 
+// Per-stage [q][k] twiddle tables in LDS for the inverse fp32 transforms (bds_fft_t.h tstage TAB) instead of the W_S
+// table + products: -44 vector instructions per radix-16 butterfly and twiddled stage for 8-35 KB of LDS and 11 more
+// LDS reads.  Measured on cfg3: column pass 2.32 vs 2.38 ms, row pass 2.12 vs 2.10 ms (its LDS pipe is as busy as its
+// vector unit) -- so the column pass takes the tables and the row pass keeps the products.
+#ifndef BDS_F32_TAB_COLS
+#define BDS_F32_TAB_COLS 1
+#endif
+#ifndef BDS_F32_TAB_ROWS
+#define BDS_F32_TAB_ROWS 0
+#endif
+static constexpr bool kF32TabRows = BDS_F32_TAB_ROWS != 0;
+// column pass: only the 768-point plan (cfg3) -- the 256-point kernel, whose twiddled stage is also its register-heavy
+// last stage, spills 25 VGPRs with the tables and runs 2x slower (cfg2: 2.95 vs 1.43 ms)
+template <int S>
+__host__ __device__ constexpr bool f32_tab_cols() {
+    return BDS_F32_TAB_COLS != 0 && S == 768;
+}
+// float2 entries of the twiddle area behind the data in LDS
+template <int S, bool TAB>
+__host__ __device__ constexpr int f32_tw_span() {
+    return TAB ? half_table_entries<S>() : lds_span(twiddle_entries<S>());
+}
+
+
 typedef float f2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ h2 as_h2(uint32_t u) { return __builtin_bit_cast(h2, u); }
@@ -89,7 +113,10 @@ __device__ __forceinline__ void rows_inv_f_body(const RowsFArgs &A, int vb, int 
     extern __shared__ __attribute__((aligned(16))) float2 ldsf[];  // tspan<S>() data + twiddle table
     __shared__ float2 s_a[MBL], s_b[RL];
     float2 *tw_lds = ldsf + tspan<S>();
-    load_twiddles<S, NT>(tw_lds, A.tw, tid);
+    if constexpr (kF32TabRows)
+        load_stage_tables<S, NT>(tw_lds, A.tw, tid);
+    else
+        load_twiddles<S, NT>(tw_lds, A.tw, tid);
     const long L = A.L;
     const int xcd = vb & 7, m = vb >> 3;
     const int GC = A.GC, NCH = A.NCH;
@@ -185,7 +212,7 @@ __device__ __forceinline__ void rows_inv_f_body(const RowsFArgs &A, int vb, int 
             auto next = [&]() {
                 if (comp == NCOMP - 1 && g + 1 < g1) fetch_x(g + 1);
             };
-            TPlan<S>::template run_hook<1, NT, +1>(ldsf, (const float2 *)tw_lds, tid, src, out, next);
+            TPlan<S>::template run_hook<1, NT, +1, kF32TabRows>(ldsf, (const float2 *)tw_lds, tid, src, out, next);
             if (comp + 1 < NCOMP || g + 1 < g1) BDS_SYNC();  // last-stage reads precede the next first-stage writes
         }
     }
@@ -252,7 +279,10 @@ __device__ __forceinline__ void cols_inv_max_f_body(const ColsFArgs &A, int tb, 
     constexpr int TOTL = NSL * T, MBL = (TOTL + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) float2 ldsf[];  // T * SP data + twiddle table
     float2 *tw_lds = ldsf + T * SP;
-    load_twiddles<S, NT>(tw_lds, A.tw, tid);
+    if constexpr (f32_tab_cols<S>())
+        load_stage_tables<S, NT>(tw_lds, A.tw, tid);
+    else
+        load_twiddles<S, NT>(tw_lds, A.tw, tid);
     __shared__ float s_v[NW];
     __shared__ int s_cnt;
     if (tid == 0) s_cnt = 0;
@@ -310,7 +340,7 @@ __device__ __forceinline__ void cols_inv_max_f_body(const ColsFArgs &A, int tb, 
                 mag[i][q] = comp == 0 ? a : mag[i][q] + a;
             }
         };
-        TPlan<S>::template run<T, NT, +1>(ldsf, (const float2 *)tw_lds, tid, LdsIO{}, out);
+        TPlan<S>::template run<T, NT, +1, f32_tab_cols<S>()>(ldsf, (const float2 *)tw_lds, tid, LdsIO{}, out);
         if (comp + 1 < NCOMP) BDS_SYNC();  // last-stage reads done before the tile is overwritten
     }
     // lag of output (i, q): (bb + q NSL) L2 + c0 + j with b = tid + i NT, j = b / NSL, bb = b % NSL

@@ -43,7 +43,7 @@ __host__ __device__ constexpr float stage_scale(int R) { return R == 16 ? 0.25f 
 // JFAST: butterfly slot b -> (transform j = b % T, butterfly bb = b / T) instead of (j = b / NB, bb = b % NB):
 // adjacent lanes then work on ADJACENT transforms (columns), which is what a first stage fed straight from a
 // row-major global tile wants (T must be a power of two).
-template <class C, int S, int T, int NT, int DIR, int NS, int R, int TWOFF, class Src, class Dst, bool JFAST = false>
+template <class C, int S, int T, int NT, int DIR, int NS, int R, int TWOFF, class Src, class Dst, bool JFAST = false, bool TAB = false>
 __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict__ tw, int tid, Src src, Dst dst) {
     constexpr int NB = S / R;
     constexpr int TOTAL = NB * T;
@@ -96,6 +96,12 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
 #pragma unroll
                     for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], tk[q * NS]);
                     v[i][0] = cscale(v[i][0], stage_scale(R));
+                } else if constexpr (TAB) {
+                    // fp32 with per-stage tables (stage_tables_f32 on the host: [q][k], already in the transform
+                    // direction): 15 LDS reads instead of 4 reads + 11 complex products per radix-16 butterfly
+                    const C *tk = tw + TWOFF + kidx[i];
+#pragma unroll
+                    for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], tk[q * NS]);
                 } else {
                     const int kt = kidx[i] * TWS;
                     if constexpr (R == 16 || R == 8) {
@@ -151,15 +157,15 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
-template <class C, int S, int T, int NT, int DIR, int NS, int TWOFF, bool JFAST, class Src, class Dst, class Hook, int R, int... REST>
+template <class C, int S, int T, int NT, int DIR, int NS, int TWOFF, bool JFAST, bool TAB, class Src, class Dst, class Hook, int R, int... REST>
 __device__ __forceinline__ void tfft_run(C *__restrict__ buf, const C *__restrict__ tw, int tid, Src src, Dst dst, Hook hook) {
     if constexpr (sizeof...(REST) == 0) {
-        tstage<C, S, T, NT, DIR, NS, R, TWOFF, Src, Dst, JFAST>(buf, tw, tid, src, dst);
+        tstage<C, S, T, NT, DIR, NS, R, TWOFF, Src, Dst, JFAST, TAB>(buf, tw, tid, src, dst);
         hook();
     } else {
-        tstage<C, S, T, NT, DIR, NS, R, TWOFF, Src, LdsIO, JFAST>(buf, tw, tid, src, LdsIO{});
+        tstage<C, S, T, NT, DIR, NS, R, TWOFF, Src, LdsIO, JFAST, TAB>(buf, tw, tid, src, LdsIO{});
         hook();
-        tfft_run<C, S, T, NT, DIR, NS * R, TWOFF + (NS > 1 ? NS * R : 0), false, LdsIO, Dst, NoHook, REST...>(buf, tw, tid, LdsIO{}, dst, NoHook{});
+        tfft_run<C, S, T, NT, DIR, NS * R, TWOFF + (NS > 1 ? NS * R : 0), false, TAB, LdsIO, Dst, NoHook, REST...>(buf, tw, tid, LdsIO{}, dst, NoHook{});
     }
 }
 
@@ -173,6 +179,10 @@ __device__ __forceinline__ void load_twiddles(float2 *__restrict__ tw_lds, const
     for (int i = tid; i < twiddle_entries<S>(); i += NT) tw_lds[lds_phys(i)] = tw[i];
 }
 
+// fp32 stage tables (same layout as the fp16 ones below, unscaled): linear copy into LDS
+template <int S, int NT>
+__device__ __forceinline__ void load_stage_tables(float2 *__restrict__ tw_lds, const float2 *__restrict__ tab, int tid);
+
 // fp16 stage-twiddle tables: for every stage after the first, [q][k] (q < R, k < NS) entries
 // stage_scale(R) * exp(+2 pi j q k / (NS R)) (inverse direction), concatenated in stage order.
 template <int S>
@@ -184,18 +194,18 @@ struct TPlan;
 #define BDS_TPLAN(S_, ...)                                                                         \
     template <>                                                                                    \
     struct TPlan<S_> {                                                                             \
-        template <int T, int NT, int DIR, class C, class Src, class Dst>                           \
+        template <int T, int NT, int DIR, bool TAB = false, class C, class Src, class Dst>         \
         __device__ __forceinline__ static void run(C *buf, const C *tw, int tid, Src src, Dst dst) { \
-            tfft_run<C, S_, T, NT, DIR, 1, 0, false, Src, Dst, NoHook, __VA_ARGS__>(buf, tw, tid, src, dst, NoHook{}); \
+            tfft_run<C, S_, T, NT, DIR, 1, 0, false, TAB, Src, Dst, NoHook, __VA_ARGS__>(buf, tw, tid, src, dst, NoHook{}); \
         }                                                                                          \
         /* first stage with adjacent lanes on adjacent transforms (tstage JFAST) */                \
         template <int T, int NT, int DIR, class C, class Src, class Dst, class Hook>               \
         __device__ __forceinline__ static void run_jfast(C *buf, const C *tw, int tid, Src src, Dst dst, Hook hook) { \
-            tfft_run<C, S_, T, NT, DIR, 1, 0, true, Src, Dst, Hook, __VA_ARGS__>(buf, tw, tid, src, dst, hook); \
+            tfft_run<C, S_, T, NT, DIR, 1, 0, true, false, Src, Dst, Hook, __VA_ARGS__>(buf, tw, tid, src, dst, hook); \
         }                                                                                          \
-        template <int T, int NT, int DIR, class C, class Src, class Dst, class Hook>               \
+        template <int T, int NT, int DIR, bool TAB = false, class C, class Src, class Dst, class Hook> \
         __device__ __forceinline__ static void run_hook(C *buf, const C *tw, int tid, Src src, Dst dst, Hook hook) { \
-            tfft_run<C, S_, T, NT, DIR, 1, 0, false, Src, Dst, Hook, __VA_ARGS__>(buf, tw, tid, src, dst, hook); \
+            tfft_run<C, S_, T, NT, DIR, 1, 0, false, TAB, Src, Dst, Hook, __VA_ARGS__>(buf, tw, tid, src, dst, hook); \
         }                                                                                          \
         static constexpr int kRadix[] = {__VA_ARGS__};                                             \
     };
@@ -234,6 +244,11 @@ __host__ __device__ constexpr int half_table_entries() {
         ns *= r;
     }
     return n;
+}
+
+template <int S, int NT>
+__device__ __forceinline__ void load_stage_tables(float2 *__restrict__ tw_lds, const float2 *__restrict__ tab, int tid) {
+    for (int i = tid; i < half_table_entries<S>(); i += NT) tw_lds[i] = tab[i];
 }
 
 }  // namespace bds

@@ -1,0 +1,18 @@
+#!/bin/bash
+# A/B: per-stage fp32 twiddle tables in LDS (default) vs W_S table + products (variant notab = -DBDS_F32_TAB_COLS=0)
+cd "$GRAFT_REPO_ROOT"
+P=${PRNS:-8}
+run() {
+  env "$@" timeout 600 python bench.py --workload ${W:-b1c} --prns $P --steps 2 --warmup 1 --no-cpu-baseline --no-tracking --no-fast-path 2>&1 | python -c "
+import sys,json
+tag=sys.argv[1]
+for l in sys.stdin:
+    if l.startswith('{'):
+        j=json.loads(l); r=j['roofline']; print(tag.ljust(50), 'step', round(j['ms_per_step'],2), 'pair', round(r['pair_ms'],3), 'rows', round(r.get('rows_ms') or 0,3), 'cols', round(r.get('cols_ms') or 0,3), 'frac', round(r['frac'],3), 'det', j['config']['satellites_detected'])
+    elif 'amdgpu.ids' not in l: print(l.rstrip())
+" "$*"
+}
+run BDS_X=0
+run BDS_LIB_PATH=tools/variants/libbds_notab.so
+run BDS_X=0
+run BDS_LIB_PATH=tools/variants/libbds_notab.so
