@@ -335,6 +335,7 @@ def main():
                    "parallelism": f"(signal, PRN) job shard x{world}, LPT by cost; one all-reduce(SUM) of 3 x 63 f64 per signal",
                    "jobs": sum(len(set(int(p) for p in g["s"].acqSatelliteList)) for g in sigs),
                    "jobs_rank0": {g["name"]: len(g["shard"]) for g in sigs},
+                   "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size()} if dist is not None else None),
                    "satellites_injected": sorted(sat.prn for sat in sats), "satellites_detected": detected},
         "block_msps": n_circ / (dt / args.steps) / 1e6,
         "whole_job_algorithmic_GBps": b_alg / (dt / args.steps) / 1e9,

@@ -52,6 +52,7 @@ def test_bench_two_ranks_self_spawn():
     assert 0 < two["config"]["jobs_rank0"]["b2a"] < 63 and two["config"]["jobs"] == 63
     assert two["config"]["satellites_detected"] == one["config"]["satellites_detected"]
     assert two["cpu_baseline"] is None  # rank 0 at N = 1 only
+    assert two["config"]["collective"] == {"backend": "gloo", "ranks": 2} and one["config"]["collective"] is None
 
 
 def test_bench_joint_two_ranks():
