@@ -188,3 +188,41 @@ def test_low_sampling_rates_and_both_correlators(ctx, monkeypatch, signal, mode,
         p = np.hypot(t["sums"][2], t["sums"][3])
         np.testing.assert_allclose(g, t["sums"], rtol=0, atol=1e-6 * p)
         np.testing.assert_allclose(g, q, rtol=0, atol=1e-6 * p)
+
+
+@pytest.mark.parametrize("mode,iq", [("WB", False), ("NB", True), ("B2A", False), ("B2A", True)])
+def test_random_states_at_full_rate_both_correlators(ctx, monkeypatch, mode, iq):
+    """99.375 MS/s (the rate of BASELINE.json's configs: code-table slices in LDS, ~21 half-chip and ~127 BOC(6,1) steps
+    per replica and pass): random open-loop states -- code phase, code / carrier frequency, carrier phase, start sample,
+    block lengths that end inside a segment -- through the run-based and the per-sample correlator.  Both evaluate the
+    reference's index expression for every sample, so the sums may differ by the summation order only."""
+    rng = np.random.default_rng(77)
+    if mode == "B2A":
+        s = bds_amd.init_settings_b2a(msToProcess=4, numberOfChannels=4, fileType=2 if iq else 1)
+        spc, L = 99375, 10230
+    else:
+        s = bds_amd.init_settings_b1c(samplingFreq=99.375e6, IF=14.58e6, msToProcess=40, numberOfChannels=4,
+                                      pilotTRKflag=2 if mode == "WB" else 1, fileType=2 if iq else 1)
+        spc, L = 993750, 10230
+    n = 3 * spc
+    x = np.clip(np.rint(rng.normal(0, 25, n * (2 if iq else 1))), -127, 127).astype(np.int8)
+    prn, st = [], []
+    for c in range(8):
+        code_freq = s.codeFreqBasis * (1 + rng.uniform(-3e-6, 3e-6))
+        rem = rng.uniform(-0.4, 0.4) if c else 0.0
+        blk = int(np.ceil((L - rem) / (code_freq / s.samplingFreq)))
+        if c % 3 == 2:
+            blk -= int(rng.integers(1, 5000))  # an arbitrary block length: the last pass ends inside a segment
+        prn.append(int(rng.integers(1, 64)))
+        st.append([int(rng.integers(0, spc)), blk, rem, code_freq, rng.uniform(0, 2 * np.pi), s.IF + rng.uniform(-5000, 5000)])
+    runs = ctx.track_correlate(s, x, prn, st)
+    monkeypatch.setenv("BDS_TRK_PERSAMPLE", "1")
+    ctx.reload_tuning()
+    try:
+        per_sample = ctx.track_correlate(s, x, prn, st)
+    finally:
+        monkeypatch.delenv("BDS_TRK_PERSAMPLE")
+        ctx.reload_tuning()
+    scale = np.abs(per_sample).max() + 127.0 * np.sqrt(spc)  # noise-only record: the size of a correlator sum
+    np.testing.assert_allclose(runs, per_sample, rtol=0, atol=2e-7 * scale)
+    assert np.abs(per_sample[:, :6]).max() > 0
