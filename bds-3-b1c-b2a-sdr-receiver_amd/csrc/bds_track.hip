@@ -50,6 +50,10 @@ struct ChanState {
     int pad;
 };
 
+static constexpr int kUpdGroups = 14;    // groups of correlate workgroups in the fixed-order sum of the partial sums
+static constexpr int kUpdThreads = 256;  // >= kUpdGroups * kNSums
+static constexpr int kUpdScratch = (1 + kUpdGroups) * kNSums * 8 + 48 + (int)sizeof(ChanState);  // LDS bytes of apply_update
+
 struct TrkParams {
     int mode;        // BDS_TRACK_*
     int pilot;       // pilot correlators on
@@ -235,7 +239,16 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
 //            LDS; the segment totals are scanned in f64 over the workgroup (segment bases)
 //   phase 2  the index steps of the six (E/P/L x {code, BOC(6,1)}) sequences are spread over the
 //            threads; each finds its k_u, reads S(k_u) = base + local prefix and adds its term in f64
-static constexpr int kCap1 = 256, kCap6 = 1280;  // code / BOC(6,1) table entries of a wave's pass staged in LDS
+#ifndef BDS_TRK_CAP1
+#define BDS_TRK_CAP1 256
+#endif
+#ifndef BDS_TRK_CAP6
+#define BDS_TRK_CAP6 1280
+#endif
+#ifndef BDS_TRK_MINW
+#define BDS_TRK_MINW 1
+#endif
+static constexpr int kCap1 = BDS_TRK_CAP1, kCap6 = BDS_TRK_CAP6;  // code / BOC(6,1) table entries of a wave's pass staged in LDS
 template <int R6>
 __device__ __forceinline__ double code_arg(double st, double inc, int k) {
     double v = st + (double)k * inc;  // two roundings (-ffp-contract=off), as the reference's colon vector
@@ -606,7 +619,7 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
 // grid (nblocks, n_ch); part: [n_ch][nblocks][18]
 template <int MODE>
 __device__ __forceinline__ void apply_update(const TrkParams &p, ChanState &s, const double *__restrict__ part, int ch,
-                                             int nblocks, int epoch, const TrkOut &o, bool store);
+                                             int nblocks, int epoch, const TrkOut &o, bool store, unsigned char *scratch);
 
 // One kernel per (tracker, correlator variant, record type): a kernel holding all variants ran out of SGPRs
 // (150 spilled in wide-band mode, each a lane write + read on the vector unit).
@@ -616,7 +629,7 @@ __device__ __forceinline__ void apply_update(const TrkParams &p, ChanState &s, c
 // floor of a small dependent launch).  State and partial sums ping-pong between two buffers; workgroup 0 of the channel
 // writes the results of the previous epoch and the state the current one starts from.
 template <int MODE, int SEG, bool CPLX>
-__global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__restrict__ data,
+__global__ __launch_bounds__(kTrkThreads, BDS_TRK_MINW) void k_trk_correlate(const int8_t *__restrict__ data,
                                                               const int8_t *__restrict__ prim, TrkParams p,
                                                               const ChanState *__restrict__ st_in, ChanState *__restrict__ st_out,
                                                               const double *__restrict__ part_prev, double *__restrict__ part,
@@ -624,7 +637,15 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate(const int8_t *__r
     const int ch = blockIdx.y;
     ChanState s = st_in[ch];
     // (the table of result arrays comes by pointer: 21 pointers by value cost this kernel 40 SGPRs it does not have)
-    if (part_prev && s.active == 1) apply_update<MODE>(p, s, part_prev, ch, nblocks, epoch - 1, *op, blockIdx.x == 0);
+    if (part_prev && s.active == 1) {
+        if constexpr (SEG > 0) {  // the update's scratch sits in the dynamic region the correlator takes over afterwards
+            extern __shared__ __attribute__((aligned(16))) unsigned char trk_lds[];
+            apply_update<MODE>(p, s, part_prev, ch, nblocks, epoch - 1, *op, blockIdx.x == 0, trk_lds);
+        } else {
+            __shared__ __attribute__((aligned(16))) unsigned char scratch[kUpdScratch];
+            apply_update<MODE>(p, s, part_prev, ch, nblocks, epoch - 1, *op, blockIdx.x == 0, scratch);
+        }
+    }
     if (st_out != st_in && blockIdx.x == 0 && threadIdx.x == 0) st_out[ch] = s;  // the state this epoch runs with
     double *out = part + ((long)ch * nblocks + blockIdx.x) * kNSums;
     if (s.active != 1) return;
@@ -700,17 +721,17 @@ __global__ void k_trk_reduce_open(const double *__restrict__ part, int nblocks, 
 
 // one workgroup per channel: kUpdGroups x 18 threads add up the correlate workgroups' partial sums,
 // thread 0 then runs the loop filters
-static constexpr int kUpdGroups = 14;
-static constexpr int kUpdThreads = 256;  // >= kUpdGroups * kNSums
 // Loop update of one channel, run by a whole workgroup (>= kUpdGroups * 18 threads): `s` is the state the epoch was
 // correlated with, `part` that epoch's partial sums; every thread returns with the next state in `s`.  The result
 // arrays of the epoch are written only if `store` (one workgroup per channel).
 template <int MODE>
 __device__ __forceinline__ void apply_update(const TrkParams &p, ChanState &s, const double *__restrict__ part, int ch,
-                                             int nblocks, int epoch, const TrkOut &o, bool store) {
-    __shared__ double s_sum[kNSums];
-    __shared__ double s_grp[kUpdGroups][kNSums];
-    __shared__ ChanState s_next;
+                                             int nblocks, int epoch, const TrkOut &o, bool store, unsigned char *scratch) {
+    // kUpdScratch bytes of LDS (the caller's: at the head of a correlate launch the region the correlator uses afterwards)
+    double *s_sum = reinterpret_cast<double *>(scratch);                                     // [18]
+    double(*s_grp)[kNSums] = reinterpret_cast<double(*)[kNSums]>(scratch + kNSums * 8);      // [kUpdGroups][18]
+    double *s_x = reinterpret_cast<double *>(scratch + (1 + kUpdGroups) * kNSums * 8);       // [6]
+    ChanState &s_next = *reinterpret_cast<ChanState *>(scratch + (1 + kUpdGroups) * kNSums * 8 + 48);
     const EpochGeom g = epoch_geom(s, p);
     // fixed-order two-level sum over the correlate workgroups (bit-stable from run to run): group j
     // takes workgroups j, j+14, ...; the 14 group sums are then added in order.  (A single thread per
@@ -749,7 +770,7 @@ __device__ __forceinline__ void apply_update(const TrkParams &p, ChanState &s, c
     // thread, and at the head of a correlate launch every workgroup waits for it).  Its independent pieces run on four
     // waves of the workgroup (different SIMDs), one lane each, with exactly the expressions of the serial form; thread 0
     // then combines them in the reference's order.
-    __shared__ double s_x[6];  // data atan, pilot atan, data (E-L)/(E+L), pilot (E-L)/(E+L), next code phase, next carrier phase
+    // s_x: data atan, pilot atan, data (E-L)/(E+L), pilot (E-L)/(E+L), next code phase, next carrier phase
     if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) {
         const int w = threadIdx.x >> 6;
         if (w == 0) {
@@ -884,6 +905,7 @@ __device__ __forceinline__ void apply_update(const TrkParams &p, ChanState &s, c
     }
     __syncthreads();
     s = s_next;
+    __syncthreads();  // the scratch may be reused from here on
 }
 
 template <int MODE>
@@ -891,9 +913,10 @@ __global__ __launch_bounds__(kUpdThreads) void k_trk_update(TrkParams p, ChanSta
                                                    const double *__restrict__ part, int nblocks, int epoch,
                                                    TrkOut o) {
     const int ch = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[kUpdScratch];
     ChanState s = st[ch];
     if (s.active != 1) return;
-    apply_update<MODE>(p, s, part, ch, nblocks, epoch, o, true);
+    apply_update<MODE>(p, s, part, ch, nblocks, epoch, o, true, scratch);
     if (threadIdx.x == 0) st[ch] = s;
 }
 
