@@ -29,7 +29,7 @@
 #include <set>
 #include <tuple>
 
-#include "bds_acq_f32.h"
+#include "bds_acq_wcols.h"
 #include "bds_internal.h"
 
 namespace bds {
@@ -325,6 +325,10 @@ struct AcqState {
     size_t extra_cap = 0;
     int *d_extra_count = nullptr;
     int n_extra_last = 0;            // entries of the last search (diagnostics)
+    unsigned long long *d_cellmax = nullptr;  // wave-private column pass: packed {maximum, first lag} per cell ...
+    size_t cellmax_cap = 0;
+    float *d_lb = nullptr;                    // ... and the running lower bound of each PRN's sieve maximum
+    size_t lb_cap = 0;
     std::map<int, std::vector<std::pair<int, long>>> last_cands;  // PRN -> (bin, lag) cells the last run refined in f64
     bool no_fast_search = false;     // this configuration fell back to the run-time-plan search kernels
     CorrJob *d_jobs = nullptr;
@@ -356,7 +360,7 @@ void acq_state_free(AcqState *a) {
     for (void *p : {(void *)a->d_sig, (void *)a->d_prim, (void *)a->d_Cs, (void *)a->d_Xs, (void *)a->d_Bw,
                     (void *)a->d_recs, (void *)a->d_rowmax, (void *)a->d_rowarg, (void *)a->d_jobs, (void *)a->d_codes,
                     (void *)a->d_jobout, (void *)a->d_sig64, (void *)a->d_ffa, (void *)a->d_ffb, (void *)a->d_fir, (void *)a->d_cells,
-                    (void *)a->d_extra, (void *)a->d_extra_count})
+                    (void *)a->d_extra, (void *)a->d_extra_count, (void *)a->d_cellmax, (void *)a->d_lb})
         if (p) (void)hipFree(p);
     delete a;
 }
@@ -562,6 +566,10 @@ struct SieveOut {
     int extra_cap = 0;
     int cell0 = 0;     // run-wide index of cell 0 of the launch
     float keep = 1.f;  // 1 - sieve tolerance
+    // wave-private column pass (bds_acq_wcols.h) reports per cell / per PRN instead of per tile
+    unsigned long long *cellmax = nullptr;
+    float *lb = nullptr;
+    int lb_div = 1;
     hipEvent_t mid = nullptr;  // recorded between the two passes of a sampled launch pair (timing)
     // overlapped passes: the column pass runs on its own stream behind ev_rows and signals ev_cols
     hipStream_t cols_stream = nullptr;
@@ -598,9 +606,42 @@ static void launch_cols_ft(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G
         hipLaunchKernelGGL((k_cols_inv_max_f<S, T, NC, false, ST>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
     }
 }
+// wave-private column pass: persistent grid of as many workgroups as are resident on the chip
+template <int S, int NC, bool MASKED, class ST, int NV>
+static void launch_cols_wm(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, const WColsArgs &A) {
+    using W = WCols<S>;
+    const void *kern = (const void *)k_cols_wave_f<S, NC, MASKED, ST, NV>;
+    want_lds(ctx, k_cols_wave_f<S, NC, MASKED, ST, NV>, W::kLdsBytes);
+    auto it = ctx->resident.find(kern);
+    if (it == ctx->resident.end()) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, W::NT, W::kLdsBytes) != hipSuccess || nb < 1) nb = 1;
+        it = ctx->resident.emplace(kern, nb).first;
+        if (ctx->tune.verbose) fprintf(stderr, "[bds] k_cols_wave_f<%d, NV %d>: %d workgroups per CU, %zu B LDS each\n", S, NV, nb, (size_t)W::kLdsBytes);
+    }
+    const int per_cu = ctx->tune.wcols_grid > 0 ? ctx->tune.wcols_grid : it->second;
+    const int ncu = std::max(8, ctx->n_cu) / 8 * 8;  // workgroup id % 8 = XCD: the item map relies on a multiple of 8
+    const int grid = std::min(A.n_items, ncu * per_cu);
+    hipLaunchKernelGGL((k_cols_wave_f<S, NC, MASKED, ST, NV>), dim3(grid), dim3(W::NT), W::kLdsBytes, sc, A);
+}
+template <int S, int NC, class ST>
+static void launch_cols_w(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1,
+                          int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl) {
+    const int ntiles = pl.L2 / WCols<S>::T;  // L2 % 64 == 0 on every specialised plan
+    const WColsArgs A{(const float2 *)pl.d_tw1, pl.L2, ntiles, G, G * ntiles, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, cl.rng,
+                      so.cellmax, so.lb, so.lb_div, so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep};
+    const bool masked = cl.rng || !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
+    if (masked)
+        launch_cols_wm<S, NC, true, ST, 8>(ctx, sc, pl, A);
+    else if (hi1 / pl.L2 < 6 * 8 * WCols<S>::R1)  // no searched lag beyond output row 48 R1: outputs v = 6, 7 of the last stage unused
+        launch_cols_wm<S, NC, false, ST, 6>(ctx, sc, pl, A);
+    else
+        launch_cols_wm<S, NC, false, ST, 8>(ctx, sc, pl, A);
+}
 template <int S, int NC, class ST>
 static void launch_cols_f(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1,
                           int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl) {
+    if (so.cellmax) return launch_cols_w<S, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl);
     if (pl.logT == 2)
         launch_cols_ft<S, 4, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl);
     else
@@ -1097,6 +1138,28 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         BDS_HIP(ctx, hipMemsetAsync(a.d_extra_count, 0, sizeof(int), st(ctx)));
     }
     SieveOut so{a.d_recs, a.d_extra, a.d_extra_count, kExtraCap, 0, (float)(1.0 - kDelta)};
+    // wave-private column pass (default for the fp32-arithmetic search): per-cell packed maxima and per-PRN running
+    // bounds instead of per-tile records
+    const bool wcols = fsearch && tune.wcols != 0;
+    if (wcols) {
+        if ((rc = ensure(ctx, &a.d_cellmax, &a.cellmax_cap, (size_t)std::max(P, 1) * D))) return rc;
+        if ((rc = ensure(ctx, &a.d_lb, &a.lb_cap, (size_t)std::max(P, 1)))) return rc;
+        BDS_HIP(ctx, hipMemsetAsync(a.d_cellmax, 0, sizeof(unsigned long long) * (size_t)std::max(P, 1) * D, st(ctx)));
+        BDS_HIP(ctx, hipMemsetAsync(a.d_lb, 0, sizeof(float) * (size_t)std::max(P, 1), st(ctx)));
+        so.cellmax = a.d_cellmax;
+        so.lb = a.d_lb;
+        so.lb_div = D;
+    }
+    // packed cell maximum -> (value, 0-based lag); nothing searched / nothing written: (-1, -1)
+    auto unpack_cell = [](unsigned long long pk, float *v, int *lag) {
+        if (pk == 0) {
+            *v = -1.f, *lag = -1;
+            return;
+        }
+        const uint32_t hi = (uint32_t)(pk >> 32);
+        memcpy(v, &hi, sizeof(float));
+        *lag = (int)~(uint32_t)(pk & 0xffffffffu);
+    };
     const size_t elem = a.half ? 4 : 8;  // bytes of one stored complex value
     // Small Doppler grids (B2a: 26 bins): one launch pair carries the whole rows of several PRNs through
     // a cell list, so that the grids fill the chip and a row workgroup still walks one PRN's bins.
@@ -1286,16 +1349,23 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             for (int i = 0; i < 2 && i < group_idx; ++i) BDS_HIP(ctx, hipStreamWaitEvent(s_main, ev_cols[i], 0));
     }
     BDS_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)(P * D)), dim3(256), 0, st(ctx), (const Rec *)a.d_recs,
-                       pl.ntiles, pl.ntiles, a.d_rowmax, a.d_rowarg);
+    if (!wcols)
+        hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)(P * D)), dim3(256), 0, st(ctx), (const Rec *)a.d_recs,
+                           pl.ntiles, pl.ntiles, a.d_rowmax, a.d_rowarg);
     BDS_HIP(ctx, hipEventRecord(ev2, st(ctx)));
     a.h_rowmax.resize((size_t)P * D);
     a.h_rowarg.resize((size_t)P * D);
     int n_extra = 0;
-    BDS_HIP(ctx, hipMemcpyAsync(a.h_rowmax.data(), a.d_rowmax, sizeof(float) * P * D, hipMemcpyDeviceToHost, st(ctx)));
-    BDS_HIP(ctx, hipMemcpyAsync(a.h_rowarg.data(), a.d_rowarg, sizeof(int) * P * D, hipMemcpyDeviceToHost, st(ctx)));
+    std::vector<unsigned long long> h_cellmax(wcols ? (size_t)P * D : 0);
+    if (wcols) {
+        BDS_HIP(ctx, hipMemcpyAsync(h_cellmax.data(), a.d_cellmax, sizeof(unsigned long long) * P * D, hipMemcpyDeviceToHost, st(ctx)));
+    } else {
+        BDS_HIP(ctx, hipMemcpyAsync(a.h_rowmax.data(), a.d_rowmax, sizeof(float) * P * D, hipMemcpyDeviceToHost, st(ctx)));
+        BDS_HIP(ctx, hipMemcpyAsync(a.h_rowarg.data(), a.d_rowarg, sizeof(int) * P * D, hipMemcpyDeviceToHost, st(ctx)));
+    }
     BDS_HIP(ctx, hipMemcpyAsync(&n_extra, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, st(ctx)));
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+    for (size_t i = 0; i < h_cellmax.size(); ++i) unpack_cell(h_cellmax[i], &a.h_rowmax[i], &a.h_rowarg[i]);
     a.run_prns = prns;
     a.last.clear();
     // Re-run with wider storage / plainer kernels when the sieve cannot be trusted:
@@ -1347,7 +1417,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             for (int b = 0; b < D; ++b) M = std::max(M, a.h_rowmax[(size_t)pi * D + b]);
             max_of[pi] = M;
             thr_of[pi] = (float)((1.0 - kDelta) * (double)M);
-            for (int b = 0; b < D; ++b)
+            for (int b = 0; b < D && !wcols; ++b)  // (the wave-private pass keeps no tile records: its list is complete)
                 if (!(a.h_rowmax[(size_t)pi * D + b] < thr_of[pi])) rows.push_back({pi, b});
         }
         const size_t all = (size_t)P * D * pl.ntiles;
@@ -1378,7 +1448,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         };
         for (int pi = 0; pi < P; ++pi) {
             const float thr = thr_of[pi];
-            for (int b = 0; b < D; ++b) {
+            for (int b = 0; b < D && !wcols; ++b) {
                 if (a.h_rowmax[(size_t)pi * D + b] < thr) continue;
                 const Rec *rr = &h_recs[row_at[{pi, b}]];
                 for (int t = 0; t < pl.ntiles; ++t)
@@ -1465,6 +1535,11 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         const size_t cap_cells = a.bw_cap / (size_t)pl.L * 8 / elem / (size_t)ncomp;  // cells the work buffer holds
         const bool batched = (fsearch || hsearch) && (size_t)P <= cap_cells;
         BDS_HIP(ctx, hipMemsetAsync(a.d_extra_count, 0, sizeof(int), st(ctx)));  // overflow list of this pass: cell = PRN index
+        if (wcols) {  // one cell per PRN: maxima and bounds are both indexed by the PRN index
+            BDS_HIP(ctx, hipMemsetAsync(a.d_cellmax, 0, sizeof(unsigned long long) * (size_t)std::max(P, 1), st(ctx)));
+            BDS_HIP(ctx, hipMemsetAsync(a.d_lb, 0, sizeof(float) * (size_t)std::max(P, 1), st(ctx)));
+            so.lb_div = 1;
+        }
         std::vector<int> h_bin(P);
         std::vector<long> h_cs(P);
         std::vector<int4> h_rng(P);
@@ -1497,9 +1572,13 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             launch_list(P, a.d_recs, cl, 0, nullptr);
         }
         BDS_HIP(ctx, hipGetLastError());
-        std::vector<Rec> r2((size_t)P * pl.ntiles);
+        std::vector<Rec> r2(wcols ? 0 : (size_t)P * pl.ntiles);
+        std::vector<unsigned long long> h_cm2(wcols ? (size_t)P : 0);
         int n_extra2 = 0;
-        BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, st(ctx)));
+        if (wcols)
+            BDS_HIP(ctx, hipMemcpyAsync(h_cm2.data(), a.d_cellmax, sizeof(unsigned long long) * h_cm2.size(), hipMemcpyDeviceToHost, st(ctx)));
+        else
+            BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, st(ctx)));
         BDS_HIP(ctx, hipMemcpyAsync(&n_extra2, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, st(ctx)));
         BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
         if (n_extra2 > kExtraCap && !a.no_fast_search) return rerun(true, "overflow list of the second-peak pass ran over");
@@ -1513,13 +1592,17 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         std::vector<std::vector<long>> lags(P);
         for (int pi = 0; pi < P; ++pi) {
             float M = -1.f;
-            for (int t = 0; t < pl.ntiles; ++t) M = std::max(M, r2[(size_t)pi * pl.ntiles + t].v);
+            if (wcols) {
+                int lag_unused;
+                unpack_cell(h_cm2[pi], &M, &lag_unused);
+            }
+            for (int t = 0; t < pl.ntiles && !wcols; ++t) M = std::max(M, r2[(size_t)pi * pl.ntiles + t].v);
             const float thr = (float)((1.0 - kDelta) * (double)M);
             std::set<long> ls;
             auto inrange = [&](long l) {
                 return (l >= rng[pi][0] && l <= rng[pi][1]) || (l >= rng[pi][2] && l <= rng[pi][3]);
             };
-            for (int t = 0; t < pl.ntiles; ++t) {
+            for (int t = 0; t < pl.ntiles && !wcols; ++t) {
                 const Rec &r = r2[(size_t)pi * pl.ntiles + t];
                 if (r.lag < 0 || r.v < thr) continue;
                 for (long dl = -1; dl <= 1; ++dl)

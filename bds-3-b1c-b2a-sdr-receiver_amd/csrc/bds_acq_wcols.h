@@ -1,0 +1,379 @@
+// Inverse column pass of the search with wave-private transforms (gfx950): the default column pass of the
+// fp32-arithmetic search on the specialised plans (replaces k_cols_inv_max_f of bds_acq_f32.h there).
+//
+// What it computes is what that kernel computes -- the L1-point inverse transforms down the columns of the
+// inter-pass buffer, w_d |y_d| + w_p |y_p| per lag, and the sieve's candidates -- but organised around the
+// measured costs of this chip (tools/probe/valu_rate.hip): a workgroup barrier between every stage of an LDS
+// transform (twelve per tile in the old kernel: 39 % of its wave-cycles were waits), LDS writes at a third of
+// the read rate, 4-cycle conversions and 8-cycle square roots.
+//
+//   S = 64 R1 points per column (R1 = 4, 8, 12, 16), a tile of 8 adjacent columns per workgroup of 4 waves.
+//   X[p + R1 (u + 8 v)] = sum_bl w8^(bl v) w64^(bl u) sum_bh w8^(bh u) [ w_S^(b p) sum_q w_R1^(q p) x[b + 64 q] ],  b = bl + 8 bh
+//
+//   phase A (cooperative, first stage fed straight from global memory): wave i, lane (cp = lane & 3, bq = lane >> 2)
+//       takes butterfly b = 16 i + bq of column pair cp: 8 bytes per row, four lanes share a 32-byte piece of a
+//       tile row; radix-R1 in registers, twiddle w_S^(b p) from per-lane constants, result to the LDS region
+//       of the wave that owns column pair cp at [m = c R1 + p][b]                      -- barrier --
+//   phase B (wave w owns columns 2w, 2w+1 and its LDS region; no workgroup barrier inside): lane (ml = lane & 7,
+//       bl = lane >> 3), slots s: m = ml + 8 s.  Radix-8 over bh, twiddle w64^(bl u) from per-lane constants, written
+//       back IN PLACE at [m][8 u + bl]; then lane (ml, u) reads row u starting at column u (a rotation of the
+//       butterfly's inputs = a unit factor on its outputs, invisible in |X|; it makes the read conflict-free),
+//       radix-8 over bl, magnitudes in registers.
+//   Two LDS round trips per point instead of three-plus-tables, four barriers per tile and two components
+//   instead of twelve-plus, every stage twiddle a per-lane constant held in registers across the tiles a
+//   (persistent) workgroup walks, the next tile's rows in flight during the transform.
+//   Every LDS access class is bank-conflict free (tools/proto_cols_wave.py models the layouts lane by lane).
+//
+// Outputs (no per-tile records): per cell the packed maximum {value, first lag} by a 64-bit atomic max (rare:
+// only when a wave beats the cell's current value), per PRN a running lower bound `lb` of the sieve maximum,
+// and the candidate list: every lag whose value is within `keep` of max(wave maximum, lb).  Both are lower
+// bounds of the PRN's final maximum M, so every lag >= keep * M is on the list -- the completeness argument of
+// DESIGN.md section 1.5 -- while the list stays a few thousand entries per PRN instead of one record per tile.
+#pragma once
+
+#include "bds_acq_f32.h"
+
+namespace bds {
+
+template <int DIR>
+struct Butterfly<12, DIR> {
+    // n = 3 a + b, k = c + 4 d:  X[c + 4 d] = sum_b W3^(b d) W12^(b c) sum_a x[3 a + b] W4^(a c)
+    __device__ __forceinline__ static void run(float2 *v) {
+        const float h = 0.5f, s = 0.86602540378443864676f;
+        float2 t[3][4];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[b][0] = v[b];
+            t[b][1] = v[b + 3];
+            t[b][2] = v[b + 6];
+            t[b][3] = v[b + 9];
+            Butterfly<4, DIR>::run(t[b]);
+        }
+        t[1][1] = mulc<DIR>(t[1][1], s, h);    // W12^1
+        t[1][2] = mulc<DIR>(t[1][2], h, s);    // W12^2
+        t[1][3] = rot90<DIR>(t[1][3]);         // W12^3 = -j
+        t[2][1] = mulc<DIR>(t[2][1], h, s);    // W12^2
+        t[2][2] = mulc<DIR>(t[2][2], -h, s);   // W12^4
+        t[2][3] = make_float2(-t[2][3].x, -t[2][3].y);  // W12^6 = -1
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float2 u[3] = {t[0][c], t[1][c], t[2][c]};
+            Butterfly<3, DIR>::run(u);
+            v[c] = u[0];
+            v[c + 4] = u[1];
+            v[c + 8] = u[2];
+        }
+    }
+};
+
+// geometry of the wave-private column pass for a length-S transform
+template <int S>
+struct WCols {
+    static_assert(S % 64 == 0 && (S / 64 == 4 || S / 64 == 8 || S / 64 == 12 || S / 64 == 16), "S = 64 x {4, 8, 12, 16}");
+    static constexpr int R1 = S / 64;     // radix of the first stage
+    static constexpr int M = 2 * R1;      // (column of the pair, p) combinations a wave owns
+    static constexpr int SL = M / 8;      // radix-8 butterflies per lane and stage
+    static constexpr int MS = 68;         // elements between consecutive m: 2 MS = 8 (mod 64 banks)
+    static constexpr int RS = M * MS + 8; // elements between the waves' regions: 2 RS = 16 (mod 64)
+    static constexpr int NW = 4, NT = 256, T = 8;
+    static constexpr size_t kLdsBytes = sizeof(float2) * NW * RS;
+    // waves per SIMD the register budget is set for (measured unconstrained need: 80 / 123 / 174 / 215 VGPRs; the
+    // LDS regions allow 9 / 4 / 3 / 2 workgroups per CU, so neither resource is wasted on the other's account)
+#ifdef BDS_WCOLS_OCC
+    static constexpr int kOcc = BDS_WCOLS_OCC;
+#else
+    static constexpr int kOcc = R1 == 4 ? 6 : R1 == 8 ? 4 : R1 == 12 ? 3 : 2;
+#endif
+};
+
+struct WColsArgs {
+    const float2 *tw;    // W_S table of the column transform, exp(-2 pi j i / S), i < S
+    int L2, ntiles, G, n_items;
+    const void *Bw;
+    long L;
+    float w0, w1;
+    int lo1, hi1, lo2, hi2;
+    const int4 *cell_rng;            // optional per-cell (lo1, hi1, lo2, hi2), MASKED kernels only
+    unsigned long long *cellmax;     // [run-wide cell]: (value bits << 32) | ~lag, by atomic max
+    float *lb;                       // [(run-wide cell) / lb_div]: running lower bound of that PRN's sieve maximum
+    int lb_div;
+    Extra *extra;                    // candidate list
+    int *extra_count;
+    int extra_cap;
+    int cell0;                       // run-wide index of cell 0 of this launch
+    float keep;                      // 1 - tolerance of the sieve
+};
+
+__device__ __forceinline__ unsigned long long wc_pack(float v, int lag) {
+    return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(~(unsigned)lag);
+}
+
+template <int S, int NCOMP, bool MASKED, class ST, int NV>
+__global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WColsArgs A) {
+    static_assert(NV >= 1 && NV <= 8, "outputs of the last radix-8 stage");
+    using W = WCols<S>;
+    constexpr bool HS = std::is_same<ST, __half2>::value;
+    constexpr int R1 = W::R1, SL = W::SL, MS = W::MS, RS = W::RS;
+    extern __shared__ __attribute__((aligned(16))) float2 ldsf[];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L2 = A.L2;
+    const long L = A.L;
+
+    // ---- per-lane constants -------------------------------------------------------------------------
+    // phase A: butterfly b of column pair cp
+    const int cp = lane & 3, b = 16 * wave + (lane >> 2);
+    float2 twA[R1];  // w_S^(b p), inverse direction
+#pragma unroll
+    for (int p = 1; p < R1; ++p) {
+        const float2 t = A.tw[(b * p) % S];
+        twA[p] = make_float2(t.x, -t.y);
+    }
+    float2 *const wrA = ldsf + cp * RS + b;  // + m MS
+    // phase B: stage 2 as lane (ml, bl), stage 3 as lane (ml, u) with u = bl
+    const int ml = lane & 7, bl = lane >> 3;
+    float2 twB[8];  // w_64^(bl u)
+#pragma unroll
+    for (int u = 1; u < 8; ++u) {
+        const float2 t = A.tw[(R1 * bl * u) % S];
+        twB[u] = make_float2(t.x, -t.y);
+    }
+    float2 *const rw2 = ldsf + wave * RS + ml * MS + bl;  // + s 8 MS + 8 bh (read), + 8 u (write back)
+    const float2 *rd3[8];                                 // row u from column u on: + s 8 MS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rd3[j] = ldsf + wave * RS + ml * MS + 8 * bl + ((j + bl) & 7);
+    // output (s, v) of this lane: row e = p + R1 u + 8 R1 v of column 2 wave + c, m = ml + 8 s = c R1 + p
+    int e0[SL], cc[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+        const int m = ml + 8 * s;
+        cc[s] = m >= R1 ? 1 : 0;
+        e0[s] = m - cc[s] * R1 + R1 * bl;
+    }
+
+    using Raw = typename std::conditional<HS, uint2, float4>::type;
+    // rows b + 64 q of column pair cp of (cell g, component comp, tile)
+    // (uniform 64-bit base per row in scalar registers + one 32-bit lane offset: the loads take the saddr form
+    //  and no per-row 64-bit vector address exists)
+    const uint32_t voff = (uint32_t)((b * L2 + 2 * cp) * (int)sizeof(ST));  // < 2^22
+    auto fetch = [&](Raw(&pre)[R1], int g, int comp, int c0) {
+        const char *base = (const char *)A.Bw + (((long)g * NCOMP + comp) * L + c0) * (long)sizeof(ST);
+#pragma unroll
+        for (int q = 0; q < R1; ++q) {
+            const uint64_t sb = (uint64_t)(base + (long)q * 64 * L2 * (long)sizeof(ST));
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+            pre[q] = *reinterpret_cast<const Raw *>((const char *)(((uint64_t)hi << 32) | lo) + voff);
+        }
+    };
+    // opaque to the scheduler: the raw rows are "produced" where this stands, nothing consuming them moves above it
+    auto pin = [](Raw(&pre)[R1]) {
+#pragma unroll
+        for (int q = 0; q < R1; ++q) {
+            if constexpr (HS)
+                asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y));
+            else
+                asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y), "+v"(pre[q].z), "+v"(pre[q].w));
+        }
+    };
+    // first stage of both columns of the pair, twiddled
+    auto phaseA = [&](const Raw(&pre)[R1], float2(&z)[2][R1]) {
+#pragma unroll
+        for (int q = 0; q < R1; ++q) {
+            if constexpr (HS) {
+                z[0][q] = h2_to_f2(pre[q].x);
+                z[1][q] = h2_to_f2(pre[q].y);
+            } else {
+                z[0][q] = make_float2(pre[q].x, pre[q].y);
+                z[1][q] = make_float2(pre[q].z, pre[q].w);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            Butterfly<R1, +1>::run(z[c]);
+#pragma unroll
+            for (int p = 1; p < R1; ++p) z[c][p] = cmul(z[c][p], twA[p]);
+        }
+    };
+    auto storeA = [&](const float2(&z)[2][R1]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int p = 0; p < R1; ++p) wrA[(c * R1 + p) * MS] = z[c][p];
+        }
+    };
+    auto wave_sync = [] {  // LDS traffic of one wave is in order; this only stops the compiler from moving it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    const int TX = A.ntiles >> 3;  // tiles per XCD and cell: workgroup id % 8 = XCD, which keeps a contiguous
+                                   // run of tiles (they share 128-byte lines) in one L2
+    auto item_of = [&](int it, int &g, int &c0) {
+        const int xcd = it & 7, j = it >> 3;
+        g = j / TX;
+        c0 = (xcd * TX + (j - g * TX)) * W::T;
+    };
+
+    int item = (int)blockIdx.x;
+    if (item >= A.n_items) return;
+    int g, c0;
+    item_of(item, g, c0);
+    Raw pre0[R1], pre1[NCOMP > 1 ? R1 : 1];
+    fetch(pre0, g, 0, c0);
+    float mag[SL][NV];
+    for (;;) {
+        int lo1 = A.lo1, hi1 = A.hi1, lo2 = A.lo2, hi2 = A.hi2;
+        if (MASKED && A.cell_rng) {
+            const int4 r = A.cell_rng[g];
+            lo1 = r.x, hi1 = r.y, lo2 = r.z, hi2 = r.w;
+        }
+        // lag of output (s, v): lbase[s] + v vstep.  c0 goes through an opaque move so that nothing of the lag
+        // arithmetic is loop invariant (hoisted out of the tile loop it would occupy two dozen registers for a rare path)
+        int c0v = c0;
+        asm volatile("" : "+v"(c0v));
+        int lbase[SL];
+#pragma unroll
+        for (int s = 0; s < SL; ++s) lbase[s] = e0[s] * L2 + cc[s] + 2 * wave + c0v;  // L < 2^31
+        const int vstep = 8 * R1 * L2;
+        float mx = -1.f;
+        const int next = item + (int)gridDim.x;
+        int gn = 0, c0n = 0;
+        if (next < A.n_items) item_of(next, gn, c0n);
+#pragma unroll
+        for (int comp = 0; comp < NCOMP; ++comp) {
+            float2 z[2][R1];
+            if constexpr (NCOMP > 1) {
+                if (comp == 0) {
+                    fetch(pre1, g, 1, c0);
+                    phaseA(pre0, z);
+                } else {
+                    // (pinned here: moved up into the first component's last stage it doubles the live registers)
+                    pin(pre1);
+                    phaseA(pre1, z);
+                }
+            } else {
+                phaseA(pre0, z);
+            }
+            // the rows of the next tile are in flight from here on
+#ifndef WC_EXP_NOPREFETCH
+            if (comp == NCOMP - 1 && next < A.n_items) fetch(pre0, gn, 0, c0n);
+#endif
+            __syncthreads();  // every wave is through with its region (last reads of the previous transform)
+            storeA(z);
+            __syncthreads();
+            // ---- phase B, one slot (= 8 of the wave's rows m) at a time so that only 16-32 points are live:
+            //   st2(s): radix 8 over bh, twiddle, back in place;  st3(s): radix 8 over bl (rotated start), magnitudes.
+            // Row m is read and written by the 8 lanes of one ml only, all in this wave, and LDS traffic of a wave is in
+            // order: st2(s) may write as soon as its own reads are in, st3(s) may read as soon as st2(s) has written.
+            // The units are software-pipelined by hand (st2(s + 1) sits between the write and the read-back of slot s)
+            // and fenced, so that the scheduler neither serialises the LDS latency nor hoists every read to the top.
+            const float w = comp == 0 ? A.w0 : A.w1;
+            auto st2 = [&](int s) {
+                float2 y[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y[q] = rw2[s * 8 * MS + 8 * q];
+                wave_sync();
+                Butterfly<8, +1>::run(y);
+#pragma unroll
+                for (int u = 1; u < 8; ++u) y[u] = cmul(y[u], twB[u]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rw2[s * 8 * MS + 8 * u] = y[u];
+                wave_sync();
+            };
+            auto st3 = [&](int s) {
+                float2 y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = rd3[j][s * 8 * MS];
+                wave_sync();
+                Butterfly<8, +1>::run(y);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    // (no branches in here, not even uniform ones: every basic-block boundary pins the butterfly's
+                    //  outputs in registers -- 254 VGPRs with a workgroup-uniform "row range searched at all?" test per v
+                    //  against 174 without.  Output v covers rows 8 R1 v .. 8 R1 (v + 1) - 1; the host instantiates NV = 6
+                    //  when no searched lag lies beyond row 48 R1 -- the padded transform is ~1.6 N long -- and the
+                    //  unused outputs of the last butterfly fall away at compile time.)
+                    const float2 t = y[v];
+                    // raw v_sqrt_f32 (1 ulp): the value only feeds the sieve
+                    float a = w * __builtin_amdgcn_sqrtf(t.x * t.x + t.y * t.y);
+                    if (comp > 0) a += mag[s][v];
+                    if (comp == NCOMP - 1) {
+                        // lags outside the searched ranges hold -1 from here on (searched values are >= 0)
+                        const int lag = lbase[s] + v * vstep;
+                        const bool ok = MASKED ? ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2)) : lag <= hi1;
+                        a = ok ? a : -1.f;
+                        mx = fmaxf(mx, a);
+                    }
+                    mag[s][v] = a;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            st2(0);
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                if (s + 1 < SL) st2(s + 1);
+                st3(s);
+            }
+        }
+        // ---- maximum of the wave's two columns, candidates ------------------------------------------
+        const float Mw = wave_max_f32(mx);
+        if (Mw >= 0.f) {  // (wave-uniform) something of these two columns is searched
+            const int cell = A.cell0 + g;
+            float *lbp = A.lb + cell / A.lb_div;
+            const float lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+            const float thr = fmaxf(Mw, lbv) * A.keep;
+            const bool newmax = __float_as_uint(Mw) >= cur;  // this wave holds (a tie of) the cell's maximum so far
+            if (newmax || __builtin_amdgcn_ballot_w64(mx >= thr) != 0) {
+                // Rare (wave-uniform): the values go through the wave's own LDS region (free until the next barrier)
+                // and a compact loop picks the maximum's first lag and every lag within the sieve tolerance of the bound.
+                float *sm = reinterpret_cast<float *>(ldsf + wave * RS) + lane;  // [k = 8 s + v][lane]
+                wave_sync();
+#pragma unroll
+                for (int s = 0; s < SL; ++s) {
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) sm[(8 * s + v) * 64] = v < NV ? mag[s][v < NV ? v : 0] : -1.f;
+                }
+                wave_sync();
+                int best = 0x7fffffff;
+#pragma nounroll
+                for (int k = 0; k < 8 * SL; ++k) {
+                    const float a = sm[k * 64];
+                    if (a >= thr || (newmax && a == Mw)) {
+                        const int m = ml + (k & ~7), c = m >= R1 ? 1 : 0;
+                        const int lag = (m - c * R1 + R1 * bl + 8 * R1 * (k & 7)) * L2 + c0 + 2 * wave + c;
+                        if (a == Mw) best = min(best, lag);
+                        if (a >= thr) {
+                            const int idx = atomicAdd(A.extra_count, 1);
+                            if (idx < A.extra_cap) {
+                                Extra ex;
+                                ex.v = a;
+                                ex.lag = lag;
+                                ex.cell = cell;
+                                A.extra[idx] = ex;
+                            }
+                        }
+                    }
+                }
+                if (newmax) {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+                    if (lane == 0) {
+                        atomicMax(A.cellmax + cell, wc_pack(Mw, best));
+                        if (Mw > lbv) atomicMax(reinterpret_cast<unsigned *>(lbp), __float_as_uint(Mw));
+                    }
+                }
+                wave_sync();
+            }
+        }
+        if (next >= A.n_items) break;
+#ifdef WC_EXP_NOPREFETCH
+        fetch(pre0, gn, 0, c0n);
+#endif
+        item = next;
+        g = gn;
+        c0 = c0n;
+    }
+}
+
+}  // namespace bds

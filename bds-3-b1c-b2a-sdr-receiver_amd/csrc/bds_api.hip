@@ -56,6 +56,8 @@ Tuning tuning_from_env() {
     if (const char *e = std::getenv("BDS_ACQ_KDELTA")) t.kdelta = std::max(0.0, std::min(0.9, std::atof(e)));
     t.no_selfcheck = has("BDS_ACQ_NO_SELFCHECK");
     t.test_force_fallback = has("BDS_ACQ_TEST_FORCE_FALLBACK");
+    t.wcols = geti("BDS_ACQ_WCOLS", -1);
+    t.wcols_grid = std::max(0, geti("BDS_ACQ_WCOLS_GRID", 0));
     t.verbose = has("BDS_VERBOSE");
     t.multi_force_rccl = has("BDS_MULTI_FORCE_RCCL");
     t.trk_nblocks = std::max(0, geti("BDS_TRK_NBLOCKS", 0));
@@ -106,6 +108,7 @@ extern "C" bds_ctx *bds_create(int device_id) {
         ctx->devname = prop.name;
         ctx->devname += " ";
         ctx->devname += prop.gcnArchName;
+        ctx->n_cu = prop.multiProcessorCount;
     }
     return ctx;
 }
