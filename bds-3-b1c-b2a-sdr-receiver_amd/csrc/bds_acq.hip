@@ -1527,6 +1527,10 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         }
     } else {
         // second peak in the winning bin, outside +-2 chips and within +-1 code (B2a/acquisition.m:224-249)
+        // (one cell per PRN, a single round of workgroups: the tile kernel with its per-tile records serves this pass; the
+        //  wave-private kernel's running bounds have nothing to run on)
+        so.cellmax = nullptr;
+        so.lb = nullptr;
         const long s2c = (long)std::ceil(s->samplingFreq / s->codeFreqBasis) * 2;  // samples2CodeChip :137
         std::vector<std::array<long, 4>> rng(P);
         if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * D * pl.ntiles))) return rc;
@@ -1535,11 +1539,6 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         const size_t cap_cells = a.bw_cap / (size_t)pl.L * 8 / elem / (size_t)ncomp;  // cells the work buffer holds
         const bool batched = (fsearch || hsearch) && (size_t)P <= cap_cells;
         BDS_HIP(ctx, hipMemsetAsync(a.d_extra_count, 0, sizeof(int), st(ctx)));  // overflow list of this pass: cell = PRN index
-        if (wcols) {  // one cell per PRN: maxima and bounds are both indexed by the PRN index
-            BDS_HIP(ctx, hipMemsetAsync(a.d_cellmax, 0, sizeof(unsigned long long) * (size_t)std::max(P, 1), st(ctx)));
-            BDS_HIP(ctx, hipMemsetAsync(a.d_lb, 0, sizeof(float) * (size_t)std::max(P, 1), st(ctx)));
-            so.lb_div = 1;
-        }
         std::vector<int> h_bin(P);
         std::vector<long> h_cs(P);
         std::vector<int4> h_rng(P);
@@ -1572,13 +1571,9 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             launch_list(P, a.d_recs, cl, 0, nullptr);
         }
         BDS_HIP(ctx, hipGetLastError());
-        std::vector<Rec> r2(wcols ? 0 : (size_t)P * pl.ntiles);
-        std::vector<unsigned long long> h_cm2(wcols ? (size_t)P : 0);
+        std::vector<Rec> r2((size_t)P * pl.ntiles);
         int n_extra2 = 0;
-        if (wcols)
-            BDS_HIP(ctx, hipMemcpyAsync(h_cm2.data(), a.d_cellmax, sizeof(unsigned long long) * h_cm2.size(), hipMemcpyDeviceToHost, st(ctx)));
-        else
-            BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, st(ctx)));
+        BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, st(ctx)));
         BDS_HIP(ctx, hipMemcpyAsync(&n_extra2, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, st(ctx)));
         BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
         if (n_extra2 > kExtraCap && !a.no_fast_search) return rerun(true, "overflow list of the second-peak pass ran over");
@@ -1592,17 +1587,13 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         std::vector<std::vector<long>> lags(P);
         for (int pi = 0; pi < P; ++pi) {
             float M = -1.f;
-            if (wcols) {
-                int lag_unused;
-                unpack_cell(h_cm2[pi], &M, &lag_unused);
-            }
-            for (int t = 0; t < pl.ntiles && !wcols; ++t) M = std::max(M, r2[(size_t)pi * pl.ntiles + t].v);
+            for (int t = 0; t < pl.ntiles; ++t) M = std::max(M, r2[(size_t)pi * pl.ntiles + t].v);
             const float thr = (float)((1.0 - kDelta) * (double)M);
             std::set<long> ls;
             auto inrange = [&](long l) {
                 return (l >= rng[pi][0] && l <= rng[pi][1]) || (l >= rng[pi][2] && l <= rng[pi][3]);
             };
-            for (int t = 0; t < pl.ntiles && !wcols; ++t) {
+            for (int t = 0; t < pl.ntiles; ++t) {
                 const Rec &r = r2[(size_t)pi * pl.ntiles + t];
                 if (r.lag < 0 || r.v < thr) continue;
                 for (long dl = -1; dl <= 1; ++dl)

@@ -206,12 +206,19 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    const int TX = A.ntiles >> 3;  // tiles per XCD and cell: workgroup id % 8 = XCD, which keeps a contiguous
-                                   // run of tiles (they share 128-byte lines) in one L2
+    // Item order.  Workgroup id % 8 = XCD; XCD x keeps the contiguous run of tiles [x TX, (x + 1) TX) of every cell (adjacent
+    // tiles share 128-byte lines: one L2).  Inside it, four adjacent tiles of one cell are followed by the same four of the
+    // NEXT cell (not by the cell's next tiles), and each XCD starts one eighth of the way further round the cells: the
+    // workgroups that run at the same time then work on different cells (~4 per cell), so that a cell's running maximum is
+    // settled by a few early waves instead of every wave of the cell seeing it unset at once.
+    const int TX = A.ntiles >> 3;
     auto item_of = [&](int it, int &g, int &c0) {
         const int xcd = it & 7, j = it >> 3;
-        g = j / TX;
-        c0 = (xcd * TX + (j - g * TX)) * W::T;
+        const int t4 = j & 3, rest = j >> 2;
+        const int tg = rest / A.G, gi = rest - tg * A.G;
+        g = gi + xcd * (A.G >> 3);
+        g = g >= A.G ? g - A.G : g;
+        c0 = (xcd * TX + tg * 4 + t4) * W::T;
     };
 
     int item = (int)blockIdx.x;
@@ -236,6 +243,12 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         for (int s = 0; s < SL; ++s) lbase[s] = e0[s] * L2 + cc[s] + 2 * wave + c0v;  // L < 2^31
         const int vstep = 8 * R1 * L2;
         float mx = -1.f;
+        // the cell's maximum so far and the PRN's running bound: read now (L2 / fabric latency), used after the transforms;
+        // stale values are lower values, which only costs a redundant visit of the rare path below
+        const int cell = A.cell0 + g;
+        float *const lbp = A.lb + cell / A.lb_div;
+        const float lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
         const int next = item + (int)gridDim.x;
         int gn = 0, c0n = 0;
         if (next < A.n_items) item_of(next, gn, c0n);
@@ -318,10 +331,6 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         // ---- maximum of the wave's two columns, candidates ------------------------------------------
         const float Mw = wave_max_f32(mx);
         if (Mw >= 0.f) {  // (wave-uniform) something of these two columns is searched
-            const int cell = A.cell0 + g;
-            float *lbp = A.lb + cell / A.lb_div;
-            const float lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
             const float thr = fmaxf(Mw, lbv) * A.keep;
             const bool newmax = __float_as_uint(Mw) >= cur;  // this wave holds (a tie of) the cell's maximum so far
             if (newmax || __builtin_amdgcn_ballot_w64(mx >= thr) != 0) {
@@ -335,24 +344,36 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
                     for (int v = 0; v < 8; ++v) sm[(8 * s + v) * 64] = v < NV ? mag[s][v < NV ? v : 0] : -1.f;
                 }
                 wave_sync();
-                int best = 0x7fffffff;
+                auto lag_at = [&](int k) {
+                    const int m = ml + (k & ~7), c = m >= R1 ? 1 : 0;
+                    return (m - c * R1 + R1 * bl + 8 * R1 * (k & 7)) * L2 + c0 + 2 * wave + c;
+                };
+                int best = 0x7fffffff, total = 0;
 #pragma nounroll
                 for (int k = 0; k < 8 * SL; ++k) {
                     const float a = sm[k * 64];
-                    if (a >= thr || (newmax && a == Mw)) {
-                        const int m = ml + (k & ~7), c = m >= R1 ? 1 : 0;
-                        const int lag = (m - c * R1 + R1 * bl + 8 * R1 * (k & 7)) * L2 + c0 + 2 * wave + c;
-                        if (a == Mw) best = min(best, lag);
+                    total += __builtin_popcountll(__builtin_amdgcn_ballot_w64(a >= thr));
+                    if (newmax && a == Mw) best = min(best, lag_at(k));
+                }
+                if (total > 0) {  // one reservation per wave on the list's counter
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(A.extra_count, total);
+                    base = __builtin_amdgcn_readfirstlane(base);
+#pragma nounroll
+                    for (int k = 0; k < 8 * SL; ++k) {
+                        const float a = sm[k * 64];
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(a >= thr);
                         if (a >= thr) {
-                            const int idx = atomicAdd(A.extra_count, 1);
+                            const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                             if (idx < A.extra_cap) {
                                 Extra ex;
                                 ex.v = a;
-                                ex.lag = lag;
+                                ex.lag = lag_at(k);
                                 ex.cell = cell;
                                 A.extra[idx] = ex;
                             }
                         }
+                        base += __builtin_popcountll(mask);
                     }
                 }
                 if (newmax) {
