@@ -619,9 +619,11 @@ static void launch_cols_wm(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, const
         it = ctx->resident.emplace(kern, nb).first;
         if (ctx->tune.verbose) fprintf(stderr, "[bds] k_cols_wave_f<%d, NV %d>: %d workgroups per CU, %zu B LDS each\n", S, NV, nb, (size_t)W::kLdsBytes);
     }
-    const int per_cu = ctx->tune.wcols_grid > 0 ? ctx->tune.wcols_grid : it->second;
-    const int ncu = std::max(8, ctx->n_cu) / 8 * 8;  // workgroup id % 8 = XCD: the item map relies on a multiple of 8
-    const int grid = std::min(A.n_items, ncu * per_cu);
+    // one item per workgroup (see the kernel's note on item order); BDS_ACQ_WCOLS_GRID=n makes the grid persistent with n
+    // workgroups per CU, -1 with as many as are resident
+    const int per_cu = ctx->tune.wcols_grid < 0 ? it->second : ctx->tune.wcols_grid;
+    const int ncu = std::max(8, ctx->n_cu) / 8 * 8;  // workgroup id % 8 = XCD: the item lists rely on a multiple of 8
+    const int grid = per_cu > 0 ? std::min(A.n_items, ncu * per_cu) : A.n_items;
     hipLaunchKernelGGL((k_cols_wave_f<S, NC, MASKED, ST, NV>), dim3(grid), dim3(W::NT), W::kLdsBytes, sc, A);
 }
 template <int S, int NC, class ST>
@@ -1140,7 +1142,9 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     SieveOut so{a.d_recs, a.d_extra, a.d_extra_count, kExtraCap, 0, (float)(1.0 - kDelta)};
     // wave-private column pass (default for the fp32-arithmetic search): per-cell packed maxima and per-PRN running
     // bounds instead of per-tile records
-    const bool wcols = fsearch && tune.wcols != 0;
+    // (the 256-point plans keep the tile kernel unless forced with BDS_ACQ_WCOLS=1: a workgroup's share of such a tile is
+    //  8 points per lane and the per-workgroup constants and barriers dominate -- measured at cfg2 2.18 vs 1.39 ms per launch)
+    const bool wcols = fsearch && tune.wcols != 0 && (pl.L1 != 256 || tune.wcols > 0);
     if (wcols) {
         if ((rc = ensure(ctx, &a.d_cellmax, &a.cellmax_cap, (size_t)std::max(P, 1) * D))) return rc;
         if ((rc = ensure(ctx, &a.d_lb, &a.lb_cap, (size_t)std::max(P, 1)))) return rc;

@@ -33,6 +33,16 @@
 
 #include "bds_acq_f32.h"
 
+// Timing experiments (tools/exp_wparts.sh; results are INVALID with any of these defined):
+//   BDS_EXP_WC_NOTAIL  nothing after the wave maximum (no bounds, no list, no atomics)
+//   BDS_EXP_WC_NOLOAD  the inter-pass buffer is not read
+//   BDS_EXP_WC_NOBAR   workgroup barriers compiled out
+#ifdef BDS_EXP_WC_NOBAR
+#define BDS_WSYNC() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define BDS_WSYNC() __syncthreads()
+#endif
+
 namespace bds {
 
 template <int DIR>
@@ -155,13 +165,28 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     // (uniform 64-bit base per row in scalar registers + one 32-bit lane offset: the loads take the saddr form
     //  and no per-row 64-bit vector address exists)
     const uint32_t voff = (uint32_t)((b * L2 + 2 * cp) * (int)sizeof(ST));  // < 2^22
+    // (buffer loads: the descriptor of (cell, component, tile) and the row offsets live in scalar registers, the lane
+    //  offset is one VGPR -- global_load with per-row 64-bit vector addresses cost two dozen VGPRs and their arithmetic;
+    //  a flat_load would also count on the LDS counter and every LDS wait of the transform would wait for the prefetch)
     auto fetch = [&](Raw(&pre)[R1], int g, int comp, int c0) {
         const char *base = (const char *)A.Bw + (((long)g * NCOMP + comp) * L + c0) * (long)sizeof(ST);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000);
+        const int rowstep = 64 * L2 * (int)sizeof(ST);
 #pragma unroll
         for (int q = 0; q < R1; ++q) {
-            const uint64_t sb = (uint64_t)(base + (long)q * 64 * L2 * (long)sizeof(ST));
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
-            pre[q] = *reinterpret_cast<const Raw *>((const char *)(((uint64_t)hi << 32) | lo) + voff);
+#ifdef BDS_EXP_WC_NOLOAD
+            if (A.w0 != 1.2345f) {
+                pre[q] = Raw{};
+                continue;
+            }
+#endif
+            if constexpr (HS) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, q * rowstep, 0);
+                pre[q] = make_uint2(v[0], v[1]);
+            } else {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, q * rowstep, 0);
+                pre[q] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
         }
     };
     // opaque to the scheduler: the raw rows are "produced" where this stands, nothing consuming them moves above it
@@ -206,11 +231,17 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    // Item order.  Workgroup id % 8 = XCD; XCD x keeps the contiguous run of tiles [x TX, (x + 1) TX) of every cell (adjacent
-    // tiles share 128-byte lines: one L2).  Inside it, four adjacent tiles of one cell are followed by the same four of the
-    // NEXT cell (not by the cell's next tiles), and each XCD starts one eighth of the way further round the cells: the
-    // workgroups that run at the same time then work on different cells (~4 per cell), so that a cell's running maximum is
-    // settled by a few early waves instead of every wave of the cell seeing it unset at once.
+    // Item order.  Workgroup id % 8 = XCD; XCD x keeps the contiguous run of tiles [x TX, (x + 1) TX) of every cell.  Its
+    // list: four adjacent tiles of one cell (they share 128-byte lines), then the same four of the NEXT cell (not the cell's
+    // next tiles), each XCD starting one eighth of the way further round the cells -- the workgroups that run at the same
+    // time then work on different cells (~4 per cell), so that a cell's running maximum is settled by a few early waves
+    // instead of every wave of the cell seeing it unset at once.
+    // The grid is NOT persistent by default (one item per workgroup, gridDim = items): the hardware then starts the
+    // workgroups in list order over time and the four tiles of a line are loaded within microseconds of each other.  Measured
+    // alternatives: a persistent grid with a static item -> workgroup map drifts apart over its ~130 items per workgroup and
+    // every tile refetches its lines (2.7x the HBM traffic, the pass fabric-bound at 6 TB/s); persistent workgroups drawing
+    // tickets from a per-XCD atomic counter stay in order but device-scope atomics on one address complete at ~1.4 M/s
+    // (9.6 ms per launch instead of 2.3).
     const int TX = A.ntiles >> 3;
     auto item_of = [&](int it, int &g, int &c0) {
         const int xcd = it & 7, j = it >> 3;
@@ -268,12 +299,10 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
                 phaseA(pre0, z);
             }
             // the rows of the next tile are in flight from here on
-#ifndef WC_EXP_NOPREFETCH
             if (comp == NCOMP - 1 && next < A.n_items) fetch(pre0, gn, 0, c0n);
-#endif
-            __syncthreads();  // every wave is through with its region (last reads of the previous transform)
+            BDS_WSYNC();  // every wave is through with its region (last reads of the previous transform)
             storeA(z);
-            __syncthreads();
+            BDS_WSYNC();
             // ---- phase B, one slot (= 8 of the wave's rows m) at a time so that only 16-32 points are live:
             //   st2(s): radix 8 over bh, twiddle, back in place;  st3(s): radix 8 over bl (rotated start), magnitudes.
             // Row m is read and written by the 8 lanes of one ml only, all in this wave, and LDS traffic of a wave is in
@@ -330,7 +359,11 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         }
         // ---- maximum of the wave's two columns, candidates ------------------------------------------
         const float Mw = wave_max_f32(mx);
-        if (Mw >= 0.f) {  // (wave-uniform) something of these two columns is searched
+#ifdef BDS_EXP_WC_NOTAIL
+        if (Mw == 1.2345f) {
+#else
+        if (Mw >= 0.f) {
+#endif  // (wave-uniform) something of these two columns is searched
             const float thr = fmaxf(Mw, lbv) * A.keep;
             const bool newmax = __float_as_uint(Mw) >= cur;  // this wave holds (a tie of) the cell's maximum so far
             if (newmax || __builtin_amdgcn_ballot_w64(mx >= thr) != 0) {
@@ -388,9 +421,6 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
             }
         }
         if (next >= A.n_items) break;
-#ifdef WC_EXP_NOPREFETCH
-        fetch(pre0, gn, 0, c0n);
-#endif
         item = next;
         g = gn;
         c0 = c0n;
