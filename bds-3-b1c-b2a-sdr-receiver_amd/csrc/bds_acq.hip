@@ -47,6 +47,7 @@ struct Plan2D {
     bool fast = false;  // both lengths have compile-time specialised search kernels (bds_acq_fast.h)
     float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_hi = nullptr, *d_lo = nullptr;
     float2 *d_ftab1 = nullptr, *d_ftab2 = nullptr;  // fp32 stage-twiddle tables of the inverse column / row transform
+    float2 *d_wtab = nullptr;                       // per-lane twiddle table of the wave-private column pass (bds_acq_wcols.h)
     h2 *d_htab1 = nullptr, *d_htab2 = nullptr;  // fp16 stage-twiddle tables of the column / row transform
     double hscale1 = 1, hscale2 = 1;            // product of the stage scales folded into them
 };
@@ -151,7 +152,7 @@ static int threads_for(const Plan1D &p, int T) {
 }
 
 static void plan_free(Plan2D &pl) {
-    for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo, &pl.d_ftab1, &pl.d_ftab2})
+    for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo, &pl.d_ftab1, &pl.d_ftab2, &pl.d_wtab})
         if (*p) (void)hipFree(*p), *p = nullptr;
     for (h2 **p : {&pl.d_htab1, &pl.d_htab2})
         if (*p) (void)hipFree(*p), *p = nullptr;
@@ -200,6 +201,28 @@ static int upload_stage_tables_f32(bds_ctx *ctx, const Plan1D &p, float2 **dptr)
         ns *= R;
     }
     if (h.empty()) h.push_back(make_float2(1.f, 0.f));
+    BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * h.size()));
+    BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
+    return BDS_OK;
+}
+
+// per-lane twiddle table of the wave-private column pass (layout: wcols_table_entries<S>() in bds_acq_wcols.h), inverse
+// direction, rounded from f64: [p - 1][thread] = w_S^(b p) with b = 16 (thread / 64) + (thread % 64) / 4, then
+// [u - 1][lane] = w_64^((lane / 8) u)
+static int upload_wcols_table(bds_ctx *ctx, int S, float2 **dptr) {
+    const int R1 = S / 64;
+    std::vector<float2> h;
+    for (int p = 1; p < R1; ++p)
+        for (int t = 0; t < 256; ++t) {
+            const int b = 16 * (t >> 6) + ((t & 63) >> 2);
+            const double a = 2.0 * kPi * (double)((b * p) % S) / (double)S;
+            h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+        }
+    for (int u = 1; u < 8; ++u)
+        for (int lane = 0; lane < 64; ++lane) {
+            const double a = 2.0 * kPi * (double)(((lane >> 3) * u) % 64) / 64.0;
+            h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+        }
     BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * h.size()));
     BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
     return BDS_OK;
@@ -264,6 +287,7 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
         if ((rc = upload_half_tables(ctx, pl.p2, &pl.d_htab2, &pl.hscale2))) return rc;
         if ((rc = upload_stage_tables_f32(ctx, pl.p1, &pl.d_ftab1))) return rc;
         if ((rc = upload_stage_tables_f32(ctx, pl.p2, &pl.d_ftab2))) return rc;
+        if ((rc = upload_wcols_table(ctx, pl.L1, &pl.d_wtab))) return rc;
     }
     pl.p1.tw = pl.d_tw1;
     pl.p2.tw = pl.d_tw2;
@@ -606,31 +630,19 @@ static void launch_cols_ft(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G
         hipLaunchKernelGGL((k_cols_inv_max_f<S, T, NC, false, ST>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
     }
 }
-// wave-private column pass: persistent grid of as many workgroups as are resident on the chip
+// wave-private column pass: one tile per workgroup, workgroups started by the hardware in list order (see the kernel's
+// note on item order)
 template <int S, int NC, bool MASKED, class ST, int NV>
 static void launch_cols_wm(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, const WColsArgs &A) {
     using W = WCols<S>;
-    const void *kern = (const void *)k_cols_wave_f<S, NC, MASKED, ST, NV>;
     want_lds(ctx, k_cols_wave_f<S, NC, MASKED, ST, NV>, W::kLdsBytes);
-    auto it = ctx->resident.find(kern);
-    if (it == ctx->resident.end()) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, W::NT, W::kLdsBytes) != hipSuccess || nb < 1) nb = 1;
-        it = ctx->resident.emplace(kern, nb).first;
-        if (ctx->tune.verbose) fprintf(stderr, "[bds] k_cols_wave_f<%d, NV %d>: %d workgroups per CU, %zu B LDS each\n", S, NV, nb, (size_t)W::kLdsBytes);
-    }
-    // one item per workgroup (see the kernel's note on item order); BDS_ACQ_WCOLS_GRID=n makes the grid persistent with n
-    // workgroups per CU, -1 with as many as are resident
-    const int per_cu = ctx->tune.wcols_grid < 0 ? it->second : ctx->tune.wcols_grid;
-    const int ncu = std::max(8, ctx->n_cu) / 8 * 8;  // workgroup id % 8 = XCD: the item lists rely on a multiple of 8
-    const int grid = per_cu > 0 ? std::min(A.n_items, ncu * per_cu) : A.n_items;
-    hipLaunchKernelGGL((k_cols_wave_f<S, NC, MASKED, ST, NV>), dim3(grid), dim3(W::NT), W::kLdsBytes, sc, A);
+    hipLaunchKernelGGL((k_cols_wave_f<S, NC, MASKED, ST, NV>), dim3(A.n_items), dim3(W::NT), W::kLdsBytes, sc, A);
 }
 template <int S, int NC, class ST>
 static void launch_cols_w(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1,
                           int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl) {
-    const int ntiles = pl.L2 / WCols<S>::T;  // L2 % 64 == 0 on every specialised plan
-    const WColsArgs A{(const float2 *)pl.d_tw1, pl.L2, ntiles, G, G * ntiles, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, cl.rng,
+    const int ntiles = pl.L2 / WCols<S>::T;  // L2 % 256 == 0 on every specialised plan: ntiles % 32 == 0 (8 XCDs x quads)
+    const WColsArgs A{(const float2 *)pl.d_wtab, pl.L2, ntiles, G, G * ntiles, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, cl.rng,
                       so.cellmax, so.lb, so.lb_div, so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep};
     const bool masked = cl.rng || !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
     if (masked)

@@ -19,9 +19,9 @@
 //       back IN PLACE at [m][8 u + bl]; then lane (ml, u) reads row u starting at column u (a rotation of the
 //       butterfly's inputs = a unit factor on its outputs, invisible in |X|; it makes the read conflict-free),
 //       radix-8 over bl, magnitudes in registers.
-//   Two LDS round trips per point instead of three-plus-tables, four barriers per tile and two components
-//   instead of twelve-plus, every stage twiddle a per-lane constant held in registers across the tiles a
-//   (persistent) workgroup walks, the next tile's rows in flight during the transform.
+//   Two LDS round trips per point instead of three-plus-tables, three barriers per tile and two components
+//   instead of twelve-plus, every stage twiddle a per-lane constant (one coalesced load each from a per-lane table),
+//   the rows of both components in flight before anything else happens.
 //   Every LDS access class is bank-conflict free (tools/proto_cols_wave.py models the layouts lane by lane).
 //
 // Outputs (no per-tile records): per cell the packed maximum {value, first lag} by a 64-bit atomic max (rare:
@@ -92,12 +92,12 @@ struct WCols {
 #ifdef BDS_WCOLS_OCC
     static constexpr int kOcc = BDS_WCOLS_OCC;
 #else
-    static constexpr int kOcc = R1 == 4 ? 6 : R1 == 8 ? 4 : R1 == 12 ? 3 : 2;
+    static constexpr int kOcc = R1 == 4 ? 5 : R1 == 8 ? 4 : R1 == 12 ? 3 : 2;
 #endif
 };
 
 struct WColsArgs {
-    const float2 *tw;    // W_S table of the column transform, exp(-2 pi j i / S), i < S
+    const float2 *wtab;  // per-lane twiddle table of the plan (wcols_table_entries<S>())
     int L2, ntiles, G, n_items;
     const void *Bw;
     long L;
@@ -118,6 +118,13 @@ __device__ __forceinline__ unsigned long long wc_pack(float v, int lag) {
     return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(~(unsigned)lag);
 }
 
+// entries of the per-lane twiddle table of a length-S plan: (R1 - 1) x 256 for phase A (w_S^(b p), p = 1 .. R1 - 1, indexed
+// [p - 1][thread]) followed by 7 x 64 for phase B (w_64^(bl u), u = 1 .. 7, indexed [u - 1][lane]); inverse direction
+template <int S>
+__host__ __device__ constexpr int wcols_table_entries() {
+    return (WCols<S>::R1 - 1) * WCols<S>::NT + 7 * 64;
+}
+
 template <int S, int NCOMP, bool MASKED, class ST, int NV>
 __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WColsArgs A) {
     static_assert(NV >= 1 && NV <= 8, "outputs of the last radix-8 stage");
@@ -129,46 +136,37 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     const int L2 = A.L2;
     const long L = A.L;
 
-    // ---- per-lane constants -------------------------------------------------------------------------
-    // phase A: butterfly b of column pair cp
-    const int cp = lane & 3, b = 16 * wave + (lane >> 2);
-    float2 twA[R1];  // w_S^(b p), inverse direction
-#pragma unroll
-    for (int p = 1; p < R1; ++p) {
-        const float2 t = A.tw[(b * p) % S];
-        twA[p] = make_float2(t.x, -t.y);
-    }
-    float2 *const wrA = ldsf + cp * RS + b;  // + m MS
-    // phase B: stage 2 as lane (ml, bl), stage 3 as lane (ml, u) with u = bl
-    const int ml = lane & 7, bl = lane >> 3;
-    float2 twB[8];  // w_64^(bl u)
-#pragma unroll
-    for (int u = 1; u < 8; ++u) {
-        const float2 t = A.tw[(R1 * bl * u) % S];
-        twB[u] = make_float2(t.x, -t.y);
-    }
-    float2 *const rw2 = ldsf + wave * RS + ml * MS + bl;  // + s 8 MS + 8 bh (read), + 8 u (write back)
-    const float2 *rd3[8];                                 // row u from column u on: + s 8 MS
-#pragma unroll
-    for (int j = 0; j < 8; ++j) rd3[j] = ldsf + wave * RS + ml * MS + 8 * bl + ((j + bl) & 7);
-    // output (s, v) of this lane: row e = p + R1 u + 8 R1 v of column 2 wave + c, m = ml + 8 s = c R1 + p
-    int e0[SL], cc[SL];
-#pragma unroll
-    for (int s = 0; s < SL; ++s) {
-        const int m = ml + 8 * s;
-        cc[s] = m >= R1 ? 1 : 0;
-        e0[s] = m - cc[s] * R1 + R1 * bl;
+    // ---- the item of this workgroup ----------------------------------------------------------------------
+    // One tile per workgroup, workgroups started by the hardware in list order.  Workgroup id % 8 = XCD; XCD x keeps the
+    // contiguous run of tiles [x TX, (x + 1) TX) of every cell.  Its list: four adjacent tiles of one cell (they share
+    // 128-byte lines and are loaded within microseconds of each other by four workgroups that start together), then the same
+    // four of the NEXT cell (not the cell's next tiles), each XCD starting one eighth of the way further round the cells:
+    // the workgroups that run at the same time then work on different cells (~4 per cell), so that a cell's running maximum
+    // is settled by a few early waves instead of every wave of the cell seeing it unset at once.
+    // Measured alternatives (cfg3, per 201-cell launch): a persistent grid with a static item -> workgroup map drifts apart
+    // over its ~130 items and every tile refetches its lines (2.7x the HBM traffic, 2.31 ms against 1.80); persistent
+    // workgroups drawing tickets from a per-XCD atomic counter stay in order, but same-line device-scope atomics complete
+    // at ~10 M/s (9.6 ms); 2 - 8 items per workgroup with the next tile's rows prefetched: 2.16 - 2.29 ms.
+    const int TX = A.ntiles >> 3;
+    int g, c0;
+    {
+        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        const int t4 = j & 3, rest = j >> 2;
+        const int tg = rest / A.G, gi = rest - tg * A.G;
+        g = gi + xcd * (A.G >> 3);
+        g = g >= A.G ? g - A.G : g;
+        c0 = (xcd * TX + tg * 4 + t4) * W::T;
     }
 
+    // ---- rows of both components: in flight before anything else ---------------------------------------------
+    // phase A: butterfly b of column pair cp takes rows b + 64 q
+    const int cp = lane & 3, b = 16 * wave + (lane >> 2);
     using Raw = typename std::conditional<HS, uint2, float4>::type;
-    // rows b + 64 q of column pair cp of (cell g, component comp, tile)
-    // (uniform 64-bit base per row in scalar registers + one 32-bit lane offset: the loads take the saddr form
-    //  and no per-row 64-bit vector address exists)
-    const uint32_t voff = (uint32_t)((b * L2 + 2 * cp) * (int)sizeof(ST));  // < 2^22
     // (buffer loads: the descriptor of (cell, component, tile) and the row offsets live in scalar registers, the lane
     //  offset is one VGPR -- global_load with per-row 64-bit vector addresses cost two dozen VGPRs and their arithmetic;
-    //  a flat_load would also count on the LDS counter and every LDS wait of the transform would wait for the prefetch)
-    auto fetch = [&](Raw(&pre)[R1], int g, int comp, int c0) {
+    //  a flat_load would also count on the LDS counter and every LDS wait of the transform would wait for the rows)
+    const int voff = (b * L2 + 2 * cp) * (int)sizeof(ST);  // < 2^22
+    auto fetch = [&](Raw(&pre)[R1], int comp) {
         const char *base = (const char *)A.Bw + (((long)g * NCOMP + comp) * L + c0) * (long)sizeof(ST);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000);
         const int rowstep = 64 * L2 * (int)sizeof(ST);
@@ -181,24 +179,53 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
             }
 #endif
             if constexpr (HS) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, q * rowstep, 0);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, q * rowstep, 0);
                 pre[q] = make_uint2(v[0], v[1]);
             } else {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, q * rowstep, 0);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, q * rowstep, 0);
                 pre[q] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
         }
     };
-    // opaque to the scheduler: the raw rows are "produced" where this stands, nothing consuming them moves above it
-    auto pin = [](Raw(&pre)[R1]) {
+    Raw pre0[R1], pre1[NCOMP > 1 ? R1 : 1];
+    fetch(pre0, 0);
+    if constexpr (NCOMP > 1) fetch(pre1, 1);
+    // the cell's maximum so far and the PRN's running bound: read now (L2 / fabric latency), used after the transforms;
+    // stale values are lower values, which only costs a redundant visit of the rare path below
+    const int cell = A.cell0 + g;
+    float *const lbp = A.lb + cell / A.lb_div;
+    const float lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+
+    // ---- per-lane constants (coalesced from the plan's per-lane table) ------------------------------------------
+    float2 twA[R1];  // w_S^(b p), inverse direction
 #pragma unroll
-        for (int q = 0; q < R1; ++q) {
-            if constexpr (HS)
-                asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y));
-            else
-                asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y), "+v"(pre[q].z), "+v"(pre[q].w));
-        }
-    };
+    for (int p = 1; p < R1; ++p) twA[p] = A.wtab[(p - 1) * W::NT + tid];
+    float2 *const wrA = ldsf + cp * RS + b;  // + m MS
+    // phase B: stage 2 as lane (ml, bl), stage 3 as lane (ml, u) with u = bl
+    const int ml = lane & 7, bl = lane >> 3;
+    float2 twB[8];  // w_64^(bl u)
+#pragma unroll
+    for (int u = 1; u < 8; ++u) twB[u] = A.wtab[(R1 - 1) * W::NT + (u - 1) * 64 + lane];
+    float2 *const rw2 = ldsf + wave * RS + ml * MS + bl;  // + s 8 MS + 8 bh (read), + 8 u (write back)
+    const float2 *rd3[8];                                 // row u from column u on: + s 8 MS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rd3[j] = ldsf + wave * RS + ml * MS + 8 * bl + ((j + bl) & 7);
+    // lag of output (s, v) of this lane: row e = p + R1 u + 8 R1 v of column 2 wave + c (m = ml + 8 s = c R1 + p), i.e.
+    // lbase[s] + v vstep                                                                            (L < 2^31)
+    int lbase[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+        const int m = ml + 8 * s, c = m >= R1 ? 1 : 0;
+        lbase[s] = (m - c * R1 + R1 * bl) * L2 + c + 2 * wave + c0;
+    }
+    const int vstep = 8 * R1 * L2;
+    int lo1 = A.lo1, hi1 = A.hi1, lo2 = A.lo2, hi2 = A.hi2;
+    if (MASKED && A.cell_rng) {
+        const int4 r = A.cell_rng[g];
+        lo1 = r.x, hi1 = r.y, lo2 = r.z, hi2 = r.w;
+    }
+
     // first stage of both columns of the pair, twiddled
     auto phaseA = [&](const Raw(&pre)[R1], float2(&z)[2][R1]) {
 #pragma unroll
@@ -218,11 +245,14 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
             for (int p = 1; p < R1; ++p) z[c][p] = cmul(z[c][p], twA[p]);
         }
     };
-    auto storeA = [&](const float2(&z)[2][R1]) {
+    // opaque to the scheduler: the raw rows are "produced" where this stands, nothing consuming them moves above it
+    auto pin = [](Raw(&pre)[R1]) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-#pragma unroll
-            for (int p = 0; p < R1; ++p) wrA[(c * R1 + p) * MS] = z[c][p];
+        for (int q = 0; q < R1; ++q) {
+            if constexpr (HS)
+                asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y));
+            else
+                asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y), "+v"(pre[q].z), "+v"(pre[q].w));
         }
     };
     auto wave_sync = [] {  // LDS traffic of one wave is in order; this only stops the compiler from moving it
@@ -231,199 +261,144 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    // Item order.  Workgroup id % 8 = XCD; XCD x keeps the contiguous run of tiles [x TX, (x + 1) TX) of every cell.  Its
-    // list: four adjacent tiles of one cell (they share 128-byte lines), then the same four of the NEXT cell (not the cell's
-    // next tiles), each XCD starting one eighth of the way further round the cells -- the workgroups that run at the same
-    // time then work on different cells (~4 per cell), so that a cell's running maximum is settled by a few early waves
-    // instead of every wave of the cell seeing it unset at once.
-    // The grid is NOT persistent by default (one item per workgroup, gridDim = items): the hardware then starts the
-    // workgroups in list order over time and the four tiles of a line are loaded within microseconds of each other.  Measured
-    // alternatives: a persistent grid with a static item -> workgroup map drifts apart over its ~130 items per workgroup and
-    // every tile refetches its lines (2.7x the HBM traffic, the pass fabric-bound at 6 TB/s); persistent workgroups drawing
-    // tickets from a per-XCD atomic counter stay in order but device-scope atomics on one address complete at ~1.4 M/s
-    // (9.6 ms per launch instead of 2.3).
-    const int TX = A.ntiles >> 3;
-    auto item_of = [&](int it, int &g, int &c0) {
-        const int xcd = it & 7, j = it >> 3;
-        const int t4 = j & 3, rest = j >> 2;
-        const int tg = rest / A.G, gi = rest - tg * A.G;
-        g = gi + xcd * (A.G >> 3);
-        g = g >= A.G ? g - A.G : g;
-        c0 = (xcd * TX + tg * 4 + t4) * W::T;
-    };
-
-    int item = (int)blockIdx.x;
-    if (item >= A.n_items) return;
-    int g, c0;
-    item_of(item, g, c0);
-    Raw pre0[R1], pre1[NCOMP > 1 ? R1 : 1];
-    fetch(pre0, g, 0, c0);
     float mag[SL][NV];
-    for (;;) {
-        int lo1 = A.lo1, hi1 = A.hi1, lo2 = A.lo2, hi2 = A.hi2;
-        if (MASKED && A.cell_rng) {
-            const int4 r = A.cell_rng[g];
-            lo1 = r.x, hi1 = r.y, lo2 = r.z, hi2 = r.w;
-        }
-        // lag of output (s, v): lbase[s] + v vstep.  c0 goes through an opaque move so that nothing of the lag
-        // arithmetic is loop invariant (hoisted out of the tile loop it would occupy two dozen registers for a rare path)
-        int c0v = c0;
-        asm volatile("" : "+v"(c0v));
-        int lbase[SL];
+    float mx = -1.f;
 #pragma unroll
-        for (int s = 0; s < SL; ++s) lbase[s] = e0[s] * L2 + cc[s] + 2 * wave + c0v;  // L < 2^31
-        const int vstep = 8 * R1 * L2;
-        float mx = -1.f;
-        // the cell's maximum so far and the PRN's running bound: read now (L2 / fabric latency), used after the transforms;
-        // stale values are lower values, which only costs a redundant visit of the rare path below
-        const int cell = A.cell0 + g;
-        float *const lbp = A.lb + cell / A.lb_div;
-        const float lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
-        const int next = item + (int)gridDim.x;
-        int gn = 0, c0n = 0;
-        if (next < A.n_items) item_of(next, gn, c0n);
-#pragma unroll
-        for (int comp = 0; comp < NCOMP; ++comp) {
+    for (int comp = 0; comp < NCOMP; ++comp) {
+        {
             float2 z[2][R1];
-            if constexpr (NCOMP > 1) {
-                if (comp == 0) {
-                    fetch(pre1, g, 1, c0);
-                    phaseA(pre0, z);
-                } else {
-                    // (pinned here: moved up into the first component's last stage it doubles the live registers)
+            if (comp == 0) {
+                phaseA(pre0, z);
+            } else {
+                // (pinned here: moved up into the first component's last stage it doubles the live registers)
+                if constexpr (NCOMP > 1) {
                     pin(pre1);
                     phaseA(pre1, z);
                 }
-            } else {
-                phaseA(pre0, z);
             }
-            // the rows of the next tile are in flight from here on
-            if (comp == NCOMP - 1 && next < A.n_items) fetch(pre0, gn, 0, c0n);
-            BDS_WSYNC();  // every wave is through with its region (last reads of the previous transform)
-            storeA(z);
-            BDS_WSYNC();
-            // ---- phase B, one slot (= 8 of the wave's rows m) at a time so that only 16-32 points are live:
-            //   st2(s): radix 8 over bh, twiddle, back in place;  st3(s): radix 8 over bl (rotated start), magnitudes.
-            // Row m is read and written by the 8 lanes of one ml only, all in this wave, and LDS traffic of a wave is in
-            // order: st2(s) may write as soon as its own reads are in, st3(s) may read as soon as st2(s) has written.
-            // The units are software-pipelined by hand (st2(s + 1) sits between the write and the read-back of slot s)
-            // and fenced, so that the scheduler neither serialises the LDS latency nor hoists every read to the top.
-            const float w = comp == 0 ? A.w0 : A.w1;
-            auto st2 = [&](int s) {
-                float2 y[8];
+            if (comp > 0) BDS_WSYNC();  // every wave is through with its region (last reads of the previous component)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) y[q] = rw2[s * 8 * MS + 8 * q];
-                wave_sync();
-                Butterfly<8, +1>::run(y);
+            for (int c = 0; c < 2; ++c) {
 #pragma unroll
-                for (int u = 1; u < 8; ++u) y[u] = cmul(y[u], twB[u]);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) rw2[s * 8 * MS + 8 * u] = y[u];
-                wave_sync();
-            };
-            auto st3 = [&](int s) {
-                float2 y[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) y[j] = rd3[j][s * 8 * MS];
-                wave_sync();
-                Butterfly<8, +1>::run(y);
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    // (no branches in here, not even uniform ones: every basic-block boundary pins the butterfly's
-                    //  outputs in registers -- 254 VGPRs with a workgroup-uniform "row range searched at all?" test per v
-                    //  against 174 without.  Output v covers rows 8 R1 v .. 8 R1 (v + 1) - 1; the host instantiates NV = 6
-                    //  when no searched lag lies beyond row 48 R1 -- the padded transform is ~1.6 N long -- and the
-                    //  unused outputs of the last butterfly fall away at compile time.)
-                    const float2 t = y[v];
-                    // raw v_sqrt_f32 (1 ulp): the value only feeds the sieve
-                    float a = w * __builtin_amdgcn_sqrtf(t.x * t.x + t.y * t.y);
-                    if (comp > 0) a += mag[s][v];
-                    if (comp == NCOMP - 1) {
-                        // lags outside the searched ranges hold -1 from here on (searched values are >= 0)
-                        const int lag = lbase[s] + v * vstep;
-                        const bool ok = MASKED ? ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2)) : lag <= hi1;
-                        a = ok ? a : -1.f;
-                        mx = fmaxf(mx, a);
-                    }
-                    mag[s][v] = a;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            st2(0);
-#pragma unroll
-            for (int s = 0; s < SL; ++s) {
-                if (s + 1 < SL) st2(s + 1);
-                st3(s);
+                for (int p = 0; p < R1; ++p) wrA[(c * R1 + p) * MS] = z[c][p];
             }
         }
-        // ---- maximum of the wave's two columns, candidates ------------------------------------------
-        const float Mw = wave_max_f32(mx);
-#ifdef BDS_EXP_WC_NOTAIL
-        if (Mw == 1.2345f) {
-#else
-        if (Mw >= 0.f) {
-#endif  // (wave-uniform) something of these two columns is searched
-            const float thr = fmaxf(Mw, lbv) * A.keep;
-            const bool newmax = __float_as_uint(Mw) >= cur;  // this wave holds (a tie of) the cell's maximum so far
-            if (newmax || __builtin_amdgcn_ballot_w64(mx >= thr) != 0) {
-                // Rare (wave-uniform): the values go through the wave's own LDS region (free until the next barrier)
-                // and a compact loop picks the maximum's first lag and every lag within the sieve tolerance of the bound.
-                float *sm = reinterpret_cast<float *>(ldsf + wave * RS) + lane;  // [k = 8 s + v][lane]
-                wave_sync();
+        BDS_WSYNC();
+        // ---- phase B, one slot (= 8 of the wave's rows m) at a time so that only 16-32 points are live:
+        //   st2(s): radix 8 over bh, twiddle, back in place;  st3(s): radix 8 over bl (rotated start), magnitudes.
+        // Row m is read and written by the 8 lanes of one ml only, all in this wave, and LDS traffic of a wave is in
+        // order: st2(s) may write as soon as its own reads are in, st3(s) may read as soon as st2(s) has written.
+        // The units are software-pipelined by hand (st2(s + 1) sits between the write and the read-back of slot s)
+        // and fenced, so that the scheduler neither serialises the LDS latency nor hoists every read to the top.
+        const float w = comp == 0 ? A.w0 : A.w1;
+        auto st2 = [&](int s) {
+            float2 y[8];
 #pragma unroll
-                for (int s = 0; s < SL; ++s) {
+            for (int q = 0; q < 8; ++q) y[q] = rw2[s * 8 * MS + 8 * q];
+            wave_sync();
+            Butterfly<8, +1>::run(y);
 #pragma unroll
-                    for (int v = 0; v < 8; ++v) sm[(8 * s + v) * 64] = v < NV ? mag[s][v < NV ? v : 0] : -1.f;
+            for (int u = 1; u < 8; ++u) y[u] = cmul(y[u], twB[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rw2[s * 8 * MS + 8 * u] = y[u];
+            wave_sync();
+        };
+        auto st3 = [&](int s) {
+            float2 y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = rd3[j][s * 8 * MS];
+            wave_sync();
+            Butterfly<8, +1>::run(y);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                // (no branches in here, not even uniform ones: every basic-block boundary pins the butterfly's
+                //  outputs in registers -- 254 VGPRs with a workgroup-uniform "row range searched at all?" test per v
+                //  against 174 without.  Output v covers rows 8 R1 v .. 8 R1 (v + 1) - 1; the host instantiates NV = 6
+                //  when no searched lag lies beyond row 48 R1 -- the padded transform is ~1.6 N long -- and the
+                //  unused outputs of the last butterfly fall away at compile time.)
+                const float2 t = y[v];
+                // raw v_sqrt_f32 (1 ulp): the value only feeds the sieve
+                float a = w * __builtin_amdgcn_sqrtf(t.x * t.x + t.y * t.y);
+                if (comp > 0) a += mag[s][v];
+                if (comp == NCOMP - 1) {
+                    // lags outside the searched ranges hold -1 from here on (searched values are >= 0)
+                    const int lag = lbase[s] + v * vstep;
+                    const bool ok = MASKED ? ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2)) : lag <= hi1;
+                    a = ok ? a : -1.f;
+                    mx = fmaxf(mx, a);
                 }
-                wave_sync();
-                auto lag_at = [&](int k) {
-                    const int m = ml + (k & ~7), c = m >= R1 ? 1 : 0;
-                    return (m - c * R1 + R1 * bl + 8 * R1 * (k & 7)) * L2 + c0 + 2 * wave + c;
-                };
-                int best = 0x7fffffff, total = 0;
+                mag[s][v] = a;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        st2(0);
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            if (s + 1 < SL) st2(s + 1);
+            st3(s);
+        }
+    }
+    // ---- maximum of the wave's two columns, candidates ------------------------------------------
+    const float Mw = wave_max_f32(mx);
+#ifdef BDS_EXP_WC_NOTAIL
+    if (Mw == 1.2345f) {
+#else
+    if (Mw >= 0.f) {  // (wave-uniform) something of these two columns is searched
+#endif
+        const float thr = fmaxf(Mw, lbv) * A.keep;
+        const bool newmax = __float_as_uint(Mw) >= cur;  // this wave holds (a tie of) the cell's maximum so far
+        if (newmax || __builtin_amdgcn_ballot_w64(mx >= thr) != 0) {
+            // Rare (wave-uniform): the values go through the wave's own LDS region (nobody else touches it any more)
+            // and a compact loop picks the maximum's first lag and every lag within the sieve tolerance of the bound.
+            float *sm = reinterpret_cast<float *>(ldsf + wave * RS) + lane;  // [k = 8 s + v][lane]
+            wave_sync();
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+#pragma unroll
+                for (int v = 0; v < 8; ++v) sm[(8 * s + v) * 64] = v < NV ? mag[s][v < NV ? v : 0] : -1.f;
+            }
+            wave_sync();
+            auto lag_at = [&](int k) {
+                const int m = ml + (k & ~7), c = m >= R1 ? 1 : 0;
+                return (m - c * R1 + R1 * bl + 8 * R1 * (k & 7)) * L2 + c0 + 2 * wave + c;
+            };
+            int best = 0x7fffffff, total = 0;
+#pragma nounroll
+            for (int k = 0; k < 8 * SL; ++k) {
+                const float a = sm[k * 64];
+                total += __builtin_popcountll(__builtin_amdgcn_ballot_w64(a >= thr));
+                if (newmax && a == Mw) best = min(best, lag_at(k));
+            }
+            if (total > 0) {  // one reservation per wave on the list's counter
+                int base = 0;
+                if (lane == 0) base = atomicAdd(A.extra_count, total);
+                base = __builtin_amdgcn_readfirstlane(base);
 #pragma nounroll
                 for (int k = 0; k < 8 * SL; ++k) {
                     const float a = sm[k * 64];
-                    total += __builtin_popcountll(__builtin_amdgcn_ballot_w64(a >= thr));
-                    if (newmax && a == Mw) best = min(best, lag_at(k));
-                }
-                if (total > 0) {  // one reservation per wave on the list's counter
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(A.extra_count, total);
-                    base = __builtin_amdgcn_readfirstlane(base);
-#pragma nounroll
-                    for (int k = 0; k < 8 * SL; ++k) {
-                        const float a = sm[k * 64];
-                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(a >= thr);
-                        if (a >= thr) {
-                            const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                            if (idx < A.extra_cap) {
-                                Extra ex;
-                                ex.v = a;
-                                ex.lag = lag_at(k);
-                                ex.cell = cell;
-                                A.extra[idx] = ex;
-                            }
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(a >= thr);
+                    if (a >= thr) {
+                        const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if (idx < A.extra_cap) {
+                            Extra ex;
+                            ex.v = a;
+                            ex.lag = lag_at(k);
+                            ex.cell = cell;
+                            A.extra[idx] = ex;
                         }
-                        base += __builtin_popcountll(mask);
                     }
+                    base += __builtin_popcountll(mask);
                 }
-                if (newmax) {
+            }
+            if (newmax) {
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
-                    if (lane == 0) {
-                        atomicMax(A.cellmax + cell, wc_pack(Mw, best));
-                        if (Mw > lbv) atomicMax(reinterpret_cast<unsigned *>(lbp), __float_as_uint(Mw));
-                    }
+                for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+                if (lane == 0) {
+                    atomicMax(A.cellmax + cell, wc_pack(Mw, best));
+                    if (Mw > lbv) atomicMax(reinterpret_cast<unsigned *>(lbp), __float_as_uint(Mw));
                 }
-                wave_sync();
             }
         }
-        if (next >= A.n_items) break;
-        item = next;
-        g = gn;
-        c0 = c0n;
     }
 }
 

@@ -47,7 +47,6 @@ struct Tuning {
     bool no_selfcheck = false;          // BDS_ACQ_NO_SELFCHECK: timing experiments with invalid results (no re-run)
     bool test_force_fallback = false;   // BDS_ACQ_TEST_FORCE_FALLBACK: test hook, take the fp16 -> fp32 storage re-run
     int wcols = -1;                  // BDS_ACQ_WCOLS: wave-private column pass (bds_acq_wcols.h); -1 = default on, 0 = the round-2 tile kernel
-    int wcols_grid = 0;              // BDS_ACQ_WCOLS_GRID: 0 = one item per workgroup; n = persistent grid of n workgroups per CU (-1: as many as are resident)
     bool verbose = false;            // BDS_VERBOSE
     bool multi_force_rccl = false;      // BDS_MULTI_FORCE_RCCL: a single-device bds_multi still goes through RCCL (test hook)
     int trk_nblocks = 0;                // BDS_TRK_NBLOCKS: test hook, correlate workgroups per channel (0 = sized from the code rate)
@@ -76,7 +75,6 @@ struct bds_ctx {
     bds::Tuning tune;
     std::set<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit has been raised on this device
     int n_cu = 0;                          // compute units of the device
-    std::map<const void *, int> resident;  // persistent kernels: workgroups resident per CU (occupancy query, once)
 };
 
 namespace bds {

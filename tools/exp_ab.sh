@@ -15,6 +15,13 @@ ARGS="--workload b1c --prns 8 --steps 3 --warmup 1"
 run "b1c wave" A=1
 run "b1c tile (round 2)" BDS_ACQ_WCOLS=0
 for v in $(ls tools/variants/libbds_*.so 2>/dev/null); do run "b1c $v" BDS_ACQ_NO_SELFCHECK=1 BDS_LIB_PATH=$v; done
+ARGS="--workload b1c --prns 8 --steps 3 --warmup 1"
+run "b1c 1024x3072 wave" BDS_ACQ_FORCE_L1L2=1024x3072
+run "b1c 1024x3072 tile" BDS_ACQ_FORCE_L1L2=1024x3072 BDS_ACQ_WCOLS=0
 ARGS="--workload b2a --steps 10 --warmup 2"
-run "b2a wave" A=1
-run "b2a tile (round 2)" BDS_ACQ_WCOLS=0
+run "b2a default (tile at 256)" A=1
+run "b2a 512x1280 wave" BDS_ACQ_FORCE_L1L2=512x1280
+run "b2a 512x1280 tile" BDS_ACQ_FORCE_L1L2=512x1280 BDS_ACQ_WCOLS=0
+ARGS="--workload b1c --steps 5 --warmup 1"
+run "b1c full wave" A=1
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
