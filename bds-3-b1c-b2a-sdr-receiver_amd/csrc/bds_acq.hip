@@ -636,14 +636,18 @@ template <int S, int NC, bool MASKED, class ST, int NV>
 static void launch_cols_wm(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, const WColsArgs &A) {
     using W = WCols<S>;
     want_lds(ctx, k_cols_wave_f<S, NC, MASKED, ST, NV>, W::kLdsBytes);
-    hipLaunchKernelGGL((k_cols_wave_f<S, NC, MASKED, ST, NV>), dim3(A.n_items), dim3(W::NT), W::kLdsBytes, sc, A);
+    WColsArgs B = A;
+    const int quads = A.ntiles / 32;  // per XCD and cell
+    B.qchunk = std::max(1, std::min(ctx->tune.wcols_qchunk, quads));
+    while (quads % B.qchunk) --B.qchunk;
+    hipLaunchKernelGGL((k_cols_wave_f<S, NC, MASKED, ST, NV>), dim3(A.n_items), dim3(W::NT), W::kLdsBytes, sc, B);
 }
 template <int S, int NC, class ST>
 static void launch_cols_w(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1,
                           int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl) {
     const int ntiles = pl.L2 / WCols<S>::T;  // L2 % 256 == 0 on every specialised plan: ntiles % 32 == 0 (8 XCDs x quads)
     const WColsArgs A{(const float2 *)pl.d_wtab, pl.L2, ntiles, G, G * ntiles, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, cl.rng,
-                      so.cellmax, so.lb, so.lb_div, so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep};
+                      so.cellmax, so.lb, so.lb_div, so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep, 1};
     const bool masked = cl.rng || !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
     if (masked)
         launch_cols_wm<S, NC, true, ST, 8>(ctx, sc, pl, A);

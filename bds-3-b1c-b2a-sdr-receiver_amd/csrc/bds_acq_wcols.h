@@ -112,6 +112,7 @@ struct WColsArgs {
     int extra_cap;
     int cell0;                       // run-wide index of cell 0 of this launch
     float keep;                      // 1 - tolerance of the sieve
+    int qchunk;                      // adjacent quads (4 tiles = one 128-byte line per row) of a cell that follow each other in the list
 };
 
 __device__ __forceinline__ unsigned long long wc_pack(float v, int lag) {
@@ -139,10 +140,12 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     // ---- the item of this workgroup ----------------------------------------------------------------------
     // One tile per workgroup, workgroups started by the hardware in list order.  Workgroup id % 8 = XCD; XCD x keeps the
     // contiguous run of tiles [x TX, (x + 1) TX) of every cell.  Its list: four adjacent tiles of one cell (they share
-    // 128-byte lines and are loaded within microseconds of each other by four workgroups that start together), then the same
-    // four of the NEXT cell (not the cell's next tiles), each XCD starting one eighth of the way further round the cells:
-    // the workgroups that run at the same time then work on different cells (~4 per cell), so that a cell's running maximum
-    // is settled by a few early waves instead of every wave of the cell seeing it unset at once.
+    // 128-byte lines and are loaded within microseconds of each other by four workgroups that start together) and the next
+    // qchunk - 1 such quads (512 contiguous bytes per row with the default 4: DRAM page locality -- 1.70 ms per cfg3 launch
+    // against 1.84 with single lines), then the same of the NEXT cell (not the cell's next tiles), each XCD starting one
+    // eighth of the way further round the cells: the workgroups that run at the same time then work on different cells
+    // (~16 per cell), so that a cell's running maximum is settled by a few early waves instead of every wave of the cell
+    // seeing it unset at once.
     // Measured alternatives (cfg3, per 201-cell launch): a persistent grid with a static item -> workgroup map drifts apart
     // over its ~130 items and every tile refetches its lines (2.7x the HBM traffic, 2.31 ms against 1.80); persistent
     // workgroups drawing tickets from a per-XCD atomic counter stay in order, but same-line device-scope atomics complete
@@ -152,7 +155,9 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     {
         const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
         const int t4 = j & 3, rest = j >> 2;
-        const int tg = rest / A.G, gi = rest - tg * A.G;
+        const int qi = rest % A.qchunk, rest2 = rest / A.qchunk;  // qchunk adjacent quads of a cell before the next cell
+        const int tgc = rest2 / A.G, gi = rest2 - tgc * A.G;
+        const int tg = tgc * A.qchunk + qi;
         g = gi + xcd * (A.G >> 3);
         g = g >= A.G ? g - A.G : g;
         c0 = (xcd * TX + tg * 4 + t4) * W::T;
@@ -261,8 +266,8 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    float mag[SL][NV];
-    float mx = -1.f;
+    float sq[NCOMP][SL][NV];  // |y|^2 per component
+    float bmax = 0.f;         // maximum of |y_d|^2 (+ |y_p|^2) over the wave's outputs
 #pragma unroll
     for (int comp = 0; comp < NCOMP; ++comp) {
         {
@@ -290,7 +295,6 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         // order: st2(s) may write as soon as its own reads are in, st3(s) may read as soon as st2(s) has written.
         // The units are software-pipelined by hand (st2(s + 1) sits between the write and the read-back of slot s)
         // and fenced, so that the scheduler neither serialises the LDS latency nor hoists every read to the top.
-        const float w = comp == 0 ? A.w0 : A.w1;
         auto st2 = [&](int s) {
             float2 y[8];
 #pragma unroll
@@ -311,23 +315,16 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
             Butterfly<8, +1>::run(y);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                // (no branches in here, not even uniform ones: every basic-block boundary pins the butterfly's
-                //  outputs in registers -- 254 VGPRs with a workgroup-uniform "row range searched at all?" test per v
-                //  against 174 without.  Output v covers rows 8 R1 v .. 8 R1 (v + 1) - 1; the host instantiates NV = 6
-                //  when no searched lag lies beyond row 48 R1 -- the padded transform is ~1.6 N long -- and the
-                //  unused outputs of the last butterfly fall away at compile time.)
+                // Only |y|^2 is formed here; the square roots, the lag masks and the exact maximum belong to the (rare)
+                // tail below.  (And no branches in here, not even uniform ones: every basic-block boundary pins the
+                // butterfly's outputs in registers -- 254 VGPRs with a workgroup-uniform "row range searched at all?"
+                // test per v against 174 without.  Output v covers rows 8 R1 v .. 8 R1 (v + 1) - 1; the host instantiates
+                // NV = 6 when no searched lag lies beyond row 48 R1 -- the padded transform is ~1.6 N long -- and the
+                // unused outputs of the last butterfly fall away at compile time.)
                 const float2 t = y[v];
-                // raw v_sqrt_f32 (1 ulp): the value only feeds the sieve
-                float a = w * __builtin_amdgcn_sqrtf(t.x * t.x + t.y * t.y);
-                if (comp > 0) a += mag[s][v];
-                if (comp == NCOMP - 1) {
-                    // lags outside the searched ranges hold -1 from here on (searched values are >= 0)
-                    const int lag = lbase[s] + v * vstep;
-                    const bool ok = MASKED ? ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2)) : lag <= hi1;
-                    a = ok ? a : -1.f;
-                    mx = fmaxf(mx, a);
-                }
-                mag[s][v] = a;
+                const float q2 = t.x * t.x + t.y * t.y;
+                sq[comp][s][v] = q2;
+                if (comp == NCOMP - 1) bmax = fmaxf(bmax, NCOMP > 1 ? sq[0][s][v] + q2 : q2);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -339,12 +336,36 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         }
     }
     // ---- maximum of the wave's two columns, candidates ------------------------------------------
-    const float Mw = wave_max_f32(mx);
+    // Cauchy-Schwarz: (w_d |y_d| + w_p |y_p|)^2 <= (w_d^2 + w_p^2) (|y_d|^2 + |y_p|^2).  If even that bound, over all of the
+    // wave's outputs, stays below both the cell's maximum so far and the sieve threshold of the PRN's running bound, the
+    // wave has nothing to report: no square root was taken and no lag was formed -- the common case once a cell's first
+    // few workgroups are through.  (1e-5: rounding of the bound and of the squares, 40 x the fp32 unit.)
+    const float wsum2 = NCOMP > 1 ? A.w0 * A.w0 + A.w1 * A.w1 : A.w0 * A.w0;
+    const float bw = wave_max_f32(bmax) * wsum2 * 1.00001f;
+    const float curv = __uint_as_float(cur), lim = fminf(curv, lbv * A.keep);
 #ifdef BDS_EXP_WC_NOTAIL
-    if (Mw == 1.2345f) {
+    if (bw == 1.2345f) {
 #else
-    if (Mw >= 0.f) {  // (wave-uniform) something of these two columns is searched
+    if (!(bw < lim * lim)) {  // (wave-uniform; also taken while the bounds are unset or not finite)
 #endif
+        // exact values; lags outside the searched ranges hold -1 (searched values are >= 0)
+        float mag[SL][NV];
+        float mx = -1.f;
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                // raw v_sqrt_f32 (1 ulp): the value only feeds the sieve
+                float a = A.w0 * __builtin_amdgcn_sqrtf(sq[0][s][v]);
+                if constexpr (NCOMP > 1) a += A.w1 * __builtin_amdgcn_sqrtf(sq[NCOMP - 1][s][v]);
+                const int lag = lbase[s] + v * vstep;
+                const bool ok = MASKED ? ((lag >= lo1 && lag <= hi1) || (lag >= lo2 && lag <= hi2)) : lag <= hi1;
+                mag[s][v] = ok ? a : -1.f;
+                mx = fmaxf(mx, mag[s][v]);
+            }
+        }
+        const float Mw = wave_max_f32(mx);
+        if (Mw >= 0.f) {  // (wave-uniform) something of these two columns is searched
         const float thr = fmaxf(Mw, lbv) * A.keep;
         const bool newmax = __float_as_uint(Mw) >= cur;  // this wave holds (a tie of) the cell's maximum so far
         if (newmax || __builtin_amdgcn_ballot_w64(mx >= thr) != 0) {
@@ -398,6 +419,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
                     if (Mw > lbv) atomicMax(reinterpret_cast<unsigned *>(lbp), __float_as_uint(Mw));
                 }
             }
+        }
         }
     }
 }
