@@ -17,6 +17,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <exception>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -38,12 +40,21 @@ struct Rccl {
     std::string err;
     bool load() {
         if (lib) return true;
+        // BDS_RCCL_LIB names the library to load instead of the default search (deployments with RCCL elsewhere; the
+        // test that a missing library is a clean BDS_ERR_UNSUPPORTED, tests/test_multi_gpu.py)
+        const char *forced = std::getenv("BDS_RCCL_LIB");
+        std::string last = "?";
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (forced) name = forced;
+            (void)dlerror();
             lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib) break;
+            const char *e = dlerror();  // (read once: dlerror() clears the message, a second call returns NULL)
+            if (e) last = e;
+            if (forced) break;
         }
         if (!lib) {
-            err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?");
+            err = "cannot load RCCL: " + last;
             return false;
         }
 #define BDS_SYM(f)                                                         \
@@ -73,6 +84,7 @@ struct bds_multi {
     std::vector<double *> d_buf;    // per device: 4 * BDS_MAX_PRN doubles (all-reduce buffer: 3 result rows + detected)
     bds::Rccl rccl;
     bool rccl_up = false;
+    bool alias = false;             // BDS_MULTI_TEST_ALIAS: several contexts on one physical device, exchange summed on the host
     std::string err;
     int last_rccl_ranks = 0;        // communicator size reported by RCCL at the last all-reduce (diagnostics)
 };
@@ -137,15 +149,20 @@ extern "C" bds_multi *bds_multi_create(int n_devices, const int *device_ids) {
         mfail(nullptr, BDS_ERR_HIP, "no HIP device visible: libbds_mi355x has no CPU fallback");
         return nullptr;
     }
+    // Test hook BDS_MULTI_TEST_ALIAS=1 (a one-GPU box): device ids may repeat / wrap round the visible devices, so that the
+    // thread-per-device partition, the concurrent contexts and the reassembly run with n > 1; RCCL refuses two ranks on
+    // one device, so the exchange of such a handle is the same sum taken on the host.
+    const bool alias = std::getenv("BDS_MULTI_TEST_ALIAS") != nullptr;
     if (n_devices <= 0) n_devices = n;  // all visible devices
-    if (n_devices > n && !device_ids) {
+    if (n_devices > n && !device_ids && !alias) {
         mfail(nullptr, BDS_ERR_ARG, "bds_multi_create: " + std::to_string(n_devices) + " devices requested, " + std::to_string(n) + " visible");
         return nullptr;
     }
     bds_multi *m = new bds_multi();
+    m->alias = alias;
     for (int i = 0; i < n_devices; ++i) {
-        const int d = device_ids ? device_ids[i] : i;
-        if (std::find(m->dev.begin(), m->dev.end(), d) != m->dev.end()) {
+        const int d = device_ids ? device_ids[i] : (alias ? i % n : i);
+        if (!alias && std::find(m->dev.begin(), m->dev.end(), d) != m->dev.end()) {
             mfail(nullptr, BDS_ERR_ARG, "bds_multi_create: device " + std::to_string(d) + " listed twice");
             bds_multi_destroy(m);
             return nullptr;
@@ -255,6 +272,7 @@ extern "C" int bds_acquire_multi(bds_multi *m, int n_sig, const bds_acq_job *sig
     std::vector<int> dev_rc((size_t)world, BDS_OK);
     std::vector<std::string> dev_err((size_t)world);
     auto work = [&](int d) {
+      try {  // (an exception leaving a std::thread is std::terminate: a failed allocation must come back as a status)
         bds_ctx *c = m->ctx[(size_t)d];
         for (int i = 0; i < n_sig; ++i) {
             const bds_acq_job &g = sig[i];
@@ -277,6 +295,13 @@ extern "C" int bds_acquire_multi(bds_multi *m, int n_sig, const bds_acq_job *sig
             }
             for (int k = 0; k < g.max_prn; ++k) out[(size_t)3 * g.max_prn + k] = det[(size_t)k];
         }
+      } catch (const std::bad_alloc &) {
+        dev_rc[(size_t)d] = BDS_ERR_NOMEM;
+        dev_err[(size_t)d] = "device " + std::to_string(m->dev[(size_t)d]) + ": out of host memory";
+      } catch (const std::exception &e) {
+        dev_rc[(size_t)d] = BDS_ERR_HIP;
+        dev_err[(size_t)d] = "device " + std::to_string(m->dev[(size_t)d]) + ": " + e.what();
+      }
     };
     if (world == 1) {
         work(0);
@@ -294,6 +319,11 @@ extern "C" int bds_acquire_multi(bds_multi *m, int n_sig, const bds_acq_job *sig
         std::vector<double> res(cnt);
         if (world == 1 && !m->ctx[0]->tune.multi_force_rccl) {
             res = part[(size_t)i];  // a single device has nothing to exchange
+        } else if (m->alias) {
+            // test hook: the all-reduce(SUM) on the host (contexts share a physical device)
+            std::fill(res.begin(), res.end(), 0.0);
+            for (int d = 0; d < world; ++d)
+                for (size_t k = 0; k < cnt; ++k) res[k] += part[(size_t)d * n_sig + i][k];
         } else {
             for (int d = 0; d < world; ++d) {
                 (void)hipSetDevice(m->dev[(size_t)d]);

@@ -45,13 +45,15 @@ def random_sats(rng, prns, spc, cn0_dbhz=45.0, max_doppler=4500.0):
 
 
 def make_if(settings, sats, n_samples, seed=3550, sigma=20.0, codegen=None, chunk=1 << 22,
-            out=None, iq_sign=0):
+            out=None, iq_sign=0, clean=False):
     """Return int8[n_samples] of real IF samples (fileType 1), or -- iq_sign = +1 / -1 --
     int8[2*n_samples] of interleaved I/Q pairs (fileType 2) holding the analytic signal
     a(t) e^{+j th} (iq_sign +1) or its conjugate (iq_sign -1).  The reference mixes with
     exp(+j th) in both acquisition.m files and B2a/tracking.m (:309) and with exp(-j th) in
     B1C/{NB,WB}_tracking.m (:320 / :341), so a complex record needs iq_sign -1 for the former
-    and +1 for the latter to correlate."""
+    and +1 for the latter to correlate.
+    clean=True (real records only): the float64 sum of the satellites' signals, no noise, not quantised -- the caller adds
+    its own noise realisations (bench.cfg4_record builds a long record from several of them)."""
     codegen = codegen or default_codegen()
     rng = np.random.default_rng(seed)
     fs = float(settings.samplingFreq)
@@ -64,12 +66,15 @@ def make_if(settings, sats, n_samples, seed=3550, sigma=20.0, codegen=None, chun
     n_periods = int(np.ceil(n_samples * fc / fs / ncode)) + 3
     syms = {s.prn: (rng.choice([-1.0, 1.0], n_periods).astype(np.float32),
                     rng.choice([-1.0, 1.0], n_periods).astype(np.float32)) for s in sats}
-    if out is None:
+    if clean:
+        assert not iq_sign and out is None
+        out = np.empty(n_samples, dtype=np.float64)
+    elif out is None:
         out = np.empty(n_samples * (2 if iq_sign else 1), dtype=np.int8)
     for a in range(0, n_samples, chunk):
         b = min(n_samples, a + chunk)
         n = np.arange(a, b, dtype=np.float64)
-        acc = rng.normal(0.0, sigma, b - a)
+        acc = rng.normal(0.0, sigma, b - a) if not clean else np.zeros(b - a)
         if iq_sign:
             acc = acc + 1j * rng.normal(0.0, sigma, b - a)
         for s in sats:
@@ -101,6 +106,8 @@ def make_if(settings, sats, n_samples, seed=3550, sigma=20.0, codegen=None, chun
         if iq_sign:
             out[2 * a:2 * b:2] = np.clip(np.rint(acc.real), -127, 127).astype(np.int8)
             out[2 * a + 1:2 * b:2] = np.clip(np.rint(acc.imag), -127, 127).astype(np.int8)
+        elif clean:
+            out[a:b] = acc
         else:
             out[a:b] = np.clip(np.rint(acc), -127, 127).astype(np.int8)
     return out

@@ -68,30 +68,80 @@ def build_workload(name):
     return s, x, sats, label
 
 
-def cpu_baseline(s, x, name, budget_s=20.0):
-    """The oracle (NumPy/SciPy float64 restatement = 'port') timed on the host cores on a
-    bounded sample of the same workload: whole Doppler rows of one PRN until the budget is used."""
-    cores = os.cpu_count() or 1
-    os.environ["BDS_ORACLE_FFT_WORKERS"] = str(cores)
+_CPU = {}
+
+
+def _cpu_init(block_path, settings_dict, name):
+    """Worker process of the CPU baseline (spawned: no GPU state, no GIL or allocator shared with its siblings)."""
+    from types import SimpleNamespace
+
     from oracle import acquisition as oacq
 
+    _CPU["x"] = np.load(block_path).astype(np.float64)
+    _CPU["s"] = SimpleNamespace(**settings_dict)
+    _CPU["gen"] = oacq.b1c_coarse_rows if name == "b1c" else oacq.b2a_coarse_rows
+
+
+def _cpu_rows(job):
+    prn, b0, b1 = job
+    if b1 <= b0:
+        return 0
+    return sum(1 for _ in _CPU["gen"](_CPU["x"], _CPU["s"], prn, bins=range(b0, b1)))
+
+
+def cpu_baseline(s, x, name, budget_s=15.0):
+    """The oracle (NumPy/SciPy float64 restatement = 'port', not MATLAB) timed on the host cores on a bounded sample of
+    the same workload: whole (PRN, Doppler-bin) cells of the same block, code-spectrum FFTs included.
+    Two figures: ONE core (a few cells, in this process) and ALL cores -- one spawned worker process per core, each running
+    the oracle's whole row pipeline (carrier, forward FFT, two spectrum products, two inverse FFTs, magnitudes) on its share
+    of a PRN's Doppler rows.  (scipy.fft's `workers` alone does not do it -- a single 1-D transform does not parallelise,
+    which is why the round-2 figure was a one-core number under a 256-core label -- and a thread per row scaled 6x on 201
+    threads: the interpreter lock and the allocator serialise the NumPy temporaries.)  `cores` = worker processes used."""
+    import multiprocessing as mp
+    import tempfile
+
+    from oracle import acquisition as oacq
+
+    host_cores = os.cpu_count() or 1
     gen = oacq.b1c_coarse_rows if name == "b1c" else oacq.b2a_coarse_rows
+    n_bins = len(oacq.freq_bins(s))
     xf = x.astype(np.float64)
     t0 = time.perf_counter()
-    cells = 0
-    n = None
-    for prn in range(1, 64):
-        for b, row in gen(xf, s, prn):
-            n = row.size
-            cells += 1
-            if time.perf_counter() - t0 > budget_s:
-                break
-        if time.perf_counter() - t0 > budget_s:
+    cells1, n = 0, None
+    for b, row in gen(xf, s, 1):
+        n = row.size
+        cells1 += 1
+        if cells1 >= 4 or time.perf_counter() - t0 > 3.0:
             break
-    dt = time.perf_counter() - t0
-    return {"value": cells * n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{cells} (PRN, Doppler-bin) cells of the same block (code-spectrum FFTs included), "
-                      f"{dt:.1f} s, scipy.fft workers={cores}; float64 NumPy restatement of acquisition.m, not MATLAB"}
+    dt1 = time.perf_counter() - t0
+    one_core = cells1 * n / dt1 / 1e6
+    del xf
+    procs = max(1, min(host_cores, 256))
+    fd, path = tempfile.mkstemp(suffix=".npy")
+    os.close(fd)
+    cells, dt = 0, 1.0
+    try:
+        np.save(path, np.ascontiguousarray(x[:2 * n + 16]))  # (only the head of the block is ever read by the coarse search)
+        sd = {k: v for k, v in vars(s).items() if not k.startswith("_")}
+        with mp.get_context("spawn").Pool(procs, initializer=_cpu_init, initargs=(path, sd, name)) as pool:
+            pool.map(_cpu_rows, [(1, 0, 0)] * procs)  # every worker is up (imports done, block loaded)
+            per = max(1, -(-n_bins // procs))
+            prns_per_round = max(1, procs // max(1, -(-n_bins // per)))  # several PRNs per round when bins < workers
+            t0 = time.perf_counter()
+            prn = 1
+            while prn <= 63 and time.perf_counter() - t0 < budget_s:
+                jobs = [(p, b0, min(n_bins, b0 + per)) for p in range(prn, min(64, prn + prns_per_round)) for b0 in range(0, n_bins, per)]
+                cells += sum(pool.map(_cpu_rows, jobs, chunksize=1))
+                prn += prns_per_round
+            dt = time.perf_counter() - t0
+    finally:
+        os.remove(path)
+    all_cores = cells * n / dt / 1e6
+    return {"value": all_cores, "unit": "Msamples/s", "cores": procs, "host_cores": host_cores, "kind": "port",
+            "one_core_value": one_core, "all_core_speedup": all_cores / one_core,
+            "sample": f"{cells} (PRN, Doppler-bin) cells of the same block in {dt:.1f} s on {procs} worker processes (each a share of a PRN's "
+                      f"Doppler rows, code-spectrum FFTs included) + {cells1} cells in {dt1:.1f} s on one core; "
+                      "float64 NumPy restatement of acquisition.m, not MATLAB"}
 
 
 def tracking_leg(name, local_rank, base):
@@ -149,6 +199,101 @@ def tracking_leg(name, local_rank, base):
                     "(12 satellites at 47 dB-Hz, one block of whole code periods repeated)"}
 
 
+def cfg4_record(base, epochs=3600, realisations=32):
+    """BASELINE.json configs[3]: B1C wide-band tracking, 12 channels x 36 000 ms at 99.375 MS/s.  The record is built from
+    20-ms blocks: the 12 satellites' signal (47 dB-Hz, Dopplers on the 50-Hz grid: whole carrier cycles and code periods per
+    block, so it continues seamlessly from block to block and the loops lock and stay locked) plus one of `realisations`
+    independent noise realisations (sigma = 20 LSB), the blocks following each other in a seeded random order -- a single
+    repeated block would make the noise periodic and the variance-based C/N0 estimator meaningless.
+    Returns settings, channels (as preRun would hand them over), the int8 blocks [realisations][2 spc], their order in the
+    record, the shift of the record against the block grid, and the record length in samples."""
+    from types import SimpleNamespace
+
+    from bds_amd import synth
+
+    s = base.copy(msToProcess=epochs * 10, numberOfChannels=12, pilotTRKflag=2)
+    dopplers = [-1500, -1000, -750, -500, -250, -100, 100, 250, 500, 750, 1000, 1500]
+    spc = int(np.floor(s.samplingFreq / (s.codeFreqBasis / s.codeLength) + 0.5))
+    rng = np.random.default_rng(1)
+    sats = [synth.Sat(p, float(d), float(rng.uniform(0.2, 0.8)), float(rng.uniform(0, 2 * np.pi)), 47.0)
+            for p, d in zip(range(1, 13), dopplers)]
+    clean = synth.make_if(s, sats, 2 * spc, seed=7, clean=True)
+    blocks = np.empty((realisations, 2 * spc), dtype=np.int8)
+    for k in range(realisations):
+        blocks[k] = np.clip(np.rint(clean + rng.normal(0.0, 20.0, clean.size)), -127, 127).astype(np.int8)
+    shift = 12345
+    n = (epochs + 3) * spc + shift
+    order = rng.integers(0, realisations, size=n // (2 * spc) + 2)
+    ch = []
+    for sat in sats:
+        cf = s.IF + round(sat.doppler / 25) * 25
+        ch.append(SimpleNamespace(PRN=sat.prn, acquiredFreq=float(cf), codePhase=float(shift + int(np.ceil(sat.delay)) + 1),
+                                  codeFreq=float(s.codeFreqBasis - (cf - s.IF) / s.carrFreqBasis * s.codeFreqBasis), status="T"))
+    return s, ch, blocks, order, shift, n, spc
+
+
+def record_bytes(blocks, order, shift, n):
+    """The record in memory (tests at reduced length): block order[0] starts `shift` samples into the file (the file begins with
+    the tail of a block), then order[1], ..."""
+    blen = blocks.shape[1]
+    stream = np.concatenate([blocks[order[-1]][blen - shift:]] + [blocks[k] for k in order[:(n - shift) // blen + 1]])
+    return stream[:n]
+
+
+def write_record(path, blocks, order, shift, n):
+    """The same record as a raw int8 file (what the reference's fid points at)."""
+    blen = blocks.shape[1]
+    left = n
+    with open(path, "wb") as f:
+        head = blocks[order[-1]][blen - shift:]
+        f.write(head.tobytes())
+        left -= head.size
+        for k in order:
+            if left <= 0:
+                break
+            m = min(left, blen)
+            f.write(blocks[k][:m].tobytes())
+            left -= m
+    assert left == 0
+
+
+def tracking_full_leg(local_rank, base, epochs=3600, path=None):
+    """Extra key: BASELINE.json configs[3] as one piece -- 12 channels x 3 600 ten-millisecond epochs x 99.375 MS/s from a raw
+    int8 FILE, WALL time of the call: reading the window of the record the channels can touch (3.6 GB) into HBM, the
+    3 600-launch epoch loop, C/N0 on the device and the result arrays back on the host."""
+    import tempfile
+
+    import bds_amd
+
+    s, ch, blocks, order, shift, n, spc = cfg4_record(base, epochs)
+    own = path is None
+    if own:
+        fd, path = tempfile.mkstemp(prefix="bds_cfg4_", suffix=".bin", dir=os.environ.get("BDS_BENCH_TMP", tempfile.gettempdir()))
+        os.close(fd)
+    try:
+        t0 = time.perf_counter()
+        write_record(path, blocks, order, shift, n)
+        t_write = time.perf_counter() - t0
+        ctx = bds_amd.get_context(local_rank)
+        t0 = time.perf_counter()
+        res, _ = bds_amd.tracking(path, ch, s, mode="WB")
+        wall = time.perf_counter() - t0
+        dev_ms = ctx.timing()["total_ms"]
+    finally:
+        if own and os.path.exists(path):
+            os.remove(path)
+    half = epochs // 2
+    locked = sum(bool(np.abs(r.Pilot_I_P[half:]).mean() > 3 * np.abs(r.Pilot_Q_P[half:]).mean()) or
+                 bool(np.abs(r.I_P[half:]).mean() > 3 * np.abs(r.Q_P[half:]).mean()) for r in res)
+    cno = [float(np.mean(r.B1C_CNo[len(r.B1C_CNo) // 2:])) for r in res]
+    return {"mode": "WB", "channels": 12, "epochs": epochs, "completed": [int(r.completed) for r in res], "fs_MHz": s.samplingFreq / 1e6,
+            "record_GB": n / 1e9, "wall_s": wall, "device_loop_ms": dev_ms, "x_realtime_12ch_wall": epochs * 0.010 / wall,
+            "channels_locked": locked, "cno_dBHz_mean": float(np.mean(cno)), "cno_dBHz_min_max": [min(cno), max(cno)],
+            "record_write_s": t_write,
+            "note": "wall time of one WB_tracking call on a raw int8 file: file -> HBM window, 3 600 one-launch epochs, C/N0, results; "
+                    "the file itself (synthetic: the 12 satellites at 47 dB-Hz in 20-ms blocks with 32 noise realisations in random order) is written beforehand and not timed"}
+
+
 def fast_path_leg(local_rank, s, x, n_cells_samples):
     """Extra key, never `value`: the same call with the opt-in packed-fp16 search arithmetic (BDS_ACQ_HMATH=1; the f64
     refinement still decides every result).  Narrower arithmetic than the reference's, so it earns no headline."""
@@ -174,6 +319,41 @@ def fast_path_leg(local_rank, s, x, n_cells_samples):
             "note": "packed v_pk_*_f16 search arithmetic + f64 refinement; NOT the headline (narrower than the reference's single/double)"}
 
 
+def strict_f32_leg(local_rank, s, x, n_cells_samples, ncomp, n_circ):
+    """Extra key, never `value`: the same call with fp32 STORAGE of the spectra and of the inter-pass buffer as well
+    (BDS_ACQ_FP16=0): nothing between the int8 block and the f64 refinement is narrower than the reference's
+    GPU_acquisition.m (single).  Twice the bytes of the default on every pass."""
+    import bds_amd
+
+    os.environ["BDS_ACQ_FP16"] = "0"
+    try:
+        c = bds_amd.native.Context(local_rank)  # the knobs are read once, at context creation
+    finally:
+        del os.environ["BDS_ACQ_FP16"]
+    try:
+        c.acq_load(s, x)
+        c.acq_prepare(s)
+        c.acq_run(s)
+        t0 = time.perf_counter()
+        c.acq_run(s)
+        dt = time.perf_counter() - t0
+        tm = c.timing()
+    finally:
+        c.close()
+    bytes_per_pair = tm["cells_per_pair"] * 8 * (1 + ncomp) * n_circ
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_b1c_f32.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if int(tj.get("cells_per_pair", -1)) == int(tm["cells_per_pair"]):
+            traffic = tj["bytes_per_pair"] / 1e9
+    return {"dtype": "f32", "half_storage": int(tm["half_storage"]), "storage": "fp32 complex", "ms_per_step": dt * 1e3,
+            "value": n_cells_samples / dt / 1e6, "unit": "Msamples/s", "pair_ms": tm["cell_pair_ms"], "rows_ms": tm.get("rows_ms"),
+            "cols_ms": tm.get("cols_ms"), "frac": bytes_per_pair / (tm["cell_pair_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if tm["cell_pair_ms"] else None,
+            "traffic": traffic, "traffic_unit": "GB per launch pair (PMC)",
+            "note": "fp32 storage AND arithmetic end to end (one extra call); the headline stores spectra and the inter-pass buffer as fp16 complex"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,6 +363,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="skip the (untimed) tracking leg")
     ap.add_argument("--no-fast-path", action="store_true", help="skip the extra (never the headline) packed-fp16 sieve timing")
+    ap.add_argument("--no-tracking-full", action="store_true", help="skip the cfg4 leg (12 channels x 3 600 epochs from a 3.6 GB file)")
     ap.add_argument("--prns", type=int, default=63, help="tuning only: search PRNs 1..N instead of all 63")
     args = ap.parse_args()
 
@@ -314,6 +495,23 @@ def main():
         if int(tj.get("cells_per_pair", -1)) == int(cells_per_pair):
             traffic = tj["bytes_per_pair"] / 1e9  # GB per launch pair
 
+    # What binds the launch pair: SIMD issue, not HBM.  profiles/valu_<workload>.json (tools/make_valu.py) holds, per kernel,
+    # the vector instructions per dispatch counted by the hardware (PMC SQ_INSTS_VALU) and the issue cycles per instruction
+    # class from the compiler's ISA (tools/isa_mix.py: 2-cycle fp32 ops, 4-cycle packed / conversions / compares, 8-cycle
+    # square roots; LDS instructions occupy their SIMD too: 8 cycles per ds_read_b64, 24 per ds_write_b64,
+    # tools/probe/valu_rate.hip).  bound_ms = those cycles per SIMD at the 2.4 GHz peak clock.
+    valu = None
+    vpath = os.path.join(ROOT, "profiles", f"valu_{names[0]}.json")
+    if os.path.exists(vpath):
+        vj = json.load(open(vpath))
+        if int(vj.get("cells_per_pair", -1)) == int(cells_per_pair):
+            valu = {k: vj[k] for k in ("insts_per_pair", "cycles_per_inst", "lds_issue_cycles_per_simd", "valu_issue_cycles_per_simd",
+                                       "clock_GHz", "bound_ms", "kernels")}
+            valu["frac_of_issue_bound"] = vj["bound_ms"] / pair_ms if pair_ms > 0 else None
+            valu["note"] = ("SIMD-issue bound of the launch pair at the peak clock: (VALU cycles + LDS-instruction issue cycles) per SIMD / clock; "
+                            "frac_of_issue_bound = bound_ms / measured pair_ms.  An fp32 transform of 2 x 3.1 M points per cell does not fit "
+                            "into the HBM time of its operands (DESIGN.md section 1.6): 0.80 of the HBM roofline would need pair_ms <= 1.50")
+
     detected = sorted(int(p) for p in np.nonzero(res[0])[0] + 1)
     out = {
         "metric": "IF Msamples/s through acquisition (all PRNs x Doppler bins)",
@@ -344,7 +542,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "GB per launch pair (PMC)", "algorithmic_GB_per_pair": bytes_per_pair / 1e9,
-                     "kernel": "row-pass + column-pass launch pair (k_rows_inv_* + k_cols_inv_max_*; one pair = %d (PRN, bin) cells)" % int(cells_per_pair),
+                     "kernel": "row-pass + column-pass launch pair (k_rows_inv_f + k_cols_wave_f; one pair = %d (PRN, bin) cells)" % int(cells_per_pair),
+                     "valu": valu,
                      "pair_ms": pair_ms, "rows_ms": tm.get("rows_ms"), "cols_ms": tm.get("cols_ms"), "n_extra": tm.get("n_extra"),
                      "storage": "fp16 complex" if tm.get("half_storage") else "fp32 complex",
                      # `achieved` prices every spectrum element at the 8 bytes of SURVEY.md 8d's model (fp32 complex); the
@@ -357,8 +556,17 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["tracking"] = tracking_leg(names[0], local_rank, s) if world == 1 and not args.no_tracking else None
+        out["tracking_full"] = (tracking_full_leg(local_rank, s) if world == 1 and names[0] == "b1c" and not args.no_tracking
+                                and not args.no_tracking_full else None)
         out["fast_path"] = (fast_path_leg(local_rank, s, x, float(n_circ) * p_total * n_bins)
                             if world == 1 and len(sigs) == 1 and not args.no_fast_path else None)
+        import hashlib
+
+        # acqResults of the last step, per signal, as a digest: sharded / joint runs must reproduce the single-device bits
+        out["config"]["results_sha256"] = {g["name"]: hashlib.sha256(np.ascontiguousarray(np.stack(r), dtype=np.float64).tobytes()).hexdigest()
+                                           for g, r in zip(sigs, res_all)}
+        out["strict_f32"] = (strict_f32_leg(local_rank, s, x, float(n_circ) * p_total * n_bins, ncomp, n_circ)
+                             if world == 1 and len(sigs) == 1 and not args.no_fast_path else None)
         if len(sigs) > 1:
             out["config"]["satellites_detected_per_signal"] = {g["name"]: sorted(int(p) for p in np.nonzero(r[0])[0] + 1)
                                                                 for g, r in zip(sigs, res_all)}

@@ -10,7 +10,7 @@ if iq
     pairs = [real(longSignal(:)).'; imag(longSignal(:)).'];
     longSignal = pairs(:).';
 end
-if any(longSignal ~= round(longSignal)) || any(abs(longSignal) > 128)
+if any(longSignal ~= round(longSignal)) || any(longSignal > 127) || any(longSignal < -128)
     error('bds:arg', 'longSignal must hold int8 values (fread(...,''schar''))');
 end
 [carrFreq, codePhase, peakMetric, detected] = bds_mex('acquire', int8(longSignal), settings, signal, iq);

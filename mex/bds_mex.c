@@ -16,7 +16,9 @@
  *   [XcorrResult, index] = bds_mex('frame_sync', signal, PRN, bits)   % one channel: second half of
  *       xcorr(sign(bits), pattern) and find(abs(.) >= 1799.5) (B1C) / find(abs(.) > 115) (B2a)
  * signal: 1 = B1C, 2 = B2a (the reference keeps one directory per receiver).
- * Acquisition uses every GPU of the node (bds_multi_create(0, NULL); BDS_MEX_DEVICES=n limits it).
+ * Acquisition runs on ONE GPU unless BDS_MEX_DEVICES=n (n > 1, or 0 = every visible GPU) opts into the multi-device
+ * path of the library (bds_multi_create + RCCL all-reduce): that path has only ever run on one-GPU boxes (with the exchange
+ * forced, and with two contexts aliased onto one device), so it is not the default of a MATLAB session.
  * tests/test_mex_syntax.py compiles this file with -fsyntax-only against a header that declares the MEX API
  * (syntax evidence only: no MATLAB exists in the build image).
  */
@@ -26,7 +28,7 @@
 #include "bds_mi355x.h"
 #include "mex.h"
 
-/* One bds_multi for the MATLAB session: every visible GPU (BDS_MEX_DEVICES=n limits the count).  Acquisition
+/* One bds_multi for the MATLAB session: one GPU by default, BDS_MEX_DEVICES=n GPUs (0 = all visible).  Acquisition
  * goes through bds_acquire_multi (PRN shards + RCCL all-reduce inside the library); tracking, frame sync and the
  * converters run on device 0 of it (tracking needs no exchange: replicas only). */
 static bds_multi *g_multi = NULL;
@@ -39,7 +41,7 @@ static void cleanup(void) {
 static bds_multi *multi(void) {
     if (!g_multi) {
         const char *e = getenv("BDS_MEX_DEVICES");
-        g_multi = bds_multi_create(e ? atoi(e) : 0, NULL);
+        g_multi = bds_multi_create(e ? atoi(e) : 1, NULL);
         if (!g_multi) mexErrMsgIdAndTxt("bds:create", "%s", bds_multi_last_error(NULL));
         mexAtExit(cleanup);
     }

@@ -61,3 +61,21 @@ def test_bench_joint_two_ranks():
     assert d["config"]["jobs"] == 12
     per = d["config"]["satellites_detected_per_signal"]
     assert set(per) == {"b1c", "b2a"}
+
+
+def test_joint_workload_at_full_size_is_bit_equal_to_the_single_signal_runs():
+    """BASELINE.json configs[4]: B1C + B2a jointly, 63 PRNs each = 126 (signal, PRN) jobs, on the HIP path at full size:
+    one rank, and two ranks (LPT shards, one exchange per signal) sharing the one GPU of the box over gloo.  acqResults of
+    each signal must be the bits of that signal's own single-device run (zero-filled shards summed: x + 0)."""
+    b1c = run_bench(["--workload", "b1c"] + FAST)
+    b2a = run_bench(["--workload", "b2a"] + FAST)
+    want = {"b1c": b1c["config"]["results_sha256"]["b1c"], "b2a": b2a["config"]["results_sha256"]["b2a"]}
+    one = run_bench(["--workload", "joint"] + FAST)
+    check_line(one, 1)
+    assert one["config"]["jobs"] == 126 and one["config"]["jobs_rank0"] == {"b1c": 63, "b2a": 63}
+    assert one["config"]["results_sha256"] == want
+    two = run_bench(["--workload", "joint", "--gpus", "2"] + FAST, {"BDS_BENCH_TEST_ONE_DEVICE": "1"}, timeout=1500)
+    check_line(two, 2)
+    assert two["config"]["jobs"] == 126 and 0 < two["config"]["jobs_rank0"]["b1c"] < 63
+    assert two["config"]["results_sha256"] == want
+    assert sorted(two["config"]["satellites_detected_per_signal"]["b1c"]) == b1c["config"]["satellites_detected"]

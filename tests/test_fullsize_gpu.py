@@ -164,4 +164,3 @@ def test_b1c_wideband_tracking_full_rate(ctx):
             np.testing.assert_allclose(getattr(g, f), getattr(r, f), rtol=0, atol=1e-4 * p, err_msg=f)
         np.testing.assert_allclose(g.carrFreq, r.carrFreq, rtol=0, atol=1e-3)
         np.testing.assert_allclose(g.codeFreq, r.codeFreq, rtol=0, atol=1e-6)
-        assert np.abs(r.I_P).min() > 5 * np.abs(r.Q_P).max() or True  # lock quality is not a parity property

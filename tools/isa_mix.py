@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Static instruction mix of the two search kernels' hot loops from the compiler's ISA (no GPU needed):
+    hipcc ... -S bds_acq.hip -o acq.s ; python tools/isa_mix.py acq.s > profiles/r03_valu_bound.txt
+Per kernel: VALU instructions by issue class (SIMD cycles per wave-instruction measured with tools/probe/valu_rate.hip:
+2 for v_fma/add/sub/mul/mov/and/xor f32/b32, 4 for v_pk_*, v_cvt_*, v_max*, v_cmp*, v_cndmask, v_dot2*, v_alignbit, v_lshl_add,
+v_mul_lo, v_perm, 8 for v_sqrt/v_rsq/v_rcp), LDS instructions (issue cost per wave measured there too: ds_read_b64 8,
+ds_write_b64 24 cycles; a ds_read2/ds_write2_b64 counts as two) and the resulting SIMD-cycles per wave and item."""
+import collections
+import json
+import re
+import sys
+
+CYC4 = ("v_pk_", "v_cvt_", "v_max", "v_min", "v_cmp", "v_cndmask", "v_dot2", "v_alignbit", "v_lshl_add", "v_mul_lo", "v_perm", "v_mad_u", "v_lshlrev_b64", "v_mbcnt")
+CYC8 = ("v_sqrt", "v_rsq", "v_rcp", "v_sin", "v_cos", "v_exp", "v_log")
+
+
+def kernel_body(lines, pat):
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and pat in l and l.rstrip().endswith(":") or ("; @" in l and pat in l))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    return lines[start:end]
+
+
+def mix(body, lo, hi):
+    c = collections.Counter()
+    for l in body[lo:hi]:
+        l = l.split(";")[0].strip()
+        if not l or l.startswith("."):
+            continue
+        c[l.split()[0]] += 1
+    valu = {2: 0, 4: 0, 8: 0}
+    for op, n in c.items():
+        if op.startswith("v_") and not op.startswith("v_readlane") and not op.startswith("v_readfirstlane"):
+            k = 8 if op.startswith(CYC8) else 4 if op.startswith(CYC4) else 2
+            valu[k] += n
+    ds_r = sum(n * (2 if "read2" in op else 1) for op, n in c.items() if op.startswith("ds_read"))
+    ds_w = sum(n * (2 if "write2" in op else 1) for op, n in c.items() if op.startswith("ds_write"))
+    vm = sum(n for op, n in c.items() if op.startswith(("global_", "buffer_", "flat_", "scratch_")))
+    return c, valu, ds_r, ds_w, vm
+
+
+def report(name, body, lo, hi, items_note):
+    c, valu, ds_r, ds_w, vm = mix(body, lo, hi)
+    n_valu = sum(valu.values())
+    cyc_valu = sum(k * v for k, v in valu.items())
+    cyc_lds = 8 * ds_r + 24 * ds_w
+    print(f"== {name}  (ISA lines {lo}..{hi}: {items_note})")
+    print(f"   VALU instructions {n_valu}: {valu[2]} x 2 cycles, {valu[4]} x 4, {valu[8]} x 8  ->  {cyc_valu} SIMD cycles, {cyc_valu / n_valu:.2f} per instruction")
+    print(f"   LDS  {ds_r} b64 reads x 8 + {ds_w} b64 writes x 24 cycles  ->  {cyc_lds} SIMD cycles;   {vm} global/buffer memory instructions")
+    top = sorted(((n, op) for op, n in c.items() if op.startswith(("v_", "ds_"))), reverse=True)[:14]
+    print("   " + ", ".join(f"{op} {n}" for n, op in top))
+    return dict(valu_insts=n_valu, valu_cycles=cyc_valu, cycles_per_inst=cyc_valu / n_valu, lds_cycles=cyc_lds, class_counts={str(k): v for k, v in valu.items()})
+
+
+def main():
+    lines = open(sys.argv[1]).read().split("\n")
+    out = {}
+    # column pass: one tile (both components) per workgroup; everything up to the wave maximum is the hot part
+    b = kernel_body(lines, "k_cols_wave_fILi768ELi2ELb0E7__half2Li6E")
+    hi = next(i for i, l in enumerate(b) if "v_readlane_b32" in l)
+    out["cols"] = report("k_cols_wave_f<768, 2, false, __half2, 6>", b, 0, hi, "one 768 x 8 tile, 2 components = 96 point-components per lane")
+    # row pass: the per-cell loop (2 components of one 4096-point row on 256 threads)
+    b = kernel_body(lines, "k_rows_inv_fILi4096ELi2E7__half2E")
+    # the cell loop = the innermost loop that holds the barriers: from its header label to its back-edge branch
+    hdr = [(i, l.split(":")[0]) for i, l in enumerate(b) if l.startswith(".LBB") and "Depth=2" in l and "Loop" in l]
+    bar = [i for i, l in enumerate(b) if "s_barrier" in l]
+    lo, lab = max((i, n) for i, n in hdr if i < bar[2])
+    hi2 = max(i for i, l in enumerate(b) if "s_cbranch" in l and l.split()[-1] == lab)
+    out["rows"] = report("k_rows_inv_f<4096, 2, __half2>", b, lo, hi2, "one cell of one row, 2 components = 32 point-components per lane")
+    json.dump(out, open(sys.argv[2], "w"), indent=1) if len(sys.argv) > 2 else None
+
+
+if __name__ == "__main__":
+    main()

@@ -2,7 +2,7 @@
 """profiles/traffic_<workload>.json from a PMC summary (tools/pmc_run.sh -> gpurun_out/pmc_summary.txt): HBM bytes of one
 launch pair (row pass + column pass of the default fp32-arithmetic search kernels) = FETCH_SIZE x 2 (gfx950: the
 counter tallies 128-B requests as 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, averaged per dispatch.
-    python tools/make_traffic.py gpurun_out/pmc_summary.txt b1c 201 profiles/r02_b1c_pmc.txt
+    python tools/make_traffic.py gpurun_out/pmc_summary.txt b1c 201 profiles/r03_b1c_pmc.txt [column-kernel prefix]
 """
 import json
 import re
@@ -23,7 +23,7 @@ def counters(prefix):
 
 
 rn, r = counters("k_rows_inv_f")
-cn, c = counters("k_cols_inv_max_f")
+cn, c = counters(sys.argv[5] if len(sys.argv) > 5 else "k_cols_wave_f")
 total = 1024.0 * (2 * r["FETCH_SIZE"] + r["WRITE_SIZE"] + 2 * c["FETCH_SIZE"] + c["WRITE_SIZE"])
 out = {"workload": workload, "cells_per_pair": cells, "bytes_per_pair": total,
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_run.sh), avg per dispatch of {rn} + {cn} "
@@ -33,5 +33,6 @@ out = {"workload": workload, "cells_per_pair": cells, "bytes_per_pair": total,
        "cols": {"FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"], "duration_us": c["~duration_ns"] / 1e3},
        "per_cell_MB": total / cells / 1e6}
 json.dump(out, open(f"profiles/traffic_{workload}.json", "w"), indent=1)
+
 shutil.copy(src, keep)
 print(json.dumps(out, indent=1))

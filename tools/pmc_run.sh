@@ -7,7 +7,7 @@ i=0
 while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set -d gpurun_out/pmc -o pass$i -- python bench.py $ARGS > gpurun_out/pmc_pass$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $set -d gpurun_out/pmc -o pass$i -- python bench.py $ARGS > gpurun_out/pmc_pass$i.log 2>&1
   echo "pass$i: $set rc=$?"
 done <<SETS
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
