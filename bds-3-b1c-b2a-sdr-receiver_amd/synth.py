@@ -45,7 +45,7 @@ def random_sats(rng, prns, spc, cn0_dbhz=45.0, max_doppler=4500.0):
 
 
 def make_if(settings, sats, n_samples, seed=3550, sigma=20.0, codegen=None, chunk=1 << 22,
-            out=None, iq_sign=0, clean=False):
+            out=None, iq_sign=0, clean=False, code_doppler=True, pilot61_secondary=False):
     """Return int8[n_samples] of real IF samples (fileType 1), or -- iq_sign = +1 / -1 --
     int8[2*n_samples] of interleaved I/Q pairs (fileType 2) holding the analytic signal
     a(t) e^{+j th} (iq_sign +1) or its conjugate (iq_sign -1).  The reference mixes with
@@ -53,7 +53,14 @@ def make_if(settings, sats, n_samples, seed=3550, sigma=20.0, codegen=None, chun
     B1C/{NB,WB}_tracking.m (:320 / :341), so a complex record needs iq_sign -1 for the former
     and +1 for the latter to correlate.
     clean=True (real records only): the float64 sum of the satellites' signals, no noise, not quantised -- the caller adds
-    its own noise realisations (bench.cfg4_record builds a long record from several of them)."""
+    its own noise realisations (bench.cfg4_record builds a long record from several of them).
+    code_doppler=False: the code runs at the nominal rate whatever the carrier Doppler, so that a block of whole code
+    periods repeats seamlessly (with the Doppler-scaled rate the code phase of such a record has a sawtooth of
+    f_d / carrFreqBasis x chips per block -- 0.02 chip at 1.5 kHz, a quarter of the BOC(6,1) correlation peak's half width).
+    pilot61_secondary=True: the BOC(6,1) part of the B1C pilot carries the secondary-code chip S like its BOC(1,1) part (as
+    the two sub-carriers of one pilot code do on the air).  SURVEY.md section 8d's model -- the default here -- puts S on the
+    BOC(1,1) part only; WB_tracking's QMBOC prompt -sqrt(4/33) p61 + sqrt(29/33) p11 then changes magnitude with S
+    (measured: 0.8e11 vs 1.5e11 in |P|^2), which the moments-based C/N0 estimator reads as noise."""
     codegen = codegen or default_codegen()
     rng = np.random.default_rng(seed)
     fs = float(settings.samplingFreq)
@@ -79,7 +86,7 @@ def make_if(settings, sats, n_samples, seed=3550, sigma=20.0, codegen=None, chun
             acc = acc + 1j * rng.normal(0.0, sigma, b - a)
         for s in sats:
             amp = sigma * np.sqrt(4.0 * 10 ** (s.cn0_dbhz / 10) / fs)
-            fcode = fc * (1.0 + s.doppler / float(settings.carrFreqBasis))
+            fcode = fc * (1.0 + s.doppler / float(settings.carrFreqBasis)) if code_doppler else fc
             chips = (n - s.delay) * (fcode / fs)  # code phase in chips (may be < 0)
             period = np.floor(chips / ncode)
             cph = chips - period * ncode
@@ -93,7 +100,7 @@ def make_if(settings, sats, n_samples, seed=3550, sigma=20.0, codegen=None, chun
                 boc11 = (2.0 * sub2 - 1.0)
                 sub12 = np.floor(cph * 12).astype(np.int64) % 12  # ii-1 -> (-1)^ii
                 boc61 = np.where(sub12 % 2 == 0, -1.0, 1.0)
-                s_i = 0.5 * d_sym * cd * boc11 - np.sqrt(1 / 11) * cp * boc61
+                s_i = 0.5 * d_sym * cd * boc11 - np.sqrt(1 / 11) * cp * boc61 * (p_sym if pilot61_secondary else 1.0)
                 s_q = np.sqrt(29 / 44) * cp * boc11 * p_sym
                 base = s_i + 1j * s_q
             else:  # d sin(th) + p cos(th) = Re[(p - j d) e^{j th}]

@@ -96,7 +96,8 @@ def cpu_baseline(s, x, name, budget_s=15.0):
     the oracle's whole row pipeline (carrier, forward FFT, two spectrum products, two inverse FFTs, magnitudes) on its share
     of a PRN's Doppler rows.  (scipy.fft's `workers` alone does not do it -- a single 1-D transform does not parallelise,
     which is why the round-2 figure was a one-core number under a 256-core label -- and a thread per row scaled 6x on 201
-    threads: the interpreter lock and the allocator serialise the NumPy temporaries.)  `cores` = worker processes used."""
+    threads: the interpreter lock and the allocator serialise the NumPy temporaries.)  `cores` = worker processes used = the
+    CPUs this process may use (affinity and cgroup quota), not the cores the host shows."""
     import multiprocessing as mp
     import tempfile
 
@@ -116,7 +117,26 @@ def cpu_baseline(s, x, name, budget_s=15.0):
     dt1 = time.perf_counter() - t0
     one_core = cells1 * n / dt1 / 1e6
     del xf
-    procs = max(1, min(host_cores, 256))
+    # CPUs this process may really use: the scheduler affinity and the cgroup CPU quota (a container that shows 256 cores
+    # under a 16-CPU quota gets 16 cores' worth of time; more workers than that only throttle each other -- measured on the
+    # GPU box of this build's pool: 118 transforms/s with 32 workers, 41 with 256)
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:  # noqa: BLE001
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:  # noqa: BLE001
+            pass
+    if quota:
+        usable = min(usable, max(1, int(np.ceil(quota))))
+    procs = max(1, min(usable, 256))
     fd, path = tempfile.mkstemp(suffix=".npy")
     os.close(fd)
     cells, dt = 0, 1.0
@@ -137,7 +157,7 @@ def cpu_baseline(s, x, name, budget_s=15.0):
     finally:
         os.remove(path)
     all_cores = cells * n / dt / 1e6
-    return {"value": all_cores, "unit": "Msamples/s", "cores": procs, "host_cores": host_cores, "kind": "port",
+    return {"value": all_cores, "unit": "Msamples/s", "cores": procs, "host_cores": host_cores, "cgroup_cpu_quota": quota, "kind": "port",
             "one_core_value": one_core, "all_core_speedup": all_cores / one_core,
             "sample": f"{cells} (PRN, Doppler-bin) cells of the same block in {dt:.1f} s on {procs} worker processes (each a share of a PRN's "
                       f"Doppler rows, code-spectrum FFTs included) + {cells1} cells in {dt1:.1f} s on one core; "
@@ -201,8 +221,8 @@ def tracking_leg(name, local_rank, base):
 
 def cfg4_record(base, epochs=3600, realisations=32):
     """BASELINE.json configs[3]: B1C wide-band tracking, 12 channels x 36 000 ms at 99.375 MS/s.  The record is built from
-    20-ms blocks: the 12 satellites' signal (47 dB-Hz, Dopplers on the 50-Hz grid: whole carrier cycles and code periods per
-    block, so it continues seamlessly from block to block and the loops lock and stay locked) plus one of `realisations`
+    20-ms blocks: the 12 satellites' signal (47 dB-Hz, Dopplers on the 50-Hz grid and the code at its nominal rate: whole carrier
+    cycles and code periods per block, so it continues seamlessly from block to block and the loops lock and stay locked) plus one of `realisations`
     independent noise realisations (sigma = 20 LSB), the blocks following each other in a seeded random order -- a single
     repeated block would make the noise periodic and the variance-based C/N0 estimator meaningless.
     Returns settings, channels (as preRun would hand them over), the int8 blocks [realisations][2 spc], their order in the
@@ -217,7 +237,7 @@ def cfg4_record(base, epochs=3600, realisations=32):
     rng = np.random.default_rng(1)
     sats = [synth.Sat(p, float(d), float(rng.uniform(0.2, 0.8)), float(rng.uniform(0, 2 * np.pi)), 47.0)
             for p, d in zip(range(1, 13), dopplers)]
-    clean = synth.make_if(s, sats, 2 * spc, seed=7, clean=True)
+    clean = synth.make_if(s, sats, 2 * spc, seed=7, clean=True, code_doppler=False, pilot61_secondary=True)  # code at the nominal rate: seamless repetition
     blocks = np.empty((realisations, 2 * spc), dtype=np.int8)
     for k in range(realisations):
         blocks[k] = np.clip(np.rint(clean + rng.normal(0.0, 20.0, clean.size)), -127, 127).astype(np.int8)
