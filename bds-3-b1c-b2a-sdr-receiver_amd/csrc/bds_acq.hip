@@ -48,8 +48,6 @@ struct Plan2D {
     float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_hi = nullptr, *d_lo = nullptr;
     float2 *d_ftab1 = nullptr, *d_ftab2 = nullptr;  // fp32 stage-twiddle tables of the inverse column / row transform
     float2 *d_wtab = nullptr;                       // per-lane twiddle table of the wave-private column pass (bds_acq_wcols.h)
-    h2 *d_htab1 = nullptr, *d_htab2 = nullptr;  // fp16 stage-twiddle tables of the column / row transform
-    double hscale1 = 1, hscale2 = 1;            // product of the stage scales folded into them
 };
 
 static bool is_5smooth(long v) {
@@ -154,39 +152,10 @@ static int threads_for(const Plan1D &p, int T) {
 static void plan_free(Plan2D &pl) {
     for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo, &pl.d_ftab1, &pl.d_ftab2, &pl.d_wtab})
         if (*p) (void)hipFree(*p), *p = nullptr;
-    for (h2 **p : {&pl.d_htab1, &pl.d_htab2})
-        if (*p) (void)hipFree(*p), *p = nullptr;
 }
 
-// fp16 stage tables of an inverse transform (bds_fft_t.h: [q][k] per stage after the first,
-// entry = stage_scale(R) * exp(+2 pi j q k / (NS R)))
-static int upload_half_tables(bds_ctx *ctx, const Plan1D &p, h2 **dptr, double *total_scale) {
-    std::vector<h2> h;
-    int ns = 1;
-    *total_scale = 1;
-    for (int s = 0; s < p.nstage; ++s) {
-        const int R = p.radix[s];
-        if (ns > 1) {
-            const double sc = stage_scale(R);
-            *total_scale *= sc;
-            for (int q = 0; q < R; ++q)
-                for (int k = 0; k < ns; ++k) {
-                    const double a = 2.0 * kPi * (double)((long)q * k) / (double)((long)ns * R);
-                    h2 v;
-                    v.x = (_Float16)(sc * std::cos(a));
-                    v.y = (_Float16)(sc * std::sin(a));
-                    h.push_back(v);
-                }
-        }
-        ns *= R;
-    }
-    if (h.empty()) h.push_back(h2{(_Float16)1, (_Float16)0});
-    BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(h2) * h.size()));
-    BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(h2) * h.size(), hipMemcpyHostToDevice));
-    return BDS_OK;
-}
-
-// fp32 stage tables of an inverse transform: the layout of the fp16 ones, entries exp(+2 pi j q k / (NS R)) unscaled
+// fp32 stage tables of an inverse transform (bds_fft_t.h tstage TAB): per stage after the first [q][k], entries
+// exp(+2 pi j q k / (NS R))
 static int upload_stage_tables_f32(bds_ctx *ctx, const Plan1D &p, float2 **dptr) {
     std::vector<float2> h;
     int ns = 1;
@@ -283,8 +252,6 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
     if ((rc = upload_twiddles(ctx, nhi, pl.L, 1L << kTwLoBits, &pl.d_hi))) return rc;
     if ((rc = upload_twiddles(ctx, 1 << kTwLoBits, pl.L, 1, &pl.d_lo))) return rc;
     if (pl.fast) {
-        if ((rc = upload_half_tables(ctx, pl.p1, &pl.d_htab1, &pl.hscale1))) return rc;
-        if ((rc = upload_half_tables(ctx, pl.p2, &pl.d_htab2, &pl.hscale2))) return rc;
         if ((rc = upload_stage_tables_f32(ctx, pl.p1, &pl.d_ftab1))) return rc;
         if ((rc = upload_stage_tables_f32(ctx, pl.p2, &pl.d_ftab2))) return rc;
         if ((rc = upload_wcols_table(ctx, pl.L1, &pl.d_wtab))) return rc;
@@ -370,8 +337,6 @@ struct AcqState {
     int group_env = 0;
     int group = 16;
     bool half = false;         // spectra + inter-pass buffer stored as fp16 complex (specialised plans only)
-    bool hmath = false;        // ... and the search arithmetic itself in packed fp16 (k_*_h kernels)
-    float in_scale = 1.f;      // power of two applied to the spectrum row on load (fp16 arithmetic)
     double sum_abs_ext = 0;    // sum |x| over the periodically extended block: bound of |X[k]|
     double sum_sq_ext = 0;     // sum x^2 over it: X_rms^2 (Parseval)
     long sums_N = 0, sums_next = 0;  // sizes the two sums above were computed for
@@ -469,7 +434,6 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
     // default: fp32 search arithmetic on fp16-stored spectra (BDS_ACQ_FP16=0: fp32 storage;
     // BDS_ACQ_HMATH=1: the packed-fp16 arithmetic kernels)
     a.half = a.plan.fast && ctx->tune.fp16_storage != 0;
-    a.hmath = a.half && ctx->tune.hmath > 0;
     // code spectrum: |fft(code)| <= X; stored value conj(C)/L * sC, kept below 2^15
     a.sC = a.half ? (float)std::exp2(std::floor(std::log2(32768.0 * (double)a.plan.L / (double)a.X))) : 1.f;
     // primary codes of every PRN, both components
@@ -690,87 +654,6 @@ static void launch_fast_f(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const
         default: launch_cols_f<1024, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
     }
     if (so.cols_stream) (void)hipEventRecord(so.ev_cols, sc);
-}
-
-// ---- fp16-arithmetic search kernels ---------------------------------------------------------------
-template <int S, int NC>
-static void launch_rows_h(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
-                          float in_scale, CellList cl = {}) {
-    const size_t lds = sizeof(h2) * (((tspan<S>() + 3) & ~3) + half_table_entries<S>());
-    want_lds(ctx, k_rows_inv_h<S, NC>, lds);
-    // balanced chunks of at most tune.gchunk cells
-    int nch = (G + ctx->tune.gchunk - 1) / ctx->tune.gchunk;
-    int gc = (G + nch - 1) / nch;
-    if (cl.bin) gc = cl.gc, nch = (G + cl.gc - 1) / cl.gc;  // a workgroup stays inside one PRN's cells
-    const RowsHArgs A{(const h2 *)pl.d_htab2, pl.twl, (const __half2 *)Xs, pl.L, pl.L1, G, bin0, (const __half2 *)Cs, (__half2 *)Bw, in_scale, gc, nch, cl.bin, cl.cs};
-    hipLaunchKernelGGL((k_rows_inv_h<S, NC>), dim3(pl.L1 * nch), dim3(rows_threads<S>()), lds, sr, A);
-}
-template <int S, int T, int NC>
-static void launch_cols_hh(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
-                           int lo2, int hi2, Rec *recs, CellList cl = {}) {
-    const size_t lds = sizeof(h2) * (((T * tspan<S>() + 3) & ~3) + half_table_entries<S>());
-    const ColsHArgs A{(const h2 *)pl.d_htab1, pl.L2, (const __half2 *)Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles, cl.rng};
-    const bool masked = cl.rng || !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
-    if (masked) {
-        want_lds(ctx, k_cols_inv_max_h<S, T, NC, true>, lds);
-        hipLaunchKernelGGL((k_cols_inv_max_h<S, T, NC, true>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
-    } else {
-        want_lds(ctx, k_cols_inv_max_h<S, T, NC, false>, lds);
-        hipLaunchKernelGGL((k_cols_inv_max_h<S, T, NC, false>), dim3(pl.ntiles, G), dim3(cols_threads<S, T>()), lds, sc, A);
-    }
-}
-template <int S, int NC>
-static void launch_cols_h(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1, int hi1,
-                          int lo2, int hi2, Rec *recs, CellList cl = {}) {
-    if (pl.logT == 2)
-        launch_cols_hh<S, 4, NC>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl);
-    else
-        launch_cols_hh<S, 8, NC>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl);
-}
-template <int NC>
-static void launch_fast_h(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs, void *Bw,
-                          float in_scale, float w0, float w1, int lo1, int hi1, int lo2, int hi2, Rec *recs,
-                          CellList cl = {}) {
-    switch (pl.L2) {
-        case 1280: launch_rows_h<1280, NC>(ctx, sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
-        case 2048: launch_rows_h<2048, NC>(ctx, sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
-        case 3072: launch_rows_h<3072, NC>(ctx, sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
-        default: launch_rows_h<4096, NC>(ctx, sr, pl, Xs, G, bin0, Cs, Bw, in_scale, cl); break;
-    }
-    switch (pl.L1) {
-        case 256: launch_cols_h<256, NC>(ctx, sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
-        case 512: launch_cols_h<512, NC>(ctx, sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
-        case 768: launch_cols_h<768, NC>(ctx, sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
-        default: launch_cols_h<1024, NC>(ctx, sr, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, recs, cl); break;
-    }
-}
-
-// Fused row(k+1) + column(k) launch.  Instantiated for the plan pairs the cost model picks at the
-// BASELINE configs; other specialised pairs run the two kernels back to back.
-template <int S2, int S1, int T, int NC>
-static void launch_fused_tt(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const RowsHArgs &RA, const ColsHArgs &CA, int nr, int nc) {
-    const size_t lr = sizeof(h2) * (((tspan<S2>() + 3) & ~3) + half_table_entries<S2>());
-    const size_t lc = sizeof(h2) * (((T * tspan<S1>() + 3) & ~3) + half_table_entries<S1>());
-    const size_t lds = std::max(lr, lc);
-    want_lds(ctx, k_search_fused_h<S2, S1, T, NC>, lds);
-    hipLaunchKernelGGL((k_search_fused_h<S2, S1, T, NC>), dim3(8u * (unsigned)(nr + nc)), dim3(rows_threads<S2>()), lds, st_, RA, CA,
-                       nr, nc, pl.ntiles);
-}
-// Measured on MI355X: the fused launch wins on the small B2a plan (4.7 vs 5.7 ms per search: half
-// the launches, and its grids are short) and is neutral-to-worse on the B1C plan (287 vs 275 ms:
-// the mixed grid runs at the row pass's LDS footprint, which costs the column pass occupancy), so
-// the large plan only fuses on request (BDS_ACQ_FUSE=1).
-static bool fused_available(const Tuning &tune, const Plan2D &pl) {
-    if (pl.logT != 2) return false;
-    if (pl.L2 == 1280 && pl.L1 == 256) return true;
-    return pl.L2 == 4096 && pl.L1 == 768 && tune.fuse;
-}
-template <int NC>
-static void launch_fused(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const RowsHArgs &RA, const ColsHArgs &CA, int nr, int nc) {
-    if (pl.L2 == 4096)
-        launch_fused_tt<4096, 768, 4, NC>(ctx, st_, pl, RA, CA, nr, nc);
-    else
-        launch_fused_tt<1280, 256, 4, NC>(ctx, st_, pl, RA, CA, nr, nc);
 }
 
 // inter-pass work buffer: two halves of `group` cells each (float2-sized elements)
@@ -1105,16 +988,6 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         // inter-pass values: rms = X_rms * C_rms / L * sqrt(L2) (Parseval); allow 64 x rms
         const double b_rms = std::sqrt(a.sum_sq_ext) * std::sqrt((double)a.X) / (double)pl.L * std::sqrt((double)pl.L2);
         a.sB = (float)std::exp2(std::floor(std::log2(32768.0 / (64.0 * std::max(1e-30, b_rms) * a.sX * a.sC))));
-        if (a.hmath) {
-            // fp16 arithmetic: bring the spectrum product to unit RMS after the first radix-16 stage
-            // (x4 on noise-like data); later stages are rescaled inside their twiddle tables
-            // The scale goes into the stored spectrum itself (sX), so the row pass multiplies X by C
-            // as loaded: stored X rms = 1 / (4 C_rms) ~ 1e-2, |X| <= sX * sum|x| ~ 15, well inside fp16.
-            const double p_rms1 = std::sqrt(a.sum_sq_ext) * std::sqrt((double)a.X) * a.sC / (double)pl.L;  // at sX = 1
-            a.sX = (float)std::exp2(std::round(std::log2(1.0 / (4.0 * std::max(1e-30, p_rms1)))));
-            a.in_scale = 1.f;
-            a.sB = (float)(pl.hscale2 * pl.hscale1);  // total scale the kernels apply themselves
-        }
     }
 
     // ---- forward transforms, once per Doppler bin -------------------------------------
@@ -1141,11 +1014,10 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         w1 *= inv;
     }
     const Tuning &tune = ctx->tune;
-    const bool fsearch = pl.fast && !a.hmath && !a.no_fast_search;  // fp32-arithmetic specialised kernels (default)
-    const bool hsearch = pl.fast && a.hmath && !a.no_fast_search;   // packed-fp16 arithmetic kernels (opt-in)
+    const bool fsearch = pl.fast && !a.no_fast_search;  // fp32-arithmetic specialised kernels (default)
     // sieve tolerance: every lag within kDelta of a PRN's maximum is re-evaluated in f64.  fp32 storage errs by
-    // ~1e-7 of the output RMS, fp16 storage by ~3e-4, fp16 arithmetic by ~1.3e-3 (tools/sieve_error.py)
-    const double kDelta = tune.kdelta > 0 ? tune.kdelta : a.hmath ? 1e-2 : a.half ? 2e-3 : 2e-5;
+    // ~1e-7 of the output RMS, fp16 storage by ~3e-4 (tools/sieve_error.py, tools/sieve_error_cfg3.py)
+    const double kDelta = tune.kdelta > 0 ? tune.kdelta : a.half ? 2e-3 : 2e-5;
     // overflow list of the column pass: lags within kDelta of their tile's maximum (other than the tile's record)
     constexpr int kExtraCap = 1 << 22;
     {
@@ -1183,9 +1055,9 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     const size_t elem = a.half ? 4 : 8;  // bytes of one stored complex value
     // Small Doppler grids (B2a: 26 bins): one launch pair carries the whole rows of several PRNs through
     // a cell list, so that the grids fill the chip and a row workgroup still walks one PRN's bins.
-    const bool multiprn = (fsearch || hsearch) && (D <= 104 || tune.multi_any) && P > 1 && !tune.nomulti;
+    const bool multiprn = fsearch && (D <= 104 || tune.multi_any) && P > 1 && !tune.nomulti;
     // (measured at cfg2, 63 PRNs x 26 bins: 104 cells per pair 3.9 ms, 208 -> 3.6, 416 -> 3.2, 832 -> 3.1, all 1638 -> 3.0;
-    //  the fused chain 4.0); the work buffer is capped at 8 GiB
+    //  the fused fp16 chain of round 2 4.0); the work buffer is capped at 8 GiB
     const long pb_cap = std::max<long>(1, (long)(tune.pbcap_gb * 1073741824.0 / ((double)ncomp * (double)pl.L * (double)elem)));
     const long pb_cells = tune.pbcells ? tune.pbcells : pb_cap;
     const int PB = multiprn ? (int)std::min<long>(P, std::max<long>(2, std::min(pb_cells, pb_cap) / D)) : 1;
@@ -1224,13 +1096,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             so1.ev_rows = ev_rows[buf];
             so1.ev_cols = ev_cols[buf];
         }
-        if (hsearch) {
-            const void *Ch = (const __half2 *)a.d_Cs + cs_off;
-            if (ncomp == 2)
-                launch_fast_h<2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.in_scale, w0, w1, lo1, hi1, lo2, hi2, recs);
-            else
-                launch_fast_h<1>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, a.d_Bw, a.in_scale, w0, w1, lo1, hi1, lo2, hi2, recs);
-        } else if (fsearch && a.half) {
+        if (fsearch && a.half) {
             const void *Ch = (const __half2 *)a.d_Cs + cs_off;
             if (ncomp == 2)
                 launch_fast_f<2, __half2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
@@ -1264,14 +1130,9 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         so1.recs = recs;
         so1.cell0 = cell0;
         so1.mid = mid;
-        if (mid && !hsearch) mids = true;
+        if (mid) mids = true;
         const int hi1 = cl.rng ? -1 : (int)a.N - 1, lo2 = cl.rng ? 0 : 1, hi2 = cl.rng ? -1 : 0;
-        if (hsearch) {
-            if (ncomp == 2)
-                launch_fast_h<2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, hi1, lo2, hi2, recs, cl);
-            else
-                launch_fast_h<1>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.in_scale, w0, w1, 0, hi1, lo2, hi2, recs, cl);
-        } else if (a.half) {
+        if (a.half) {
             if (ncomp == 2)
                 launch_fast_f<2, __half2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
             else
@@ -1283,7 +1144,6 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
                 launch_fast_f<1, float2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
         }
     };
-    const bool fused = !multiprn && hsearch && a.half && fused_available(tune, pl) && !tune.nofuse;
     if (multiprn) {
         // float2-sized elements the PB*D cells of one launch pair occupy
         const size_t need = ((size_t)PB * D * ncomp * elem + 7) / 8;
@@ -1312,45 +1172,6 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             launch_list(np_ * D, a.d_recs + (size_t)pi0 * D * pl.ntiles, cl, pi0 * D, sample ? sm[nsamp] : nullptr);
             if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], st(ctx)));
         }
-    } else if (fused) {
-        // chain of fused launches (fp16-arithmetic kernels): launch k carries the row pass of group k and the
-        // column pass of group k-1 (the two use different halves of the inter-pass buffer)
-        struct Grp {
-            int pi, b0, nb;
-        };
-        std::vector<Grp> grps;
-        for (int pi = 0; pi < P; ++pi)
-            for (int b0 = 0; b0 < D; b0 += G) grps.push_back({pi, b0, std::min(G, D - b0)});
-        const size_t half_elems = (size_t)G * ncomp * pl.L;
-        const int ng = (int)grps.size();
-        for (int k = 0; k <= ng; ++k) {
-            RowsHArgs RA{};
-            ColsHArgs CA{};
-            int nr = 0, nc = 0;
-            if (k < ng) {
-                const Grp &gr = grps[k];
-                RA = RowsHArgs{(const h2 *)pl.d_htab2, pl.twl, (const __half2 *)a.d_Xs, pl.L, pl.L1, gr.nb, gr.b0,
-                               (const __half2 *)a.d_Cs + (size_t)a.cs_slot[prns[gr.pi]] * ncomp * pl.L,
-                               (__half2 *)a.d_Bw + (size_t)(k & 1) * half_elems, a.in_scale, 1, gr.nb};
-                // row workgroups walk through a few cells each (shorter chunks than the unfused
-                // launch: a long row workgroup late in the mixed grid would be its tail)
-                RA.NCH = (gr.nb + tune.fchunk - 1) / tune.fchunk;
-                RA.GC = (gr.nb + RA.NCH - 1) / RA.NCH;
-                nr = pl.L1 * RA.NCH / 8;
-            }
-            if (k >= 1) {
-                const Grp &gc = grps[k - 1];
-                CA = ColsHArgs{(const h2 *)pl.d_htab1, pl.L2, (const __half2 *)a.d_Bw + (size_t)((k - 1) & 1) * half_elems,
-                               pl.L, w0, w1, 0, (int)a.N - 1, 1, 0,
-                               a.d_recs + ((size_t)gc.pi * D + gc.b0) * pl.ntiles, pl.ntiles};
-                nc = pl.ntiles * gc.nb / 8;
-            }
-            if (ncomp == 2)
-                launch_fused<2>(ctx, s_main, pl, RA, CA, nr, nc);
-            else
-                launch_fused<1>(ctx, s_main, pl, RA, CA, nr, nc);
-        }
-        pair_idx = ng;
     } else {
         for (int pi = 0; pi < P; ++pi) {
             for (int b0 = 0; b0 < D; b0 += G, ++pair_idx, ++group_idx) {
@@ -1395,7 +1216,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     //    record per tile with MATLAB's first-index tie rule.
     auto rerun = [&](bool plain_kernels, const char *why) -> int {
         if (tune.verbose) fprintf(stderr, "[bds] search re-run (%s): %s\n", plain_kernels ? "run-time-plan kernels" : "fp32 storage", why);
-        a.half = a.hmath = false;
+        a.half = false;
         a.no_fast_search = a.no_fast_search || plain_kernels;
         a.sC = 1.f;
         a.cs_slot.clear();
@@ -1557,7 +1378,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         // specialised kernels: all PRNs' (PRN, winning bin) cells in one launch pair through a cell list
         // (63 tiny launch pairs were ~1 ms of the 2.7 ms refinement at cfg2)
         const size_t cap_cells = a.bw_cap / (size_t)pl.L * 8 / elem / (size_t)ncomp;  // cells the work buffer holds
-        const bool batched = (fsearch || hsearch) && (size_t)P <= cap_cells;
+        const bool batched = fsearch && (size_t)P <= cap_cells;
         BDS_HIP(ctx, hipMemsetAsync(a.d_extra_count, 0, sizeof(int), st(ctx)));  // overflow list of this pass: cell = PRN index
         std::vector<int> h_bin(P);
         std::vector<long> h_cs(P);
@@ -1780,7 +1601,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     t.n_bins = D;
     t.n_prn = P;
     t.n_comp = ncomp;
-    t.half_storage = a.hmath ? 2 : a.half ? 1 : 0;  // 0 fp32; 1 fp16 storage, fp32 arithmetic; 2 fp16 storage and arithmetic
+    t.half_storage = a.half ? 1 : 0;  // 0 fp32; 1 fp16 storage (fp32 arithmetic either way)
     return BDS_OK;
 }
 

@@ -42,15 +42,11 @@ Tuning tuning_from_env() {
     t.generic_fwd = has("BDS_ACQ_GENERIC_FWD");
     t.group = std::max(0, std::min(1024, geti("BDS_ACQ_GROUP", 0)));
     t.fp16_storage = geti("BDS_ACQ_FP16", -1);
-    t.hmath = geti("BDS_ACQ_HMATH", -1);
     t.gchunk = std::max(1, geti("BDS_ACQ_GCHUNK", 34));
     t.multi_any = has("BDS_ACQ_MULTI_ANY");
     t.nomulti = has("BDS_ACQ_NOMULTI");
     t.pbcells = std::max(0, geti("BDS_ACQ_PBCELLS", 0));
     if (const char *e = std::getenv("BDS_ACQ_PBCAP_GB")) t.pbcap_gb = std::atof(e);
-    t.fuse = has("BDS_ACQ_FUSE");
-    t.nofuse = has("BDS_ACQ_NOFUSE");
-    t.fchunk = std::max(1, geti("BDS_ACQ_FCHUNK", 2));
     t.rows_grid = std::max(0, geti("BDS_ACQ_ROWS_GRID", 0));
     t.overlap = has("BDS_ACQ_OVERLAP");
     if (const char *e = std::getenv("BDS_ACQ_KDELTA")) t.kdelta = std::max(0.0, std::min(0.9, std::atof(e)));

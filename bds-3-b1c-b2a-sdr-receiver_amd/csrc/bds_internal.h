@@ -34,13 +34,10 @@ struct Tuning {
     bool generic_fwd = false;        // BDS_ACQ_GENERIC_FWD: run-time-radix forward transforms
     int group = 0;                   // BDS_ACQ_GROUP: (PRN, bin) cells per launch pair (0 = whole Doppler row)
     int fp16_storage = -1;           // BDS_ACQ_FP16: spectra / inter-pass buffer as fp16 complex (-1 = default on)
-    int hmath = -1;                  // BDS_ACQ_HMATH: packed-fp16 search arithmetic (-1 = default off)
     int gchunk = 34;                 // BDS_ACQ_GCHUNK: cells one row-pass workgroup walks through
     bool multi_any = false, nomulti = false;  // BDS_ACQ_MULTI_ANY / BDS_ACQ_NOMULTI: multi-PRN launch pairs
     int pbcells = 0;                 // BDS_ACQ_PBCELLS
     double pbcap_gb = 8.0;           // BDS_ACQ_PBCAP_GB
-    bool fuse = false, nofuse = false;  // BDS_ACQ_FUSE / BDS_ACQ_NOFUSE (fp16-arithmetic kernels only)
-    int fchunk = 2;                  // BDS_ACQ_FCHUNK
     int rows_grid = 0;                  // BDS_ACQ_ROWS_GRID: workgroups of the (then persistent) row pass; 0 = one per item
     bool overlap = false;               // BDS_ACQ_OVERLAP: column pass of group k on a second stream beside the row pass of group k+1
     double kdelta = 0;                  // BDS_ACQ_KDELTA: test hook, sieve tolerance override (0 = per-mode default)

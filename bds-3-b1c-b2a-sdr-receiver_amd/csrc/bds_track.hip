@@ -1195,11 +1195,16 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &loa
     // per-call device buffers, released on every exit path
     struct DevScope {
         std::vector<void *> p;
+        std::vector<hipEvent_t> ev;
         void add(void *q) { p.push_back(q); }
-        ~DevScope() {
+        void release() {
             for (void *q : p)
                 if (q) (void)hipFree(q);
+            for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+            p.clear();
+            ev.clear();
         }
+        ~DevScope() { release(); }
     } scope;
     // state and partial sums ping-pong between two buffers when the loop update rides at the head of the next epoch's
     // correlate launch (default); with BDS_TRK_NOFUSE_UPDATE both halves are the same buffer and the update is its own launch
@@ -1235,9 +1240,11 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &loa
     });
     if (err) return err;
 
-    hipEvent_t ev0, ev1;
+    hipEvent_t ev0, ev1;  // (owned by the scope: every early return below destroys them)
     BDS_HIP(ctx, hipEventCreate(&ev0));
+    scope.ev.push_back(ev0);
     BDS_HIP(ctx, hipEventCreate(&ev1));
+    scope.ev.push_back(ev1);
     BDS_HIP(ctx, hipEventRecord(ev0, st(ctx)));
     const int8_t *data = t.d_data;
     dim3 gc(nblocks, n_ch);
@@ -1284,11 +1291,10 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &loa
     memset(&ctx->timing, 0, sizeof(ctx->timing));
     ctx->timing.total_ms = ms;
     ctx->timing.n_pairs = n_epochs;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     for (int c = 0; c < n_ch; ++c)
         if (hs[c].active == -2) {  // a channel read past the loaded window (code rate > 2 % low): redo with the whole record
             if (whole_file) return fail(ctx, BDS_ERR_HIP, "bds_track: channel %d left the loaded record", c + 1);
+            scope.release();  // the retry allocates its own result arrays: do not hold this attempt's beside them
             return do_track(ctx, s, load, n_bytes, n_ch, channel, out, true);
         }
 
@@ -1419,6 +1425,13 @@ extern "C" int bds_track_correlate(bds_ctx *ctx, const bds_settings *s, const in
     int8_t *d_data = nullptr;
     int *d_prn = nullptr;
     double *d_s6 = nullptr, *d_part = nullptr, *d_sums = nullptr;
+    struct Scope {  // released on every exit path
+        void **p[5];
+        ~Scope() {
+            for (void **q : p)
+                if (*q) (void)hipFree(*q);
+        }
+    } scope{{(void **)&d_data, (void **)&d_prn, (void **)&d_s6, (void **)&d_part, (void **)&d_sums}};
     BDS_HIP(ctx, hipMalloc((void **)&d_data, n_bytes + kDataSlack));
     BDS_HIP(ctx, hipMalloc((void **)&d_prn, sizeof(int) * n_ch));
     BDS_HIP(ctx, hipMalloc((void **)&d_s6, sizeof(double) * 6 * n_ch));
@@ -1434,6 +1447,5 @@ extern "C" int bds_track_correlate(bds_ctx *ctx, const bds_settings *s, const in
     BDS_HIP(ctx, hipGetLastError());
     BDS_HIP(ctx, hipMemcpyAsync(sums18, d_sums, sizeof(double) * (size_t)n_ch * kNSums, hipMemcpyDeviceToHost, st(ctx)));
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
-    for (void *q : {(void *)d_data, (void *)d_prn, (void *)d_s6, (void *)d_part, (void *)d_sums}) (void)hipFree(q);
     return BDS_OK;
 }

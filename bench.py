@@ -314,31 +314,6 @@ def tracking_full_leg(local_rank, base, epochs=3600, path=None):
                     "the file itself (synthetic: the 12 satellites at 47 dB-Hz in 20-ms blocks with 32 noise realisations in random order) is written beforehand and not timed"}
 
 
-def fast_path_leg(local_rank, s, x, n_cells_samples):
-    """Extra key, never `value`: the same call with the opt-in packed-fp16 search arithmetic (BDS_ACQ_HMATH=1; the f64
-    refinement still decides every result).  Narrower arithmetic than the reference's, so it earns no headline."""
-    import bds_amd
-
-    os.environ["BDS_ACQ_HMATH"] = "1"
-    try:
-        c = bds_amd.native.Context(local_rank)  # the knobs are read once, at context creation
-    finally:
-        del os.environ["BDS_ACQ_HMATH"]
-    try:
-        c.acq_load(s, x)
-        c.acq_prepare(s)
-        c.acq_run(s)
-        t0 = time.perf_counter()
-        c.acq_run(s)
-        dt = time.perf_counter() - t0
-        tm = c.timing()
-    finally:
-        c.close()
-    return {"dtype": "f16", "half_storage": int(tm["half_storage"]), "ms_per_step": dt * 1e3, "value": n_cells_samples / dt / 1e6,
-            "unit": "Msamples/s", "pair_ms": tm["cell_pair_ms"],
-            "note": "packed v_pk_*_f16 search arithmetic + f64 refinement; NOT the headline (narrower than the reference's single/double)"}
-
-
 def strict_f32_leg(local_rank, s, x, n_cells_samples, ncomp, n_circ):
     """Extra key, never `value`: the same call with fp32 STORAGE of the spectra and of the inter-pass buffer as well
     (BDS_ACQ_FP16=0): nothing between the int8 block and the f64 refinement is narrower than the reference's
@@ -382,7 +357,8 @@ def main():
     ap.add_argument("--workload", default="b1c", choices=["b1c", "b2a", "joint"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="skip the (untimed) tracking leg")
-    ap.add_argument("--no-fast-path", action="store_true", help="skip the extra (never the headline) packed-fp16 sieve timing")
+    ap.add_argument("--no-strict-f32", "--no-fast-path", dest="no_fast_path", action="store_true",
+                    help="skip the extra (never the headline) call with fp32 storage end to end")
     ap.add_argument("--no-tracking-full", action="store_true", help="skip the cfg4 leg (12 channels x 3 600 epochs from a 3.6 GB file)")
     ap.add_argument("--prns", type=int, default=63, help="tuning only: search PRNs 1..N instead of all 63")
     args = ap.parse_args()
@@ -544,9 +520,8 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": {0: "f32", 1: "f32", 2: "f16"}[int(tm.get("half_storage", 0))],
-        "dtype_detail": {0: "f32 search + f64 refinement", 1: "f32 search on f16-stored spectra + f64 refinement",
-                         2: "f16 search (packed v_pk_*_f16, f32 magnitudes) + f64 refinement of every candidate"}[int(tm.get("half_storage", 0))],
+        "dtype": "f32",
+        "dtype_detail": {0: "f32 search + f64 refinement", 1: "f32 search on f16-stored spectra + f64 refinement"}[int(tm.get("half_storage", 0))],
         "data": "synthetic",
         "config": {"workload": label, "prns": p_total, "doppler_bins": n_bins, "n_circ": n_circ,
                    "fft_len": tm["fft_len"], "components": ncomp,
@@ -578,8 +553,6 @@ def main():
         out["tracking"] = tracking_leg(names[0], local_rank, s) if world == 1 and not args.no_tracking else None
         out["tracking_full"] = (tracking_full_leg(local_rank, s) if world == 1 and names[0] == "b1c" and not args.no_tracking
                                 and not args.no_tracking_full else None)
-        out["fast_path"] = (fast_path_leg(local_rank, s, x, float(n_circ) * p_total * n_bins)
-                            if world == 1 and len(sigs) == 1 and not args.no_fast_path else None)
         import hashlib
 
         # acqResults of the last step, per signal, as a digest: sharded / joint runs must reproduce the single-device bits

@@ -25,7 +25,7 @@ def test_acquisition_vs_golden(ctx, name):
     np.testing.assert_array_equal(r.carrFreq, z["carrFreq"])
     np.testing.assert_allclose(r.peakMetric, z["peakMetric"], rtol=1e-6)
     rm, ra = ctx.acq_grid(*z["row_max"].shape)
-    np.testing.assert_allclose(rm, z["row_max"], rtol={0: 1e-5, 1: 1e-3, 2: 5e-3}[ctx.timing()["half_storage"]])
+    np.testing.assert_allclose(rm, z["row_max"], rtol={0: 1e-5, 1: 1e-3}[ctx.timing()["half_storage"]])
 
 
 @pytest.mark.parametrize("name", ["trk_b2a_small", "trk_nb_small", "trk_wb_small"])
