@@ -220,6 +220,82 @@ extern "C" double bds_calc_weighing_factor(const bds_settings *s) {
     return t1 / (t1 + t2);
 }
 
+// preRun.m:61-76 on the device: one wave; lane p owns PRN p + 1.  sort(peakMetric, 'descend') is stable, so the rank
+// of PRN p is the number of PRNs with a larger metric plus the number of EARLIER PRNs with an equal one.
+__global__ void k_pre_run(int max_prn, int nch, int b1c, double codeFreqBasis, double IF, double carrFreqBasis,
+                          const double *__restrict__ carrFreq, const double *__restrict__ codePhase,
+                          const double *__restrict__ peakMetric, bds_channel *__restrict__ channel) {
+    __shared__ double pm[64];
+    __shared__ int ndet_s;
+    const int p = (int)threadIdx.x;
+    if (p == 0) ndet_s = 0;
+    pm[p] = p < max_prn ? peakMetric[p] : 0.0;
+    __syncthreads();
+    if (p < nch) {
+        bds_channel c;
+        c.PRN = 0;
+        c.status = '-';
+        c.acquiredFreq = c.codePhase = c.codeFreq = 0;
+        channel[p] = c;
+    }
+    if (p < max_prn && carrFreq[p] != 0) atomicAdd(&ndet_s, 1);
+    __syncthreads();
+    if (p >= max_prn) return;
+    int rank = 0;
+    for (int j = 0; j < max_prn; ++j) rank += (pm[j] > pm[p]) || (pm[j] == pm[p] && j < p);
+    const int ndet = ndet_s;
+    if (rank < (nch < ndet ? nch : ndet)) {
+        bds_channel c;
+        c.PRN = p + 1;
+        c.acquiredFreq = carrFreq[p];
+        c.codePhase = codePhase[p];
+        // B1C/include/preRun.m:71-73 (Doppler aiding) / B2a/include/preRun.m:70; the division before the product, as
+        // the reference writes it (this file is compiled with -ffp-contract=off)
+        c.codeFreq = b1c ? codeFreqBasis - (c.acquiredFreq - IF) / carrFreqBasis * codeFreqBasis : codeFreqBasis;
+        c.status = 'T';
+        channel[rank] = c;
+    }
+}
+
+extern "C" int bds_pre_run_device(bds_ctx *ctx, const bds_settings *s, int max_prn, const double *carrFreq,
+                                  const double *codePhase, const double *peakMetric, bds_channel *channel) {
+    if (!ctx || !s || !carrFreq || !codePhase || !peakMetric || !channel || max_prn < 1 || max_prn > BDS_MAX_PRN) return BDS_ERR_ARG;
+    const int nch = s->numberOfChannels;
+    if (nch < 1 || nch > 64) return bds::fail(ctx, BDS_ERR_ARG, "numberOfChannels = %d outside 1..64", nch);
+    BDS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)ctx->stream;
+    double *d_in = nullptr;
+    bds_channel *d_ch = nullptr;
+    struct Scope {
+        void **a, **b;
+        ~Scope() {
+            if (*a) (void)hipFree(*a);
+            if (*b) (void)hipFree(*b);
+        }
+    } scope{(void **)&d_in, (void **)&d_ch};
+    BDS_HIP(ctx, hipMalloc((void **)&d_in, sizeof(double) * 3 * max_prn));
+    BDS_HIP(ctx, hipMalloc((void **)&d_ch, sizeof(bds_channel) * nch));
+    BDS_HIP(ctx, hipMemcpyAsync(d_in, carrFreq, sizeof(double) * max_prn, hipMemcpyHostToDevice, st));
+    BDS_HIP(ctx, hipMemcpyAsync(d_in + max_prn, codePhase, sizeof(double) * max_prn, hipMemcpyHostToDevice, st));
+    BDS_HIP(ctx, hipMemcpyAsync(d_in + 2 * max_prn, peakMetric, sizeof(double) * max_prn, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_pre_run, dim3(1), dim3(64), 0, st, max_prn, nch, s->signal == BDS_SIGNAL_B1C ? 1 : 0, s->codeFreqBasis, s->IF,
+                       s->carrFreqBasis, (const double *)d_in, (const double *)(d_in + max_prn), (const double *)(d_in + 2 * max_prn), d_ch);
+    BDS_HIP(ctx, hipGetLastError());
+    BDS_HIP(ctx, hipMemcpyAsync(channel, d_ch, sizeof(bds_channel) * nch, hipMemcpyDeviceToHost, st));
+    BDS_HIP(ctx, hipStreamSynchronize(st));
+    return BDS_OK;
+}
+
+extern "C" int bds_acquire_track(bds_ctx *ctx, const bds_settings *s, const int8_t *samples, size_t n_samples, int is_complex,
+                                 int max_prn, double *carrFreq, double *codePhase, double *peakMetric, int32_t *detected,
+                                 const char *path, bds_channel *channel, bds_track_out *out) {
+    if (!ctx || !s || !path || !channel || !out) return BDS_ERR_ARG;
+    int rc = bds_acquire(ctx, s, samples, n_samples, is_complex, max_prn, carrFreq, codePhase, peakMetric, detected);
+    if (rc) return rc;
+    if ((rc = bds_pre_run_device(ctx, s, max_prn, carrFreq, codePhase, peakMetric, channel))) return rc;
+    return bds_track(ctx, s, path, s->numberOfChannels, channel, out);
+}
+
 // preRun.m:61-76
 extern "C" int bds_pre_run(const bds_settings *s, int max_prn, const double *carrFreq, const double *codePhase,
                            const double *peakMetric, bds_channel *channel) {

@@ -82,7 +82,7 @@ EXPORTS = [
     "bds_create", "bds_destroy", "bds_reload_tuning", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_gen_code", "bds_acquire",
     "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_acq_candidates", "bds_get_timing",
     "bds_track", "bds_track_mem", "bds_track_loaded_bytes", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
-    "bds_calc_weighing_factor", "bds_pre_run",
+    "bds_calc_weighing_factor", "bds_pre_run", "bds_pre_run_device", "bds_acquire_track",
     "bds_multi_create", "bds_multi_destroy", "bds_multi_last_error", "bds_multi_size", "bds_multi_ctx",
     "bds_multi_rccl_ranks", "bds_acquire_multi", "bds_shard_jobs", "bds_acq_job_cost",
 ]
@@ -153,6 +153,9 @@ def lib():
     L.bds_resample_plan.restype, L.bds_resample_plan.argtypes = i32, [SP, _DP, _DP, _DP]
     L.bds_fir1_bandpass.restype, L.bds_fir1_bandpass.argtypes = i32, [i32, C.c_double, C.c_double, _DP]
     L.bds_pre_run.argtypes = [SP, i32, _DP, _DP, _DP, C.POINTER(Channel)]
+    L.bds_pre_run_device.restype, L.bds_pre_run_device.argtypes = i32, [vp, SP, i32, _DP, _DP, _DP, C.POINTER(Channel)]
+    L.bds_acquire_track.restype = i32
+    L.bds_acquire_track.argtypes = [vp, SP, i8p, sz, i32, i32, _DP, _DP, _DP, _IP, C.c_char_p, C.POINTER(Channel), C.POINTER(TrackOut)]
     L.bds_abi_check.restype, L.bds_abi_check.argtypes = i32, [i32, i32, i32, i32]
     if L.bds_abi_check(C.sizeof(Settings), C.sizeof(Channel), C.sizeof(TrackOut), C.sizeof(Timing)) != 0:
         raise ImportError("ctypes struct layout does not match libbds_mi355x.so (include/bds_mi355x.h changed?)")
@@ -490,6 +493,48 @@ class Context:
         arrays["completed"] = completed
         arrays["status"] = status
         return arrays
+
+    def _track_out(self, nch, n_epochs, n_cno, fields):
+        out = TrackOut()
+        out.n_ch, out.n_epochs, out.n_cno = nch, n_epochs, n_cno
+        arrays = {}
+        for f in fields:
+            n = n_cno if f in ("DataCNo", "DataPLD", "PilotCNo", "PilotPLD", "SigCNo") else n_epochs
+            arrays[f] = np.zeros((nch, n))
+            setattr(out, f, arrays[f].ctypes.data_as(_DP))
+        arrays["completed"] = np.zeros(nch, dtype=np.int32)
+        arrays["status"] = np.zeros(nch, dtype=np.int32)
+        out.completed = arrays["completed"].ctypes.data_as(_IP)
+        out.status = arrays["status"].ctypes.data_as(_IP)
+        return out, arrays
+
+    def pre_run_device(self, settings, carr_freq, code_phase, peak_metric):
+        """bds_pre_run_device: preRun.m:61-76 as a device kernel; returns the ctypes channel array."""
+        cs = pack_settings(settings)
+        a = np.ascontiguousarray(carr_freq, dtype=np.float64)
+        b = np.ascontiguousarray(code_phase, dtype=np.float64)
+        c = np.ascontiguousarray(peak_metric, dtype=np.float64)
+        ch = (Channel * int(settings.numberOfChannels))()
+        self._check(self._lib.bds_pre_run_device(self._h, C.byref(cs), a.size, a.ctypes.data_as(_DP), b.ctypes.data_as(_DP),
+                                                 c.ctypes.data_as(_DP), ch))
+        return ch
+
+    def acquire_track(self, settings, samples, is_complex, path, n_epochs, n_cno, fields):
+        """bds_acquire_track: acquisition -> device preRun -> tracking of the record at `path` in one native call.
+        Returns ((carrFreq, codePhase, peakMetric, detected), channel array, dict of trackResults arrays)."""
+        cs = pack_settings(settings)
+        a, p = _i8(samples)
+        n = a.size // 2 if is_complex else a.size
+        max_prn = max(int(q) for q in np.atleast_1d(settings.acqSatelliteList))
+        carr, cph, pm = np.zeros(max_prn), np.zeros(max_prn), np.zeros(max_prn)
+        det = np.zeros(max_prn, dtype=np.int32)
+        nch = int(settings.numberOfChannels)
+        ch = (Channel * nch)()
+        out, arrays = self._track_out(nch, n_epochs, n_cno, fields)
+        self._check(self._lib.bds_acquire_track(self._h, C.byref(cs), p, n, int(bool(is_complex)), max_prn, carr.ctypes.data_as(_DP),
+                                                cph.ctypes.data_as(_DP), pm.ctypes.data_as(_DP), det.ctypes.data_as(_IP),
+                                                os.fsencode(path), ch, C.byref(out)))
+        return (carr, cph, pm, det), ch, arrays
 
     def track_loaded_bytes(self) -> int:
         """Bytes of the record the last track() call copied to HBM (the window the channels can touch)."""

@@ -98,6 +98,43 @@ def tracking(fid, channel, settings, mode=None, device: int = 0):
     return out, channel
 
 
+def _results(arr, channel_prns, n_ch, ep, cn, mode):
+    sig_name = "B2a_CNo" if mode == "B2A" else "B1C_CNo"
+    out = []
+    for c in range(n_ch):
+        r = TrackResults()
+        r.status = chr(int(arr["status"][c])) if arr["status"][c] else "-"
+        for f in ep:
+            setattr(r, f, arr[f][c].copy())
+        for f in cn:
+            setattr(r, sig_name if f == "SigCNo" else f, arr[f][c].copy())
+        r.PRN = int(channel_prns[c]) if int(channel_prns[c]) != 0 else None
+        r.completed = int(arr["completed"][c])
+        out.append(r)
+    return out
+
+
+def acquire_track(long_signal, path, settings, device: int = 0):
+    """The acquisition -> preRun -> tracking section of postProcessing.m (B2a/postProcessing.m:100-123,
+    B1C/postProcessing.m:105-143) as ONE native call: bds_acquire_track runs the search, allocates the channels with a
+    device kernel (bds_pre_run_device) and tracks the record at `path` with the variant the settings select, without
+    returning to the host language in between.  Returns (acqResults, channel, trackResults)."""
+    mode = _mode(settings, None)
+    n, m, ep, cn, pilot = field_set(settings, mode)
+    x = np.asarray(long_signal)
+    is_complex = np.iscomplexobj(x)
+    if is_complex:  # fileType 2: interleaved int8 pairs, as acquisition() hands them over
+        pairs = np.empty(2 * x.size, dtype=np.int8)
+        pairs[0::2], pairs[1::2] = x.real.astype(np.int8), x.imag.astype(np.int8)
+        x = pairs
+    ctx = get_context(device)
+    (carr, cph, pm, det), ch, arr = ctx.acquire_track(settings, np.ascontiguousarray(x, dtype=np.int8), is_complex, path, n, m, ep + cn)
+    acq = SimpleNamespace(carrFreq=carr, codePhase=cph, peakMetric=pm)
+    channel = [SimpleNamespace(PRN=int(c.PRN), acquiredFreq=float(c.acquiredFreq), codePhase=float(c.codePhase),
+                               codeFreq=float(c.codeFreq), status=chr(c.status)) for c in ch]
+    return acq, channel, _results(arr, [c.PRN for c in channel], len(channel), ep, cn, mode)
+
+
 def NB_tracking(fid, channel, settings, **kw):
     """B1C/NB_tracking.m:1."""
     return tracking(fid, channel, settings, mode="NB", **kw)

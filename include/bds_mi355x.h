@@ -272,6 +272,19 @@ BDS_API double bds_calc_weighing_factor(const bds_settings *s);
 /* preRun.m:61-76 (B1C applies Doppler aiding to codeFreq, B2a does not) */
 BDS_API int bds_pre_run(const bds_settings *s, int max_prn, const double *carrFreq,
                         const double *codePhase, const double *peakMetric, bds_channel *channel);
+/* The same allocation as a device kernel (stable descending rank of peakMetric by counting, one wave): replaces the host
+ * loop of include/preRun.m:61-76 (either receiver) when acquisition and tracking are chained inside the library; `channel` (host,
+ * numberOfChannels entries) receives a copy.  Bit-identical to bds_pre_run. */
+BDS_API int bds_pre_run_device(bds_ctx *ctx, const bds_settings *s, int max_prn, const double *carrFreq,
+                               const double *codePhase, const double *peakMetric, bds_channel *channel);
+/* acquisition -> preRun -> tracking in ONE call (B2a/postProcessing.m:100-123, B1C/postProcessing.m:105-143 without the
+ * MATLAB statements between them): bds_acquire on `samples`, bds_pre_run_device on its results, bds_track on the record
+ * at `path` with the settings' own tracking variant.  acqResults (as bds_acquire) and the channel table
+ * (numberOfChannels entries) are returned beside trackResults. */
+BDS_API int bds_acquire_track(bds_ctx *ctx, const bds_settings *s, const int8_t *samples, size_t n_samples,
+                              int is_complex, int max_prn, double *carrFreq, double *codePhase,
+                              double *peakMetric, int32_t *detected, const char *path,
+                              bds_channel *channel, bds_track_out *out);
 /* ---- frame synchronisation correlators (the first consumers of trackResults) -------------
  * B1C/include/BCNAV1decoding.m:66-91: bits = sign(Pilot_I_P) (wide-band tracking) or sign(Pilot_Q_P)
  *   (narrow-band), XcorrResult = second half of xcorr(bits, generate2ndCode(PRN)) (1800 chips),
