@@ -30,6 +30,7 @@
 #include <tuple>
 
 #include "bds_acq_wcols.h"
+#include "bds_acq_wrows.h"
 #include "bds_internal.h"
 
 namespace bds {
@@ -48,6 +49,7 @@ struct Plan2D {
     float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_hi = nullptr, *d_lo = nullptr;
     float2 *d_ftab1 = nullptr, *d_ftab2 = nullptr;  // fp32 stage-twiddle tables of the inverse column / row transform
     float2 *d_wtab = nullptr;                       // per-lane twiddle table of the wave-private column pass (bds_acq_wcols.h)
+    float2 *d_wrtab = nullptr;                      // ... of the wave-private 4096-point row pass (bds_acq_wrows.h)
 };
 
 static bool is_5smooth(long v) {
@@ -150,7 +152,7 @@ static int threads_for(const Plan1D &p, int T) {
 }
 
 static void plan_free(Plan2D &pl) {
-    for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo, &pl.d_ftab1, &pl.d_ftab2, &pl.d_wtab})
+    for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo, &pl.d_ftab1, &pl.d_ftab2, &pl.d_wtab, &pl.d_wrtab})
         if (*p) (void)hipFree(*p), *p = nullptr;
 }
 
@@ -192,6 +194,28 @@ static int upload_wcols_table(bds_ctx *ctx, int S, float2 **dptr) {
             const double a = 2.0 * kPi * (double)(((lane >> 3) * u) % 64) / 64.0;
             h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
         }
+    BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * h.size()));
+    BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
+    return BDS_OK;
+}
+
+// per-lane twiddle table of the wave-private 4096-point row pass (layout: bds_acq_wrows.h), inverse direction, rounded from f64
+static int upload_wrows_table(bds_ctx *ctx, float2 **dptr) {
+    std::vector<float2> h;
+    for (int p = 1; p < 16; ++p)
+        for (int b = 0; b < 256; ++b) {
+            const double a = 2.0 * kPi * (double)((b * p) % 4096) / 4096.0;
+            h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+        }
+    for (int u = 1; u < 16; ++u)
+        for (int lane = 0; lane < 64; ++lane) {
+            const double a = 2.0 * kPi * (double)(((lane >> 2) * u) % 256) / 256.0;
+            h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+        }
+    for (int k = 0; k < 16; ++k) {
+        const double a = 2.0 * kPi * (double)k / 16.0;
+        h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+    }
     BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * h.size()));
     BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
     return BDS_OK;
@@ -255,6 +279,7 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
         if ((rc = upload_stage_tables_f32(ctx, pl.p1, &pl.d_ftab1))) return rc;
         if ((rc = upload_stage_tables_f32(ctx, pl.p2, &pl.d_ftab2))) return rc;
         if ((rc = upload_wcols_table(ctx, pl.L1, &pl.d_wtab))) return rc;
+        if (pl.L2 == 4096 && (rc = upload_wrows_table(ctx, &pl.d_wrtab))) return rc;
     }
     pl.p1.tw = pl.d_tw1;
     pl.p2.tw = pl.d_tw2;
@@ -577,6 +602,15 @@ static void launch_rows_f(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const 
     const int nvb = pl.L1 * nch;  // L1 % 8 == 0 on every specialised plan: virtual workgroup vb sits on XCD vb % 8
     const RowsFArgs A{(const float2 *)(kF32TabRows ? pl.d_ftab2 : pl.d_tw2), pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs, nvb};
     const int grid = ctx->tune.rows_grid > 0 ? std::min(nvb, (ctx->tune.rows_grid + 7) / 8 * 8) : nvb;
+    if constexpr (S == 4096) {
+        if (ctx->tune.wrows != 0) {  // wave-private row pass (bds_acq_wrows.h): per-lane twiddle constants, 4 barriers per cell
+            RowsFArgs B = A;
+            B.tw = pl.d_wrtab;
+            want_lds(ctx, k_rows_wave_f<NC, ST>, kWRowsLdsBytes);
+            hipLaunchKernelGGL((k_rows_wave_f<NC, ST>), dim3(grid), dim3(256), kWRowsLdsBytes, sr, B);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_rows_inv_f<S, NC, ST>), dim3(grid), dim3(rows_threads<S>()), lds, sr, A);
 }
 template <int S, int T, int NC, class ST>

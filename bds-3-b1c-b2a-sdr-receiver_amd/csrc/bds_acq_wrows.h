@@ -1,0 +1,166 @@
+// Inverse row pass of the search for 4096-point rows with wave-private stages (gfx950); an alternative to k_rows_inv_f of
+// bds_acq_f32.h on the x 4096 plans (cfg3: 768 x 4096), selected by BDS_ACQ_WROWS.
+//
+// Same job and same HBM layout as that kernel -- spectrum product X_b .* conj(C_p), inverse rows (length 4096), inter-pass
+// twiddle, fp16 / fp32 store; one workgroup owns spectrum row k1 for up to GC cells, code-spectrum rows and twiddles set up
+// once, the next cell's spectrum row in flight -- organised like the wave-private column pass (bds_acq_wcols.h), decimated in
+// frequency so that the LAST stage leaves thread e'' the outputs e'' + 256 p' (coalesced stores; the 16-byte pieces are on the
+// loads, which the L1 / L2 completes to full lines):
+//
+//   r = 16 b' + q',  b' = bl + 16 bh;   e = e'' + 256 p',  e'' = u + 16 v
+//   Y_q'[u + 16 v] = sum_bl w16^(bl v) w256^(bl u) sum_bh w16^(bh u) x[16 (bl + 16 bh) + q']      wave w: q' = 4w .. 4w+3
+//   X[e'' + 256 p'] = sum_q' w16^(q' p') w4096^(q' e'') Y_q'[e'']                                  thread e''
+//
+//   phase 1a: lane (ql = lane & 3, bl = lane >> 2) forms its 16 products x[16 bl + q' + 256 bh] from registers, radix 16 over
+//       bh, twiddle w256^(bl u) from per-lane constants, to the wave's own LDS region at [64 u + lane]
+//   phase 1b: lane (ql, u = lane >> 2) reads row u starting at column u (bank-conflict free; a rotation of the butterfly's
+//       inputs = the factor w16^(-u v) on its outputs, folded into the per-lane inter-pass twiddle), radix 16 over bl, Y to the
+//       exchange buffer at [19 e'' + q']                                                            -- barrier --
+//   phase 2 : thread e'' reads its 16 q', twiddle w4096^(q' e'') from per-lane constants, radix 16, inter-pass twiddle, store.
+//   Against k_rows_inv_f: every stage twiddle is a per-lane constant (30 of them were rebuilt from four table reads with
+//   eleven complex products per butterfly and twiddled stage: 176 of its 1693 vector instructions per cell), no LDS twiddle
+//   table, 4 workgroup barriers per cell instead of 7, no LDS bank conflicts.
+//   tools/proto_rows_wave.py models the stage algebra, the lane maps and the LDS layout (conflict-free in every access class).
+#pragma once
+
+#include "bds_acq_f32.h"
+
+namespace bds {
+
+// per-lane twiddle table of the 4096-point row pass: 15 x 256 for phase 2 (w4096^(q' e''), q' = 1 .. 15, [q' - 1][thread])
+// followed by 15 x 64 for phase 1a (w256^((lane >> 2) u), u = 1 .. 15, [u - 1][lane]) and the 16 values w16^k; inverse direction
+constexpr int kWRowsTableEntries = 15 * 256 + 15 * 64 + 16;
+constexpr int kWRowsRegion = 1024;  // elements of a wave's region (4 q' x 256)
+constexpr int kWRowsXS = 19;        // elements between consecutive e'' of the exchange buffer (38 dwords: conflict-free both ways; 17 costs 7 %)
+constexpr size_t kWRowsLdsBytes = sizeof(float2) * (4 * kWRowsRegion + 256 * kWRowsXS);
+
+template <int NCOMP, class ST>
+__global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
+    constexpr bool HS = std::is_same<ST, __half2>::value;
+    constexpr int S = 4096, XS = kWRowsXS;
+    extern __shared__ __attribute__((aligned(16))) float2 ldsf[];
+    __shared__ float2 s_b[16];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long L = A.L;
+    auto wave_sync = [] {  // LDS traffic of one wave is in order; this only stops the compiler from moving it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // per-lane stage twiddles (plan constants)
+    float2 twC[16], twB[16];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) twC[q] = A.tw[(q - 1) * 256 + tid];
+#pragma unroll
+    for (int u = 1; u < 16; ++u) twB[u] = A.tw[15 * 256 + (u - 1) * 64 + lane];
+    const int ql = lane & 3, bl = lane >> 2;  // phase 1a: (ql, bl); phase 1b: (ql, u = bl)
+    const int qp = 4 * wave + ql;             // this lane's q' in phase 1
+    const int xoff = 16 * bl + qp;            // its inputs: xoff + 256 bh
+    float2 *const wr1 = ldsf + wave * kWRowsRegion + lane;                     // + 64 u
+    const float2 *const rd1 = ldsf + wave * kWRowsRegion + 64 * bl + ql;       // + 4 ((j + u) & 15)
+    float2 *const wrx = ldsf + 4 * kWRowsRegion + XS * bl + qp;                // + 16 XS v
+    const float2 *const rd2 = ldsf + 4 * kWRowsRegion + XS * tid;              // + q'
+
+    for (int vb = (int)blockIdx.x; vb < A.nvb; vb += (int)gridDim.x) {
+        const int xcd = vb & 7, m = vb >> 3;
+        const int GC = A.GC, NCH = A.NCH;
+        const int g0 = (m % NCH) * GC, k1 = (m / NCH) * 8 + xcd;
+        const int g1 = g0 + GC < A.G ? g0 + GC : A.G;
+        const ST *Cs = (const ST *)A.Cs;
+        if (A.cell_cs) Cs += A.cell_cs[g0];
+        if (tid < 16) s_b[tid] = A.twl.get<+1>((uint32_t)((long)k1 * 256 * tid));
+        // spectrum row of the next cell, raw as stored: elements xoff + 256 bh
+        typename std::conditional<HS, uint32_t, float2>::type xn[16];
+        auto fetch_x = [&](int g) {
+            const int bin = A.cell_bin ? A.cell_bin[g] : A.bin0 + g;
+            const ST *xr = (const ST *)A.Xs + (long)bin * L + (long)k1 * S + xoff;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if constexpr (HS)
+                    xn[q] = *reinterpret_cast<const uint32_t *>(xr + q * 256);
+                else
+                    xn[q] = xr[q * 256];
+            }
+        };
+        __syncthreads();  // s_b
+        // inter-pass twiddle W_L^(-k1 e) of this thread's outputs e = tid + 256 p', times the storage scale, times the factor
+        // w16^(u v) (u = tid & 15, v = tid >> 4) that undoes the rotated read of phase 1b
+        float2 wo[16];
+        {
+            float2 wi = A.twl.get<+1>((uint32_t)k1 * (uint32_t)tid);
+            wi.x *= A.out_scale;
+            wi.y *= A.out_scale;
+            wi = cmul(wi, A.tw[15 * 256 + 15 * 64 + (((tid & 15) * (tid >> 4)) & 15)]);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) wo[p] = cmul(wi, s_b[p]);
+        }
+        // (the rows are fetched after the twiddle set-up: loaded before it, they and its temporaries overflow the register file)
+        fetch_x(g0);
+        // fp16 storage: the code-spectrum rows of every component stay in registers (packed) for all cells
+        uint32_t cv[HS ? NCOMP : 1][16];
+        if constexpr (HS) {
+#pragma unroll
+            for (int comp = 0; comp < NCOMP; ++comp) {
+                const ST *cr = Cs + (long)comp * L + (long)k1 * S + xoff;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) cv[comp][q] = *reinterpret_cast<const uint32_t *>(cr + q * 256);
+            }
+        }
+        for (int g = g0; g < g1; ++g) {
+#pragma unroll
+            for (int comp = 0; comp < NCOMP; ++comp) {
+                ST *dst = (ST *)A.Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S + tid;
+                // ---- phase 1a: products, radix 16 over bh, twiddle, to the wave's region
+                float2 y[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if constexpr (HS) {
+                        // ((xi, xr) is re-formed per component: one v_alignbit against 16 registers held across both)
+                        y[q] = cmul_h(xn[q], __builtin_amdgcn_alignbit(xn[q], xn[q], 16), cv[comp][q]);
+                    } else {
+                        const ST *cr = Cs + (long)comp * L + (long)k1 * S + xoff;
+                        y[q] = cmul(xn[q], cr[q * 256]);
+                    }
+                }
+                // the last component's products are the last readers of xn: the next cell's row is fetched into the same
+                // registers while the transform and the stores run
+                if (comp == NCOMP - 1 && g + 1 < g1) fetch_x(g + 1);
+                Butterfly<16, +1>::run(y);
+#pragma unroll
+                for (int u = 1; u < 16; ++u) y[u] = cmul(y[u], twB[u]);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wr1[64 * u] = y[u];
+                wave_sync();
+                // ---- phase 1b: radix 16 over bl (rotated start), to the exchange buffer
+#pragma unroll
+                for (int j = 0; j < 16; ++j) y[j] = rd1[4 * ((j + bl) & 15)];
+                wave_sync();
+                Butterfly<16, +1>::run(y);
+                if (comp > 0 || g > g0) BDS_SYNC();  // every thread is through with the exchange buffer (previous transform)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) wrx[16 * XS * v] = y[v];
+                BDS_SYNC();
+                // ---- phase 2: twiddle, radix 16 over q', inter-pass twiddle, store
+#pragma unroll
+                for (int q = 0; q < 16; ++q) y[q] = rd2[q];
+#pragma unroll
+                for (int q = 1; q < 16; ++q) y[q] = cmul(y[q], twC[q]);
+                Butterfly<16, +1>::run(y);
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const float2 t = cmul(y[p], wo[p]);
+#ifdef BDS_EXP_ROWS_NOSTORE
+                    if (t.x == 1.2345f)
+#endif
+                    if constexpr (HS)
+                        *reinterpret_cast<uint32_t *>(dst + 256 * p) = f2_to_h2(t);
+                    else
+                        dst[256 * p] = t;
+                }
+            }
+        }
+        if (vb + (int)gridDim.x < A.nvb) BDS_SYNC();
+    }
+}
+
+}  // namespace bds

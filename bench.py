@@ -537,7 +537,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_unit": "GB per launch pair (PMC)", "algorithmic_GB_per_pair": bytes_per_pair / 1e9,
-                     "kernel": "row-pass + column-pass launch pair (k_rows_inv_f + k_cols_wave_f; one pair = %d (PRN, bin) cells)" % int(cells_per_pair),
+                     "kernel": "row-pass + column-pass launch pair (k_rows_wave_f + k_cols_wave_f; one pair = %d (PRN, bin) cells)" % int(cells_per_pair),
                      "valu": valu,
                      "pair_ms": pair_ms, "rows_ms": tm.get("rows_ms"), "cols_ms": tm.get("cols_ms"), "n_extra": tm.get("n_extra"),
                      "storage": "fp16 complex" if tm.get("half_storage") else "fp32 complex",

@@ -22,7 +22,7 @@ def counters(prefix):
     raise SystemExit(f"no kernel {prefix} in {src}")
 
 
-rn, r = counters("k_rows_inv_f")
+rn, r = counters("k_rows_")
 cn, c = counters(sys.argv[5] if len(sys.argv) > 5 else "k_cols_wave_f")
 total = 1024.0 * (2 * r["FETCH_SIZE"] + r["WRITE_SIZE"] + 2 * c["FETCH_SIZE"] + c["WRITE_SIZE"])
 out = {"workload": workload, "cells_per_pair": cells, "bytes_per_pair": total,

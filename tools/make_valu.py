@@ -25,7 +25,7 @@ def counters(prefix):
 SIMDS, CLOCK = 256 * 4, 2.4  # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
 kern = {}
 tot_valu = tot_lds = insts = 0.0
-for key, prefix in (("rows", "k_rows_inv_f"), ("cols", "k_cols_wave_f")):
+for key, prefix in (("rows", "k_rows_"), ("cols", "k_cols_wave_f")):
     name, c = counters(prefix)
     m = mix[key]
     valu_cyc = c["SQ_INSTS_VALU"] * m["cycles_per_inst"] / SIMDS

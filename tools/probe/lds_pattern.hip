@@ -63,6 +63,11 @@ int main() {
     add("stage 3 read   ml*68 + 8 u + ((j + u) & 7), j = 0", [=](int l) { return (l & 7) * MS + 8 * (l >> 3) + ((l >> 3) & 7); });
     add("stage 3 read   j = 3", [=](int l) { return (l & 7) * MS + 8 * (l >> 3) + ((3 + (l >> 3)) & 7); });
     add("stage 3 unrot  ml*68 + 8 u", [=](int l) { return (l & 7) * MS + 8 * (l >> 3); });
+    add("rows stage 2 r/w  pl*272 + bl (bl = l & 15, pl = l >> 4)", [](int l) { return (l >> 4) * 272 + (l & 15); });
+    add("rows stage 3 read pl*272 + 16 u + ((j + u) & 15), j = 0", [](int l) { return (l >> 4) * 272 + 16 * (l & 15) + ((l & 15) & 15); });
+    add("rows stage 3 read j = 5", [](int l) { return (l >> 4) * 272 + 16 * (l & 15) + ((5 + (l & 15)) & 15); });
+    add("rows stage 3 alt  pl*264 + 16 u + rot, j = 5", [](int l) { return (l >> 4) * 264 + 16 * (l & 15) + ((5 + (l & 15)) & 15); });
+    add("rows stage 3 alt  u-major lanes (pl = l & 3, u = l >> 2), j = 5", [](int l) { return (l & 3) * 272 + 16 * (l >> 2) + ((5 + (l >> 2)) & 15); });
     add("stride 2 elements (2-way by any model)", [](int l) { return 2 * l; });
     add("stride 32 elements (all one bank pair)", [](int l) { return 32 * (l & 31) + (l >> 5); });
     std::vector<int> h;
