@@ -602,12 +602,12 @@ static void launch_rows_f(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const 
     const int nvb = pl.L1 * nch;  // L1 % 8 == 0 on every specialised plan: virtual workgroup vb sits on XCD vb % 8
     const RowsFArgs A{(const float2 *)(kF32TabRows ? pl.d_ftab2 : pl.d_tw2), pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs, nvb};
     const int grid = ctx->tune.rows_grid > 0 ? std::min(nvb, (ctx->tune.rows_grid + 7) / 8 * 8) : nvb;
-    if constexpr (S == 4096) {
+    if constexpr (S == 4096 && std::is_same<ST, __half2>::value) {
         if (ctx->tune.wrows != 0) {  // wave-private row pass (bds_acq_wrows.h): per-lane twiddle constants, 4 barriers per cell
             RowsFArgs B = A;
             B.tw = pl.d_wrtab;
-            want_lds(ctx, k_rows_wave_f<NC, ST>, kWRowsLdsBytes);
-            hipLaunchKernelGGL((k_rows_wave_f<NC, ST>), dim3(grid), dim3(256), kWRowsLdsBytes, sr, B);
+            want_lds(ctx, k_rows_wave_f<NC>, kWRowsLdsBytes);
+            hipLaunchKernelGGL((k_rows_wave_f<NC>), dim3(grid), dim3(256), kWRowsLdsBytes, sr, B);
             return;
         }
     }

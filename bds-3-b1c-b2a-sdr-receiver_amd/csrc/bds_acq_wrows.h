@@ -2,7 +2,7 @@
 // bds_acq_f32.h on the x 4096 plans (cfg3: 768 x 4096), selected by BDS_ACQ_WROWS.
 //
 // Same job and same HBM layout as that kernel -- spectrum product X_b .* conj(C_p), inverse rows (length 4096), inter-pass
-// twiddle, fp16 / fp32 store; one workgroup owns spectrum row k1 for up to GC cells, code-spectrum rows and twiddles set up
+// twiddle, fp16 store (fp16 storage only); one workgroup owns spectrum row k1 for up to GC cells, code-spectrum rows and twiddles set up
 // once, the next cell's spectrum row in flight -- organised like the wave-private column pass (bds_acq_wcols.h), decimated in
 // frequency so that the LAST stage leaves thread e'' the outputs e'' + 256 p' (coalesced stores; the 16-byte pieces are on the
 // loads, which the L1 / L2 completes to full lines):
@@ -34,9 +34,9 @@ constexpr int kWRowsRegion = 1024;  // elements of a wave's region (4 q' x 256)
 constexpr int kWRowsXS = 19;        // elements between consecutive e'' of the exchange buffer (38 dwords: conflict-free both ways; 17 costs 7 %)
 constexpr size_t kWRowsLdsBytes = sizeof(float2) * (4 * kWRowsRegion + 256 * kWRowsXS);
 
-template <int NCOMP, class ST>
+template <int NCOMP>
 __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
-    constexpr bool HS = std::is_same<ST, __half2>::value;
+    using ST = __half2;  // fp16 storage only: with fp32 storage the 32-byte load pieces cost more than the stages save (5.2 vs 3.1 ms)
     constexpr int S = 4096, XS = kWRowsXS;
     extern __shared__ __attribute__((aligned(16))) float2 ldsf[];
     __shared__ float2 s_b[16];
@@ -70,17 +70,12 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         if (A.cell_cs) Cs += A.cell_cs[g0];
         if (tid < 16) s_b[tid] = A.twl.get<+1>((uint32_t)((long)k1 * 256 * tid));
         // spectrum row of the next cell, raw as stored: elements xoff + 256 bh
-        typename std::conditional<HS, uint32_t, float2>::type xn[16];
+        uint32_t xn[16];
         auto fetch_x = [&](int g) {
             const int bin = A.cell_bin ? A.cell_bin[g] : A.bin0 + g;
             const ST *xr = (const ST *)A.Xs + (long)bin * L + (long)k1 * S + xoff;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                if constexpr (HS)
-                    xn[q] = *reinterpret_cast<const uint32_t *>(xr + q * 256);
-                else
-                    xn[q] = xr[q * 256];
-            }
+            for (int q = 0; q < 16; ++q) xn[q] = *reinterpret_cast<const uint32_t *>(xr + q * 256);
         };
         __syncthreads();  // s_b
         // inter-pass twiddle W_L^(-k1 e) of this thread's outputs e = tid + 256 p', times the storage scale, times the factor
@@ -96,15 +91,13 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         }
         // (the rows are fetched after the twiddle set-up: loaded before it, they and its temporaries overflow the register file)
         fetch_x(g0);
-        // fp16 storage: the code-spectrum rows of every component stay in registers (packed) for all cells
-        uint32_t cv[HS ? NCOMP : 1][16];
-        if constexpr (HS) {
+        // the code-spectrum rows of every component stay in registers (packed) for all cells
+        uint32_t cv[NCOMP][16];
 #pragma unroll
-            for (int comp = 0; comp < NCOMP; ++comp) {
-                const ST *cr = Cs + (long)comp * L + (long)k1 * S + xoff;
+        for (int comp = 0; comp < NCOMP; ++comp) {
+            const ST *cr = Cs + (long)comp * L + (long)k1 * S + xoff;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) cv[comp][q] = *reinterpret_cast<const uint32_t *>(cr + q * 256);
-            }
+            for (int q = 0; q < 16; ++q) cv[comp][q] = *reinterpret_cast<const uint32_t *>(cr + q * 256);
         }
         for (int g = g0; g < g1; ++g) {
 #pragma unroll
@@ -113,15 +106,8 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
                 // ---- phase 1a: products, radix 16 over bh, twiddle, to the wave's region
                 float2 y[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    if constexpr (HS) {
-                        // ((xi, xr) is re-formed per component: one v_alignbit against 16 registers held across both)
-                        y[q] = cmul_h(xn[q], __builtin_amdgcn_alignbit(xn[q], xn[q], 16), cv[comp][q]);
-                    } else {
-                        const ST *cr = Cs + (long)comp * L + (long)k1 * S + xoff;
-                        y[q] = cmul(xn[q], cr[q * 256]);
-                    }
-                }
+                for (int q = 0; q < 16; ++q)  // ((xi, xr) is re-formed per component: one v_alignbit against 16 registers held across both)
+                    y[q] = cmul_h(xn[q], __builtin_amdgcn_alignbit(xn[q], xn[q], 16), cv[comp][q]);
                 // the last component's products are the last readers of xn: the next cell's row is fetched into the same
                 // registers while the transform and the stores run
                 if (comp == NCOMP - 1 && g + 1 < g1) fetch_x(g + 1);
@@ -152,10 +138,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
 #ifdef BDS_EXP_ROWS_NOSTORE
                     if (t.x == 1.2345f)
 #endif
-                    if constexpr (HS)
-                        *reinterpret_cast<uint32_t *>(dst + 256 * p) = f2_to_h2(t);
-                    else
-                        dst[256 * p] = t;
+                    *reinterpret_cast<uint32_t *>(dst + 256 * p) = f2_to_h2(t);
                 }
             }
         }

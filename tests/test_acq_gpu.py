@@ -215,6 +215,50 @@ def test_every_specialised_plan_pair(ctx, monkeypatch, l1):
     ctx.reload_tuning()
 
 
+@pytest.mark.parametrize("sig", ["b2a", "b1c"])
+def test_both_row_pass_kernels_on_4096_point_rows(ctx, monkeypatch, sig):
+    """4096-point rows have two row-pass kernels: the wave-private one (bds_acq_wrows.h, default) and k_rows_inv_f
+    (BDS_ACQ_WROWS=0).  Both, with fp16 and fp32 storage, one component (B2a) and two (B1C), against the oracle; the coarse
+    grid agrees with the oracle's between the two kernels to the sieve tolerance, the results exactly."""
+    from helpers import spc_of
+    from bds_amd import synth
+    monkeypatch.setenv("BDS_ACQ_FORCE_L1L2", "512x4096")
+    fs = 10.1e6
+    if sig == "b2a":
+        s = bds_amd.init_settings_b2a(samplingFreq=fs, IF=2.5e6, acqSatelliteList=[7, 19, 33], acqSearchBand=600, acqStep=200,
+                                      fineNoncoh=4)
+        fn, n_codes = oacq.acquisition_b2a, 7
+    else:
+        s = bds_amd.init_settings_b1c(samplingFreq=fs, IF=2.5e6, acqSatelliteList=[7, 19, 33], acqSearchBand=200, acqStep=100)
+        fn, n_codes = oacq.acquisition_b1c, 3
+    spc = spc_of(s)
+    sats = [synth.Sat(19, 130.0, 0.41 * spc, 0.7, 47.0), synth.Sat(33, -90.0, 0.83 * spc, 2.2, 45.0)]
+    x = synth.make_if(s, sats, n_codes * spc, seed=77)
+    ref = fn(x.astype(np.float64), s)
+    try:
+        for env in ({}, {"BDS_ACQ_WROWS": "0"}, {"BDS_ACQ_FP16": "0"}, {"BDS_ACQ_FP16": "0", "BDS_ACQ_WROWS": "0"},
+                    {"BDS_ACQ_GCHUNK": "1"}, {"BDS_ACQ_ROWS_GRID": "64"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            c2 = bds_amd.native.Context(0)
+            try:
+                c2.acq_load(s, x)
+                c2.acq_prepare(s)
+                carr, cph, pm, det = c2.acq_run(s)
+                assert c2.timing()["fft_len"] == 512 * 4096
+            finally:
+                c2.close()
+            for k in env:
+                monkeypatch.delenv(k)
+            np.testing.assert_array_equal(cph, ref.codePhase, err_msg=str(env))
+            np.testing.assert_array_equal(carr, ref.carrFreq, err_msg=str(env))
+            np.testing.assert_allclose(pm, ref.peakMetric, rtol=1e-6, atol=0, err_msg=str(env))
+            assert carr[18] != 0
+    finally:
+        monkeypatch.delenv("BDS_ACQ_FORCE_L1L2")
+        ctx.reload_tuning()
+
+
 def test_data_type_other_than_schar_is_rejected(ctx):
     """settings.dataType (fread(fid, ..., settings.dataType), B2a/tracking.m:237-238): only int8 records."""
     s, x, _ = cfg1_b2a()

@@ -59,7 +59,7 @@ def main():
     hi = next(i for i, l in enumerate(b) if "v_readlane_b32" in l)
     out["cols"] = report("k_cols_wave_f<768, 2, false, __half2, 6>", b, 0, hi, "one 768 x 8 tile, 2 components = 48 point-components per lane (each through phase A and phase B)")
     # row pass: the per-cell loop (2 components of one 4096-point row on 256 threads)
-    rows_kernel = ("k_rows_wave_fILi2E7__half2E", "k_rows_wave_f<2, __half2>") if any("k_rows_wave_fILi2E7__half2E" in l for l in lines) else ("k_rows_inv_fILi4096ELi2E7__half2E", "k_rows_inv_f<4096, 2, __half2>")
+    rows_kernel = ("k_rows_wave_fILi2EE", "k_rows_wave_f<2>") if any("k_rows_wave_fILi2EE" in l for l in lines) else ("k_rows_inv_fILi4096ELi2E7__half2E", "k_rows_inv_f<4096, 2, __half2>")
     b = kernel_body(lines, rows_kernel[0])
     # the cell loop = the innermost loop that holds the barriers: from its header label to its back-edge branch
     hdr = [(i, l.split(":")[0]) for i, l in enumerate(b) if l.startswith(".LBB") and "Depth=2" in l and "Loop" in l]

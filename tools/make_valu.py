@@ -16,6 +16,8 @@ blocks = {b.split("\n")[0]: b for b in re.split(r"^== ", txt, flags=re.M) if b.s
 
 
 def counters(prefix):
+    if prefix == "k_rows_":  # the row pass of the search: wave-private kernel when the plan has one, k_rows_inv_f otherwise
+        prefix = "k_rows_wave_f" if any(n.startswith("k_rows_wave_f") for n in blocks) else "k_rows_inv_f"
     for name, b in blocks.items():
         if name.startswith(prefix):
             return name, {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+([\d.]+)", b, re.M)}

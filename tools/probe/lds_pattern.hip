@@ -47,6 +47,34 @@ __global__ __launch_bounds__(256) void k_read_tp(const int *offs, float *out, in
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+typedef float f4_t __attribute__((ext_vector_type(4)));
+// b128 accesses (two elements per lane): byte address = 2 x the pattern's
+__global__ __launch_bounds__(256) void k_write128(const int *offs, float *out, int which) {
+    extern __shared__ char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned a = 2u * (unsigned)offs[which * 64 + lane] + wave * 16384u;
+    f4_t v = {(float)lane, 1.f, 2.f, 3.f};
+    for (int it = 0; it < ITER; ++it) {
+        REP8(asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory");)
+    }
+    __syncthreads();
+    out[blockIdx.x * 256 + threadIdx.x] = ((float *)lds)[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_read128_tp(const int *offs, float *out, int which) {
+    extern __shared__ char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned a = 2u * (unsigned)offs[which * 64 + lane] + wave * 16384u;
+    f4_t v0, v1, v2, v3, v4, v5, v6, v7;
+    float acc = 0.f;
+    for (int it = 0; it < ITER; ++it) {
+        asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %8\n ds_read_b128 %2, %8\n ds_read_b128 %3, %8\n ds_read_b128 %4, %8\n ds_read_b128 %5, %8\n"
+                     "ds_read_b128 %6, %8\n ds_read_b128 %7, %8\n s_waitcnt lgkmcnt(0)"
+                     : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7) : "v"(a) : "memory");
+        acc += v0.x + v7.x;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 int main() {
     struct Pat { const char *name; int off[64]; };
     std::vector<Pat> pats;
@@ -63,11 +91,16 @@ int main() {
     add("stage 3 read   ml*68 + 8 u + ((j + u) & 7), j = 0", [=](int l) { return (l & 7) * MS + 8 * (l >> 3) + ((l >> 3) & 7); });
     add("stage 3 read   j = 3", [=](int l) { return (l & 7) * MS + 8 * (l >> 3) + ((3 + (l >> 3)) & 7); });
     add("stage 3 unrot  ml*68 + 8 u", [=](int l) { return (l & 7) * MS + 8 * (l >> 3); });
-    add("rows stage 2 r/w  pl*272 + bl (bl = l & 15, pl = l >> 4)", [](int l) { return (l >> 4) * 272 + (l & 15); });
-    add("rows stage 3 read pl*272 + 16 u + ((j + u) & 15), j = 0", [](int l) { return (l >> 4) * 272 + 16 * (l & 15) + ((l & 15) & 15); });
-    add("rows stage 3 read j = 5", [](int l) { return (l >> 4) * 272 + 16 * (l & 15) + ((5 + (l & 15)) & 15); });
-    add("rows stage 3 alt  pl*264 + 16 u + rot, j = 5", [](int l) { return (l >> 4) * 264 + 16 * (l & 15) + ((5 + (l & 15)) & 15); });
-    add("rows stage 3 alt  u-major lanes (pl = l & 3, u = l >> 2), j = 5", [](int l) { return (l & 3) * 272 + 16 * (l >> 2) + ((5 + (l >> 2)) & 15); });
+    // wave-private row pass (bds_acq_wrows.h): lanes (ql = l & 3, bl = l >> 2)
+    add("rows 1a write  64 u + lane", [](int l) { return l; });
+    add("rows 1b read   64 bl + ql + 4 ((j + bl) & 15), j = 5", [](int l) { return 64 * (l >> 2) + (l & 3) + 4 * ((5 + (l >> 2)) & 15); });
+    add("rows exch write 19 bl + q' (q' = ql)", [](int l) { return 19 * (l >> 2) + (l & 3); });
+    add("rows exch write 17 bl + q'", [](int l) { return 17 * (l >> 2) + (l & 3); });
+    add("rows exch write 21 bl + q'", [](int l) { return 21 * (l >> 2) + (l & 3); });
+    add("rows exch write 16 bl + ((q' + 4 (bl >> 1)) & 15)  (swizzled)", [](int l) { return 16 * (l >> 2) + (((l & 3) + 4 * ((l >> 2) >> 1)) & 15); });
+    add("rows phase 2 read 19 e'' + q'", [](int l) { return 19 * l + 3; });
+    add("rows phase 2 read 17 e'' + q'", [](int l) { return 17 * l + 3; });
+    add("rows phase 2 read 16 e'' + ((j + (e'' >> 1)) & 15)  (swizzled), j = 3", [](int l) { return 16 * l + ((3 + (l >> 1)) & 15); });
     add("stride 2 elements (2-way by any model)", [](int l) { return 2 * l; });
     add("stride 32 elements (all one bank pair)", [](int l) { return 32 * (l & 31) + (l >> 5); });
     std::vector<int> h;
@@ -94,6 +127,21 @@ int main() {
             res[mode] = ms * 1e-3 * clk / (2.0 * 4 * ITER * 8);
         }
         printf("%-62s write %6.1f  read(lat) %6.1f  read(tp) %6.1f  CU-cycles per wave-instruction\n", pats[i].name, res[0], res[1], res[2]);
+    }
+    // b128: the same lane -> element patterns, two elements (16 bytes) per lane
+    for (size_t i : {(size_t)0, (size_t)1, (size_t)5}) {
+        double res[2];
+        for (int mode = 0; mode < 2; ++mode) {
+            auto launch = [&] {
+                if (mode == 0) hipLaunchKernelGGL(k_write128, dim3(blocks), dim3(256), 65536, 0, d_off, d_out, (int)i);
+                else hipLaunchKernelGGL(k_read128_tp, dim3(blocks), dim3(256), 65536, 0, d_off, d_out, (int)i);
+            };
+            launch(); hipDeviceSynchronize();
+            hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            res[mode] = ms * 1e-3 * clk / (2.0 * 4 * ITER * 8);
+        }
+        printf("b128 %-57s write %6.1f  read(tp) %6.1f  CU-cycles per wave-instruction (1024 bytes)\n", pats[i].name, res[0], res[1]);
     }
     return 0;
 }
