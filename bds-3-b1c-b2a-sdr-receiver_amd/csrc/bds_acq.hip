@@ -50,6 +50,7 @@ struct Plan2D {
     float2 *d_ftab1 = nullptr, *d_ftab2 = nullptr;  // fp32 stage-twiddle tables of the inverse column / row transform
     float2 *d_wtab = nullptr;                       // per-lane twiddle table of the wave-private column pass (bds_acq_wcols.h)
     float2 *d_wrtab = nullptr;                      // ... of the wave-private 4096-point row pass (bds_acq_wrows.h)
+    unsigned long long *d_clk = nullptr;            // clock probe sums (BDS_ACQ_CLOCKPROBE): rows {shader, reference}, columns {shader, reference}
 };
 
 static bool is_5smooth(long v) {
@@ -154,6 +155,7 @@ static int threads_for(const Plan1D &p, int T) {
 static void plan_free(Plan2D &pl) {
     for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo, &pl.d_ftab1, &pl.d_ftab2, &pl.d_wtab, &pl.d_wrtab})
         if (*p) (void)hipFree(*p), *p = nullptr;
+    if (pl.d_clk) (void)hipFree(pl.d_clk), pl.d_clk = nullptr;
 }
 
 // fp32 stage tables of an inverse transform (bds_fft_t.h tstage TAB): per stage after the first [q][k], entries
@@ -280,6 +282,8 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
         if ((rc = upload_stage_tables_f32(ctx, pl.p2, &pl.d_ftab2))) return rc;
         if ((rc = upload_wcols_table(ctx, pl.L1, &pl.d_wtab))) return rc;
         if (pl.L2 == 4096 && (rc = upload_wrows_table(ctx, &pl.d_wrtab))) return rc;
+        BDS_HIP(ctx, hipMalloc((void **)&pl.d_clk, 4 * sizeof(unsigned long long)));
+        BDS_HIP(ctx, hipMemset(pl.d_clk, 0, 4 * sizeof(unsigned long long)));
     }
     pl.p1.tw = pl.d_tw1;
     pl.p2.tw = pl.d_tw2;
@@ -600,7 +604,7 @@ static void launch_rows_f(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const 
     int gc = (G + nch - 1) / nch;
     if (cl.bin) gc = cl.gc, nch = (G + cl.gc - 1) / cl.gc;  // a workgroup stays inside one PRN's cells
     const int nvb = pl.L1 * nch;  // L1 % 8 == 0 on every specialised plan: virtual workgroup vb sits on XCD vb % 8
-    const RowsFArgs A{(const float2 *)(kF32TabRows ? pl.d_ftab2 : pl.d_tw2), pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs, nvb};
+    const RowsFArgs A{(const float2 *)(kF32TabRows ? pl.d_ftab2 : pl.d_tw2), pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs, nvb, ctx->tune.clockprobe ? pl.d_clk : nullptr};
     const int grid = ctx->tune.rows_grid > 0 ? std::min(nvb, (ctx->tune.rows_grid + 7) / 8 * 8) : nvb;
     if constexpr (S == 4096 && std::is_same<ST, __half2>::value) {
         if (ctx->tune.wrows != 0) {  // wave-private row pass (bds_acq_wrows.h): per-lane twiddle constants, 4 barriers per cell
@@ -645,7 +649,8 @@ static void launch_cols_w(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G,
                           int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl) {
     const int ntiles = pl.L2 / WCols<S>::T;  // L2 % 256 == 0 on every specialised plan: ntiles % 32 == 0 (8 XCDs x quads)
     const WColsArgs A{(const float2 *)pl.d_wtab, pl.L2, ntiles, G, G * ntiles, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, cl.rng,
-                      so.cellmax, so.lb, so.lb_div, so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep, 1};
+                      so.cellmax, so.lb, so.lb_div, so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep, 1,
+                      ctx->tune.clockprobe ? pl.d_clk : nullptr};
     const bool masked = cl.rng || !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
     if (masked)
         launch_cols_wm<S, NC, true, ST, 8>(ctx, sc, pl, A);
@@ -1626,6 +1631,15 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     t.rows_ms = nsamp && mids ? acc_r / nsamp : 0;
     t.cols_ms = nsamp && mids ? acc_c / nsamp : 0;
     t.n_extra = a.n_extra_last;
+    t.shader_clock_GHz = 0;
+    if (ctx->tune.clockprobe && pl.d_clk) {  // sampled workgroups of the wave-private passes: shader-clock over reference-clock ticks
+        unsigned long long h[4];
+        int wall_khz = 0;
+        BDS_HIP(ctx, hipMemcpy(h, pl.d_clk, sizeof(h), hipMemcpyDeviceToHost));
+        BDS_HIP(ctx, hipMemset(pl.d_clk, 0, sizeof(h)));
+        BDS_HIP(ctx, hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device));
+        if (h[1] + h[3]) t.shader_clock_GHz = (double)(h[0] + h[2]) / (double)(h[1] + h[3]) * wall_khz * 1e-6;
+    }
     // overlapped passes: the average launch-pair duration is the search time over the pair count
     t.cell_pair_ms = nsamp ? acc / nsamp : (n_pairs_total ? t.search_ms / (double)n_pairs_total : 0);
     t.cells_per_pair = (int)cells_per_pair;

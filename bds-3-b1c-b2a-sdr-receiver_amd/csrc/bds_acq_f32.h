@@ -99,6 +99,31 @@ struct RowsFArgs {
     const int *cell_bin;   // optional cell list: Doppler bin of cell g ...
     const long *cell_cs;   // ... and element offset of its code spectra from Cs
     int nvb;               // virtual workgroups (= L1 * NCH); a launch with fewer workgroups strides over them
+    unsigned long long *clk;  // optional (BDS_ACQ_CLOCKPROBE): [0], [1] += shader-clock / reference-clock ticks of sampled workgroups
+};
+
+// Engine clock under the real load (BDS_ACQ_CLOCKPROBE=1): every (mask + 1)-th workgroup times its own life with the shader
+// clock (s_memtime) and the constant reference clock (s_memrealtime); the host turns the two sums into GHz
+// (bds_timing::shader_clock_GHz).  All scalar; off (null pointer) it costs one scalar compare.
+struct ClockProbe {
+    unsigned long long *acc;
+    long long c0 = 0, r0 = 0;
+#ifdef BDS_EXP_NOCLOCK
+    __device__ __forceinline__ ClockProbe(unsigned long long *, unsigned) : acc(nullptr) {}
+#else
+    __device__ __forceinline__ ClockProbe(unsigned long long *p, unsigned mask) : acc((p && (blockIdx.x & mask) == 0) ? p : nullptr) {
+        if (acc) c0 = clock64(), r0 = wall_clock64();
+    }
+#endif
+    __device__ __forceinline__ void finish(int tid) const {
+        if (acc) {
+            const long long c1 = clock64(), r1 = wall_clock64();
+            if (tid == 0) {
+                atomicAdd(acc, (unsigned long long)(c1 - c0));
+                atomicAdd(acc + 1, (unsigned long long)(r1 - r0));
+            }
+        }
+    }
 };
 
 // ---- inverse row pass ------------------------------------------------------------------------------

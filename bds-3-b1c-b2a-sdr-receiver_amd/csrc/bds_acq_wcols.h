@@ -113,6 +113,7 @@ struct WColsArgs {
     int cell0;                       // run-wide index of cell 0 of this launch
     float keep;                      // 1 - tolerance of the sieve
     int qchunk;                      // adjacent quads (4 tiles = one 128-byte line per row) of a cell that follow each other in the list
+    unsigned long long *clk;         // optional (BDS_ACQ_CLOCKPROBE): [2], [3] += shader-clock / reference-clock ticks of sampled workgroups
 };
 
 __device__ __forceinline__ unsigned long long wc_pack(float v, int lag) {
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L2 = A.L2;
     const long L = A.L;
+    const ClockProbe clkp(A.clk ? A.clk + 2 : nullptr, 255);
 
     // ---- the item of this workgroup ----------------------------------------------------------------------
     // One tile per workgroup, workgroups started by the hardware in list order.  Workgroup id % 8 = XCD; XCD x keeps the
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         }
         }
     }
+    clkp.finish(tid);
 }
 
 }  // namespace bds

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
     __shared__ float2 s_b[16];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long L = A.L;
+    const ClockProbe clkp(A.clk, 63);
     auto wave_sync = [] {  // LDS traffic of one wave is in order; this only stops the compiler from moving it
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         }
         if (vb + (int)gridDim.x < A.nvb) BDS_SYNC();
     }
+    clkp.finish(tid);
 }
 
 }  // namespace bds

@@ -44,6 +44,7 @@ struct Tuning {
     bool no_selfcheck = false;          // BDS_ACQ_NO_SELFCHECK: timing experiments with invalid results (no re-run)
     bool test_force_fallback = false;   // BDS_ACQ_TEST_FORCE_FALLBACK: test hook, take the fp16 -> fp32 storage re-run
     int wcols = -1;                  // BDS_ACQ_WCOLS: wave-private column pass (bds_acq_wcols.h); -1 = default on, 0 = the round-2 tile kernel
+    int clockprobe = 0;              // BDS_ACQ_CLOCKPROBE: sampled workgroups of the wave-private search kernels time themselves (bds_timing::shader_clock_GHz)
     int wrows = -1;                  // BDS_ACQ_WROWS: wave-private 4096-point row pass (bds_acq_wrows.h); -1 = default on, 0 = k_rows_inv_f
     int wcols_qchunk = 4;            // BDS_ACQ_WCOLS_QCHUNK: adjacent 128-byte lines of a cell its work list keeps together (DRAM page locality; measured 1: 1.84, 2: 1.70, 4: 1.70, 8: 1.75, 16: 1.83 ms per cfg3 launch)
     bool verbose = false;            // BDS_VERBOSE

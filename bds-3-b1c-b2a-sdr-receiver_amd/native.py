@@ -69,7 +69,7 @@ class Timing(C.Structure):
                 ("refine_ms", C.c_double), ("cell_pair_ms", C.c_double), ("cells_per_pair", C.c_double),
                 ("n_pairs", C.c_int64), ("fft_len", C.c_int64), ("n_circ", C.c_int64),
                 ("n_bins", C.c_int32), ("n_prn", C.c_int32), ("n_comp", C.c_int32), ("half_storage", C.c_int32),
-                ("rows_ms", C.c_double), ("cols_ms", C.c_double), ("n_extra", C.c_int64)]
+                ("rows_ms", C.c_double), ("cols_ms", C.c_double), ("n_extra", C.c_int64), ("shader_clock_GHz", C.c_double)]
 
 
 class AcqJob(C.Structure):

@@ -349,6 +349,29 @@ def strict_f32_leg(local_rank, s, x, n_cells_samples, ncomp, n_circ):
             "note": "fp32 storage AND arithmetic end to end (one extra call); the headline stores spectra and the inter-pass buffer as fp16 complex"}
 
 
+def clock_leg(local_rank, s, x):
+    """Engine clock the search kernels actually run at (extra call, never `value`): with BDS_ACQ_CLOCKPROBE=1 sampled workgroups of
+    the row and column pass time their own life with the shader clock against the constant reference clock
+    (bds_timing::shader_clock_GHz).  The issue bound of roofline.valu is quoted at the 2.4 GHz peak clock; under this load the
+    chip runs slower (power), and the bound scales with it."""
+    import bds_amd
+
+    os.environ["BDS_ACQ_CLOCKPROBE"] = "1"
+    try:
+        c = bds_amd.native.Context(local_rank)
+    finally:
+        del os.environ["BDS_ACQ_CLOCKPROBE"]
+    try:
+        c.acq_load(s, x)
+        c.acq_prepare(s)
+        c.acq_run(s)
+        c.acq_run(s)
+        tm = c.timing()
+    finally:
+        c.close()
+    return {"shader_clock_GHz": tm.get("shader_clock_GHz"), "pair_ms": tm["cell_pair_ms"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -560,6 +583,14 @@ def main():
                                            for g, r in zip(sigs, res_all)}
         out["strict_f32"] = (strict_f32_leg(local_rank, s, x, float(n_circ) * p_total * n_bins, ncomp, n_circ)
                              if world == 1 and len(sigs) == 1 and not args.no_fast_path else None)
+        if valu is not None and world == 1 and len(sigs) == 1 and not args.no_fast_path:
+            ck = clock_leg(local_rank, s, x)
+            if ck["shader_clock_GHz"]:
+                valu["shader_clock_GHz"] = ck["shader_clock_GHz"]
+                valu["bound_ms_at_shader_clock"] = valu["bound_ms"] * valu["clock_GHz"] / ck["shader_clock_GHz"]
+                valu["frac_of_issue_bound_at_shader_clock"] = valu["bound_ms_at_shader_clock"] / ck["pair_ms"] if ck["pair_ms"] else None
+                valu["note"] += ("; shader_clock_GHz = the engine clock measured inside the two kernels during one extra call "
+                                 "(sampled workgroups, s_memtime against s_memrealtime): the same bound at the clock the chip sustains under this load")
         if len(sigs) > 1:
             out["config"]["satellites_detected_per_signal"] = {g["name"]: sorted(int(p) for p in np.nonzero(r[0])[0] + 1)
                                                                 for g, r in zip(sigs, res_all)}

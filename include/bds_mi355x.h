@@ -138,6 +138,8 @@ typedef struct bds_timing {
     double rows_ms;         /* average duration of the row-pass kernel of a sampled launch pair        */
     double cols_ms;         /* ... and of its column-pass kernel                                       */
     int64_t n_extra;        /* entries of the sieve's overflow list in the last search                 */
+    double shader_clock_GHz; /* engine clock the search kernels ran at (sampled workgroups time themselves with the shader
+                                clock against the reference clock); 0 unless BDS_ACQ_CLOCKPROBE=1              */
 } bds_timing;
 
 typedef struct bds_ctx bds_ctx;

@@ -237,7 +237,7 @@ def test_both_row_pass_kernels_on_4096_point_rows(ctx, monkeypatch, sig):
     ref = fn(x.astype(np.float64), s)
     try:
         for env in ({}, {"BDS_ACQ_WROWS": "0"}, {"BDS_ACQ_FP16": "0"}, {"BDS_ACQ_FP16": "0", "BDS_ACQ_WROWS": "0"},
-                    {"BDS_ACQ_GCHUNK": "1"}, {"BDS_ACQ_ROWS_GRID": "64"}):
+                    {"BDS_ACQ_GCHUNK": "1"}, {"BDS_ACQ_ROWS_GRID": "64"}, {"BDS_ACQ_CLOCKPROBE": "1"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             c2 = bds_amd.native.Context(0)
@@ -246,6 +246,10 @@ def test_both_row_pass_kernels_on_4096_point_rows(ctx, monkeypatch, sig):
                 c2.acq_prepare(s)
                 carr, cph, pm, det = c2.acq_run(s)
                 assert c2.timing()["fft_len"] == 512 * 4096
+                # the clock probe (sampled workgroups time themselves: shader clock against reference clock) reports the engine
+                # clock of the search kernels only when asked to
+                ghz = c2.timing()["shader_clock_GHz"]
+                assert (0.5 < ghz < 3.0) if "BDS_ACQ_CLOCKPROBE" in env else ghz == 0.0
             finally:
                 c2.close()
             for k in env:
