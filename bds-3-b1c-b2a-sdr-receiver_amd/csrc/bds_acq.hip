@@ -181,7 +181,7 @@ static int upload_stage_tables_f32(bds_ctx *ctx, const Plan1D &p, float2 **dptr)
 
 // per-lane twiddle table of the wave-private column pass (layout: wcols_table_entries<S>() in bds_acq_wcols.h), inverse
 // direction, rounded from f64: [p - 1][thread] = w_S^(b p) with b = 16 (thread / 64) + (thread % 64) / 4, then
-// [u - 1][lane] = w_64^((lane / 8) u)
+// [j - 1][lane] = w_64^(u (bl - u)) with u = lane / 8, bl = (j + u) % 8 (stage 3 applies the stage-2 twiddle to its inputs)
 static int upload_wcols_table(bds_ctx *ctx, int S, float2 **dptr) {
     const int R1 = S / 64;
     std::vector<float2> h;
@@ -191,9 +191,10 @@ static int upload_wcols_table(bds_ctx *ctx, int S, float2 **dptr) {
             const double a = 2.0 * kPi * (double)((b * p) % S) / (double)S;
             h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
         }
-    for (int u = 1; u < 8; ++u)
+    for (int j = 1; j < 8; ++j)
         for (int lane = 0; lane < 64; ++lane) {
-            const double a = 2.0 * kPi * (double)(((lane >> 3) * u) % 64) / 64.0;
+            const int u = lane >> 3, bl = (j + u) & 7;
+            const double a = 2.0 * kPi * (double)(((u * (bl - u)) % 64 + 64) % 64) / 64.0;
             h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
         }
     BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * h.size()));
@@ -209,13 +210,18 @@ static int upload_wrows_table(bds_ctx *ctx, float2 **dptr) {
             const double a = 2.0 * kPi * (double)((b * p) % 4096) / 4096.0;
             h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
         }
-    for (int u = 1; u < 16; ++u)
+    for (int j = 1; j < 16; ++j)
         for (int lane = 0; lane < 64; ++lane) {
-            const double a = 2.0 * kPi * (double)(((lane >> 2) * u) % 256) / 256.0;
+            const int u = lane >> 2, bl = (j + u) & 15;
+            const double a = 2.0 * kPi * (double)(((u * (bl - u)) % 256 + 256) % 256) / 256.0;
             h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
         }
     for (int k = 0; k < 16; ++k) {
         const double a = 2.0 * kPi * (double)k / 16.0;
+        h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+    }
+    for (int u = 0; u < 16; ++u) {
+        const double a = 2.0 * kPi * (double)((u * u) % 256) / 256.0;
         h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
     }
     BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * h.size()));

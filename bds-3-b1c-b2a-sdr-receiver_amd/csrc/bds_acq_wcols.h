@@ -32,6 +32,7 @@
 #pragma once
 
 #include "bds_acq_f32.h"
+#include "bds_fft_fma.h"
 
 // Timing experiments (tools/exp_wparts.sh; results are INVALID with any of these defined):
 //   BDS_EXP_WC_NOTAIL  nothing after the wave maximum (no bounds, no list, no atomics)
@@ -121,7 +122,8 @@ __device__ __forceinline__ unsigned long long wc_pack(float v, int lag) {
 }
 
 // entries of the per-lane twiddle table of a length-S plan: (R1 - 1) x 256 for phase A (w_S^(b p), p = 1 .. R1 - 1, indexed
-// [p - 1][thread]) followed by 7 x 64 for phase B (w_64^(bl u), u = 1 .. 7, indexed [u - 1][lane]); inverse direction
+// [p - 1][thread]) followed by 7 x 64 for phase B (input j of lane (ml, u = lane / 8) in stage 3 is bl = (j + u) & 7:
+// w_64^(u (bl - u)), j = 1 .. 7, indexed [j - 1][lane]); inverse direction
 template <int S>
 __host__ __device__ constexpr int wcols_table_entries() {
     return (WCols<S>::R1 - 1) * WCols<S>::NT + 7 * 64;
@@ -211,9 +213,11 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     float2 *const wrA = ldsf + cp * RS + b;  // + m MS
     // phase B: stage 2 as lane (ml, bl), stage 3 as lane (ml, u) with u = bl
     const int ml = lane & 7, bl = lane >> 3;
-    float2 twB[8];  // w_64^(bl u)
+    // stage-2 twiddle w_64^(bl u), applied by stage 3 to its INPUTS (bds_fft_fma.h: folded into the first butterfly layer): input
+    // j of lane (ml, u) is bl = (j + u) & 7; the common unit factor w_64^(u u) is left out (invisible in |X|)
+    float2 twB[8];
 #pragma unroll
-    for (int u = 1; u < 8; ++u) twB[u] = A.wtab[(R1 - 1) * W::NT + (u - 1) * 64 + lane];
+    for (int j = 1; j < 8; ++j) twB[j] = A.wtab[(R1 - 1) * W::NT + (j - 1) * 64 + lane];
     float2 *const rw2 = ldsf + wave * RS + ml * MS + bl;  // + s 8 MS + 8 bh (read), + 8 u (write back)
     const float2 *rd3[8];                                 // row u from column u on: + s 8 MS
 #pragma unroll
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         }
         BDS_WSYNC();
         // ---- phase B, one slot (= 8 of the wave's rows m) at a time so that only 16-32 points are live:
-        //   st2(s): radix 8 over bh, twiddle, back in place;  st3(s): radix 8 over bl (rotated start), magnitudes.
+        //   st2(s): radix 8 over bh, back in place;  st3(s): twiddle, radix 8 over bl (rotated start), magnitudes.
         // Row m is read and written by the 8 lanes of one ml only, all in this wave, and LDS traffic of a wave is in
         // order: st2(s) may write as soon as its own reads are in, st3(s) may read as soon as st2(s) has written.
         // The units are software-pipelined by hand (st2(s + 1) sits between the write and the read-back of slot s)
@@ -302,9 +306,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
 #pragma unroll
             for (int q = 0; q < 8; ++q) y[q] = rw2[s * 8 * MS + 8 * q];
             wave_sync();
-            Butterfly<8, +1>::run(y);
-#pragma unroll
-            for (int u = 1; u < 8; ++u) y[u] = cmul(y[u], twB[u]);
+            bfly8_fma<+1, false>(y, nullptr);
 #pragma unroll
             for (int u = 0; u < 8; ++u) rw2[s * 8 * MS + 8 * u] = y[u];
             wave_sync();
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = rd3[j][s * 8 * MS];
             wave_sync();
-            Butterfly<8, +1>::run(y);
+            bfly8_fma<+1, true>(y, twB);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 // Only |y|^2 is formed here; the square roots, the lag masks and the exact maximum belong to the (rare)

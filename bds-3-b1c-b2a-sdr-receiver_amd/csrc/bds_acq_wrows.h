@@ -12,9 +12,10 @@
 //   X[e'' + 256 p'] = sum_q' w16^(q' p') w4096^(q' e'') Y_q'[e'']                                  thread e''
 //
 //   phase 1a: lane (ql = lane & 3, bl = lane >> 2) forms its 16 products x[16 bl + q' + 256 bh] from registers, radix 16 over
-//       bh, twiddle w256^(bl u) from per-lane constants, to the wave's own LDS region at [64 u + lane]
+//       bh, to the wave's own LDS region at [64 u + lane]
 //   phase 1b: lane (ql, u = lane >> 2) reads row u starting at column u (bank-conflict free; a rotation of the butterfly's
-//       inputs = the factor w16^(-u v) on its outputs, folded into the per-lane inter-pass twiddle), radix 16 over bl, Y to the
+//       inputs = the factor w16^(-u v) on its outputs, folded into the per-lane inter-pass twiddle), twiddle w256^(bl u) from
+//       per-lane constants ON THE INPUTS (bds_fft_fma.h: folded into the first butterfly layer), radix 16 over bl, Y to the
 //       exchange buffer at [19 e'' + q']                                                            -- barrier --
 //   phase 2 : thread e'' reads its 16 q', twiddle w4096^(q' e'') from per-lane constants, radix 16, inter-pass twiddle, store.
 //   Against k_rows_inv_f: every stage twiddle is a per-lane constant (30 of them were rebuilt from four table reads with
@@ -24,12 +25,15 @@
 #pragma once
 
 #include "bds_acq_f32.h"
+#include "bds_fft_fma.h"
 
 namespace bds {
 
 // per-lane twiddle table of the 4096-point row pass: 15 x 256 for phase 2 (w4096^(q' e''), q' = 1 .. 15, [q' - 1][thread])
-// followed by 15 x 64 for phase 1a (w256^((lane >> 2) u), u = 1 .. 15, [u - 1][lane]) and the 16 values w16^k; inverse direction
-constexpr int kWRowsTableEntries = 15 * 256 + 15 * 64 + 16;
+// followed by 15 x 64 for phase 1b (input j of lane (ql, u = lane >> 2) is bl = (j + u) & 15: w256^(u (bl - u)), j = 1 .. 15,
+// [j - 1][lane]), the 16 values w16^k and the 16 values w256^(u u) (the factor taken out of the phase-1b twiddles so that
+// input 0 needs none; it goes into the inter-pass twiddle); inverse direction
+constexpr int kWRowsTableEntries = 15 * 256 + 15 * 64 + 16 + 16;
 constexpr int kWRowsRegion = 1024;  // elements of a wave's region (4 q' x 256)
 constexpr int kWRowsXS = 19;        // elements between consecutive e'' of the exchange buffer (38 dwords: conflict-free both ways; 17 costs 7 %)
 constexpr size_t kWRowsLdsBytes = sizeof(float2) * (4 * kWRowsRegion + 256 * kWRowsXS);
@@ -80,13 +84,15 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         };
         __syncthreads();  // s_b
         // inter-pass twiddle W_L^(-k1 e) of this thread's outputs e = tid + 256 p', times the storage scale, times the factor
-        // w16^(u v) (u = tid & 15, v = tid >> 4) that undoes the rotated read of phase 1b
+        // w16^(u v) (u = tid & 15, v = tid >> 4) that undoes the rotated read of phase 1b, times the factor w256^(u u) its
+        // twiddles leave out
         float2 wo[16];
         {
             float2 wi = A.twl.get<+1>((uint32_t)k1 * (uint32_t)tid);
             wi.x *= A.out_scale;
             wi.y *= A.out_scale;
             wi = cmul(wi, A.tw[15 * 256 + 15 * 64 + (((tid & 15) * (tid >> 4)) & 15)]);
+            wi = cmul(wi, A.tw[15 * 256 + 15 * 64 + 16 + (tid & 15)]);
 #pragma unroll
             for (int p = 0; p < 16; ++p) wo[p] = cmul(wi, s_b[p]);
         }
@@ -112,9 +118,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
                 // the last component's products are the last readers of xn: the next cell's row is fetched into the same
                 // registers while the transform and the stores run
                 if (comp == NCOMP - 1 && g + 1 < g1) fetch_x(g + 1);
-                Butterfly<16, +1>::run(y);
-#pragma unroll
-                for (int u = 1; u < 16; ++u) y[u] = cmul(y[u], twB[u]);
+                bfly16_fma<+1, false>(y, nullptr);
 #pragma unroll
                 for (int u = 0; u < 16; ++u) wr1[64 * u] = y[u];
                 wave_sync();
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) y[j] = rd1[4 * ((j + bl) & 15)];
                 wave_sync();
-                Butterfly<16, +1>::run(y);
+                bfly16_fma<+1, true>(y, twB);  // twiddle w256^(bl u) on the inputs (up to the factor w256^(u u))
                 if (comp > 0 || g > g0) BDS_SYNC();  // every thread is through with the exchange buffer (previous transform)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) wrx[16 * XS * v] = y[v];
@@ -130,9 +134,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
                 // ---- phase 2: twiddle, radix 16 over q', inter-pass twiddle, store
 #pragma unroll
                 for (int q = 0; q < 16; ++q) y[q] = rd2[q];
-#pragma unroll
-                for (int q = 1; q < 16; ++q) y[q] = cmul(y[q], twC[q]);
-                Butterfly<16, +1>::run(y);
+                bfly16_fma<+1, true>(y, twC);  // twiddle w4096^(q' e'') on the inputs
 #pragma unroll
                 for (int p = 0; p < 16; ++p) {
                     const float2 t = cmul(y[p], wo[p]);

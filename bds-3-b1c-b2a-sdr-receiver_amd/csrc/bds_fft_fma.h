@@ -1,0 +1,128 @@
+// Radix-16 butterfly with the twiddles folded into fused multiply-adds (gfx950: an fp32 add, a multiply and an FMA all cost one
+// 2-cycle issue slot, so what counts is the number of instructions, not of flops).
+//
+//   (a + w b, a - w b):  p = fma(w.x, b.x, fma(-w.y, b.y, a.x)), ...;  q = 2 a - p        6 instructions instead of 4 + 4
+//
+// Applied (1) to the constant twiddles W16^(n2 k1) between the two radix-4 layers (86 instead of 96 instructions for that layer)
+// and (2) to INPUT twiddles tw[1 .. 15] of the transform (a stage twiddle applied to what a lane has just read, instead of to what
+// it is about to write): the first layer takes 108 instead of 60 + 64 instructions.  A twiddled 16-point transform: 194 against
+// 220; an untwiddled one: 150 against 160.  Used by the wave-private row pass (bds_acq_wrows.h) and, as the 8-point version,
+// by the wave-private column pass (bds_acq_wcols.h).
+#pragma once
+
+#include "bds_fft.h"
+
+namespace bds {
+
+// (p, q) = (a + w b, a - w b)
+__device__ __forceinline__ void bf2w(float2 a, float2 b, float wr, float wi, float2 &p, float2 &q) {
+    p.x = fmaf(wr, b.x, fmaf(-wi, b.y, a.x));
+    p.y = fmaf(wr, b.y, fmaf(wi, b.x, a.y));
+    q.x = fmaf(2.f, a.x, -p.x);
+    q.y = fmaf(2.f, a.y, -p.y);
+}
+
+// radix 4 over x0, t1 x1, t2 x2, t3 x3 (x0 as it is)
+template <int DIR>
+__device__ __forceinline__ void radix4_tw(float2 *v, float2 t1, float2 t2, float2 t3) {
+    float2 p, q, r, s;
+    bf2w(v[0], v[2], t2.x, t2.y, p, q);
+    const float2 x1 = cmul(v[1], t1);
+    bf2w(x1, v[3], t3.x, t3.y, r, s);
+    s = rot90<DIR>(s);
+    v[0] = cadd(p, r);
+    v[1] = cadd(q, s);
+    v[2] = csub(p, r);
+    v[3] = csub(q, s);
+}
+
+// v <- DFT16(tw .* v) (TW: tw[1 .. 15] are applied to the inputs, tw[0] is taken as 1) or DFT16(v); DIR as Butterfly<16, DIR>
+template <int DIR, bool TW>
+__device__ __forceinline__ void bfly16_fma(float2 *v, const float2 *tw) {
+#ifdef BDS_EXP_PLAIN_BFLY  // timing experiment: the same transform with separate twiddle products and Butterfly<16, DIR>
+    if constexpr (TW) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v[i] = cmul(v[i], tw[i]);
+    }
+    Butterfly<16, DIR>::run(v);
+    return;
+#endif
+    constexpr float sg = DIR > 0 ? 1.f : -1.f;
+    const float h = 0.70710678118654752440f;
+    const float c = 0.92387953251128675613f;  // cos(pi/8)
+    const float s = 0.38268343236508977173f;  // sin(pi/8)
+    float2 a[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+        a[n2][0] = v[n2];
+        a[n2][1] = v[n2 + 4];
+        a[n2][2] = v[n2 + 8];
+        a[n2][3] = v[n2 + 12];
+        if constexpr (TW) {
+            if (n2 > 0) a[n2][0] = cmul(a[n2][0], tw[n2]);
+            radix4_tw<DIR>(a[n2], tw[n2 + 4], tw[n2 + 8], tw[n2 + 12]);
+        } else {
+            Butterfly<4, DIR>::run(a[n2]);
+        }
+    }
+    // second layer: radix 4 over n2 of W16^(n2 k1) a[n2][k1]
+    {
+        float2 u[4] = {a[0][0], a[1][0], a[2][0], a[3][0]};
+        Butterfly<4, DIR>::run(u);
+        v[0] = u[0], v[4] = u[1], v[8] = u[2], v[12] = u[3];
+    }
+    {
+        float2 u[4] = {a[0][1], a[1][1], a[2][1], a[3][1]};
+        radix4_tw<DIR>(u, make_float2(c, sg * s), make_float2(h, sg * h), make_float2(s, sg * c));  // W16^1, W16^2, W16^3
+        v[1] = u[0], v[5] = u[1], v[9] = u[2], v[13] = u[3];
+    }
+    {  // W16^2, W16^4 = +-j, W16^6
+        const float2 x0 = a[0][2], jx2 = rot90<DIR>(a[2][2]);
+        const float2 p = cadd(x0, jx2), q = csub(x0, jx2);
+        const float2 x1 = cmul(a[1][2], make_float2(h, sg * h));
+        float2 r, t;
+        bf2w(x1, a[3][2], -h, sg * h, r, t);
+        t = rot90<DIR>(t);
+        v[2] = cadd(p, r), v[6] = cadd(q, t), v[10] = csub(p, r), v[14] = csub(q, t);
+    }
+    {
+        float2 u[4] = {a[0][3], a[1][3], a[2][3], a[3][3]};
+        radix4_tw<DIR>(u, make_float2(s, sg * c), make_float2(-h, sg * h), make_float2(-c, -sg * s));  // W16^3, W16^6, W16^9
+        v[3] = u[0], v[7] = u[1], v[11] = u[2], v[15] = u[3];
+    }
+}
+
+// v <- DFT8(tw .* v) (TW: tw[1 .. 7] on the inputs) or DFT8(v): 72 instructions against 28 + 56, 52 against 56
+template <int DIR, bool TW>
+__device__ __forceinline__ void bfly8_fma(float2 *v, const float2 *tw) {
+#ifdef BDS_EXP_PLAIN_BFLY
+    if constexpr (TW) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], tw[i]);
+    }
+    Butterfly<8, DIR>::run(v);
+    return;
+#endif
+    constexpr float sg = DIR > 0 ? 1.f : -1.f;
+    const float h = 0.70710678118654752440f;
+    float2 a0[4] = {v[0], v[2], v[4], v[6]};
+    float2 a1[4] = {v[1], v[3], v[5], v[7]};
+    if constexpr (TW) {
+        radix4_tw<DIR>(a0, tw[2], tw[4], tw[6]);
+        a1[0] = cmul(a1[0], tw[1]);
+        radix4_tw<DIR>(a1, tw[3], tw[5], tw[7]);
+    } else {
+        Butterfly<4, DIR>::run(a0);
+        Butterfly<4, DIR>::run(a1);
+    }
+    // v[k1], v[k1 + 4] = a0[k1] +- W8^k1 a1[k1]
+    v[0] = cadd(a0[0], a1[0]);
+    v[4] = csub(a0[0], a1[0]);
+    bf2w(a0[1], a1[1], h, sg * h, v[1], v[5]);
+    const float2 j2 = rot90<DIR>(a1[2]);
+    v[2] = cadd(a0[2], j2);
+    v[6] = csub(a0[2], j2);
+    bf2w(a0[3], a1[3], -h, sg * h, v[3], v[7]);
+}
+
+}  // namespace bds

@@ -1,0 +1,72 @@
+// bfly16_fma / bfly8_fma (bds_fft_fma.h) against a double-precision DFT-16 on random data: both directions, with and without input twiddles,
+// and against Butterfly<16, DIR>.  Prints the largest error relative to the largest output.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ibds-3-b1c-b2a-sdr-receiver_amd/csrc -Iinclude tools/probe/bfly_check.hip -o /tmp/bfly_check
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#include "bds_fft_fma.h"
+using namespace bds;
+
+__global__ void k(float2 *io, const float2 *tw, int mode) {
+    float2 v[16], t[16];
+    for (int i = 0; i < 16; ++i) v[i] = io[threadIdx.x * 16 + i], t[i] = tw[threadIdx.x * 16 + i];
+    if (mode == 0) Butterfly<16, +1>::run(v);
+    else if (mode == 1) bfly16_fma<+1, false>(v, nullptr);
+    else if (mode == 2) bfly16_fma<+1, true>(v, t);
+    else if (mode == 3) Butterfly<16, -1>::run(v);
+    else if (mode == 4) bfly16_fma<-1, false>(v, nullptr);
+    else if (mode == 5) bfly16_fma<-1, true>(v, t);
+    else if (mode == 6) bfly8_fma<+1, false>(v, nullptr);
+    else if (mode == 7) bfly8_fma<+1, true>(v, t);
+    else if (mode == 8) bfly8_fma<-1, false>(v, nullptr);
+    else bfly8_fma<-1, true>(v, t);
+    for (int i = 0; i < 16; ++i) io[threadIdx.x * 16 + i] = v[i];
+}
+
+int main() {
+    const int NT = 256;
+    std::mt19937 rng(1);
+    std::normal_distribution<float> nd;
+    std::vector<float2> x(NT * 16), tw(NT * 16), y(NT * 16);
+    for (auto &e : x) e = make_float2(nd(rng), nd(rng));
+    for (int i = 0; i < NT * 16; ++i) {
+        const double a = 6.283185307179586 * (rng() % 4096) / 4096.0;
+        tw[i] = (i % 16) ? make_float2((float)cos(a), (float)sin(a)) : make_float2(1.f, 0.f);
+    }
+    float2 *d_x, *d_t;
+    (void)hipMalloc(&d_x, sizeof(float2) * NT * 16);
+    (void)hipMalloc(&d_t, sizeof(float2) * NT * 16);
+    (void)hipMemcpy(d_t, tw.data(), sizeof(float2) * NT * 16, hipMemcpyHostToDevice);
+    const char *names[10] = {"Butterfly<16,+1>", "bfly16_fma<+1,false>", "bfly16_fma<+1,true>", "Butterfly<16,-1>", "bfly16_fma<-1,false>", "bfly16_fma<-1,true>",
+                             "bfly8_fma<+1,false>", "bfly8_fma<+1,true>", "bfly8_fma<-1,false>", "bfly8_fma<-1,true>"};
+    int bad = 0;
+    for (int mode = 0; mode < 10; ++mode) {
+        (void)hipMemcpy(d_x, x.data(), sizeof(float2) * NT * 16, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k, dim3(1), dim3(NT), 0, 0, d_x, d_t, mode);
+        (void)hipMemcpy(y.data(), d_x, sizeof(float2) * NT * 16, hipMemcpyDeviceToHost);
+        const int R = mode < 6 ? 16 : 8;
+        const int dir = mode < 3 || mode == 6 || mode == 7 ? +1 : -1;
+        const bool twd = mode == 2 || mode == 5 || mode == 7 || mode == 9;
+        double worst = 0, big = 0;
+        for (int t = 0; t < NT; ++t)
+            for (int kk = 0; kk < R; ++kk) {
+                std::complex<double> acc = 0;
+                for (int n = 0; n < R; ++n) {
+                    std::complex<double> v(x[t * 16 + n].x, x[t * 16 + n].y);
+                    if (twd) v *= std::complex<double>(tw[t * 16 + n].x, tw[t * 16 + n].y);
+                    acc += v * std::polar(1.0, dir * 6.283185307179586 * n * kk / (double)R);
+                }
+                worst = std::max(worst, std::abs(acc - std::complex<double>(y[t * 16 + kk].x, y[t * 16 + kk].y)));
+                big = std::max(big, std::abs(acc));
+            }
+        printf("%-22s max |err| / max |X| = %.2e\n", names[mode], worst / big);
+        if (worst / big > 1e-6) bad = 1;
+    }
+    printf(bad ? "FAILED\n" : "ok\n");
+    return bad;
+}
