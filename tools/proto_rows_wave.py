@@ -5,9 +5,9 @@ e'' = thread id (coalesced stores); the scatter is on the loads instead (16-byte
   r = 16 b' + q',  b' = bl + 16 bh;   e = e'' + 256 p',  e'' = u + 16 v
   Y_q'[u + 16 v] = sum_bl w16^(bl v) w256^(bl u) sum_bh w16^(bh u) x[16 (bl + 16 bh) + q']        (wave-private: wave w has q' = 4w..4w+3)
   X[e'' + 256 p'] = sum_q' w16^(q' p') w4096^(q' e'') Y_q'[e'']                                     (cooperative, thread e'')
-  phase 1a: lane (ql = lane & 3, bl = lane >> 2): radix 16 over bh, twiddle w256^(bl u), to the wave's region at [64 u + lane]
+  phase 1a: lane (ql = lane & 3, bl = lane >> 2): radix 16 over bh, to the wave's region at [64 u + lane]
   phase 1b: lane (ql, u = lane >> 2): reads row u starting at column u (rotation: factor w16^(-u v), folded into the inter-pass
-            twiddle), radix 16 over bl, Y to the exchange buffer at [19 e'' + q']
+            twiddle), twiddle w256^(bl u) on these inputs, radix 16 over bl, Y to the exchange buffer at [19 e'' + q']
   phase 2 : thread e'': radix 16 over q' with twiddle w4096^(q' e'')
 """
 import numpy as np
@@ -40,18 +40,20 @@ for wave in range(4):
         q = 4 * wave + ql
         A = dft16 @ np.array([x[16 * (bl + 16 * bh) + q] for bh in range(16)])
         for u in range(16):
-            reg[wave, 64 * u + lane] = A[u] * w(256, bl * u)
+            reg[wave, 64 * u + lane] = A[u]
     for u in range(16):
         bank("1a.write", [64 * u + l for l in range(64)], 16)
     wr = {}
     for lane in range(64):
         ql, u = lane & 3, lane >> 2
         q = 4 * wave + ql
-        a = np.array([reg[wave, 64 * u + 4 * ((j + u) & 15) + ql] for j in range(16)])
+        # the twiddle w256^(bl u) is applied to the INPUTS of this butterfly (bds_fft_fma.h folds it into the first layer), less
+        # the common factor w256^(u u) so that input 0 needs none; the factor goes into the inter-pass twiddle
+        a = np.array([reg[wave, 64 * u + 4 * ((j + u) & 15) + ql] * w(256, u * (((j + u) & 15) - u)) for j in range(16)])
         Yr = dft16 @ a
         for v in range(16):
             ad = 19 * (u + 16 * v) + q
-            ex[ad] = Yr[v]   # = w16^(-u v) Y_q[u + 16 v]
+            ex[ad] = Yr[v]   # = w16^(-u v) w256^(-u u) Y_q[u + 16 v]
             wr.setdefault(v, []).append(ad)
     for j in range(16):
         bank("1b.read", [64 * (l >> 2) + 4 * ((j + (l >> 2)) & 15) + (l & 3) for l in range(64)], 32)
@@ -63,7 +65,7 @@ for e2 in range(256):
     z = np.array([ex[19 * e2 + q] * w(4096, q * e2) for q in range(16)])
     X = dft16 @ z
     for p in range(16):
-        out[e2 + 256 * p] = X[p] * w(16, u * v)   # the rotation factor, folded into the inter-pass twiddle
+        out[e2 + 256 * p] = X[p] * w(16, u * v) * w(256, u * u)   # rotation and left-out factors, folded into the inter-pass twiddle
 for q in range(16):
     for wv in range(4):
         bank("2.read", [19 * (64 * wv + l) + q for l in range(64)], 32)
