@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "bds_fft.h"
+#include "bds_fft_fma.h"
 
 #ifdef BDS_EXP_NOBARRIER
 #define BDS_TSYNC() __builtin_amdgcn_s_waitcnt(0)
@@ -56,6 +57,11 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
     constexpr bool SRC_LDS = std::is_same<Src, LdsIO>::value;
     constexpr bool DST_LDS = std::is_same<Dst, LdsIO>::value;
     constexpr bool HALF = std::is_same<C, h2>::value;
+#ifdef BDS_EXP_PLAIN_TSTAGE
+    constexpr bool kFma = false;
+#else
+    constexpr bool kFma = std::is_same<C, float2>::value && (R == 16 || R == 8);
+#endif
     static_assert(NB % 16 == 0, "S/R must be a multiple of 16");
     static_assert(NS == 1 || NS % 16 == 0, "later stages need NS % 16 == 0");
     static_assert(NS > 1 || R == 16, "the first stage must be radix 16");
@@ -90,6 +96,7 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
     for (int i = 0; i < MB; ++i) {
         const int b = tid + i * NT;
         if (FULL || b < TOTAL) {
+            [[maybe_unused]] C wq[R];  // stage twiddles of this butterfly (kFma)
             if (NS > 1) {
                 if constexpr (HALF) {
                     const C *tk = tw + TWOFF + kidx[i];  // table layout [q][k]: lanes (consecutive k) hit consecutive banks
@@ -100,8 +107,13 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
                     // fp32 with per-stage tables (stage_tables_f32 on the host: [q][k], already in the transform
                     // direction): 15 LDS reads instead of 4 reads + 11 complex products per radix-16 butterfly
                     const C *tk = tw + TWOFF + kidx[i];
+                    if constexpr (kFma) {
 #pragma unroll
-                    for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], tk[q * NS]);
+                        for (int q = 1; q < R; ++q) wq[q] = tk[q * NS];
+                    } else {
+#pragma unroll
+                        for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], tk[q * NS]);
+                    }
                 } else {
                     const int kt = kidx[i] * TWS;
                     if constexpr (R == 16 || R == 8) {
@@ -124,8 +136,13 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
 #pragma unroll
                             for (int q = 1; q < 8; ++q) w[8 + q] = cmul(w[q], w[8]);
                         }
+                        if constexpr (kFma) {
 #pragma unroll
-                        for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], w[q]);
+                            for (int q = 1; q < R; ++q) wq[q] = w[q];
+                        } else {
+#pragma unroll
+                            for (int q = 1; q < R; ++q) v[i][q] = cmul(v[i][q], w[q]);
+                        }
                     } else {
 #pragma unroll
                         for (int q = 1; q < R; ++q) {
@@ -136,7 +153,18 @@ __device__ __forceinline__ void tstage(C *__restrict__ buf, const C *__restrict_
                     }
                 }
             }
-            Butterfly<R, DIR>::run(v[i]);
+            // fp32, radix 16 / 8: the stage twiddles go into the butterfly's first layer (bds_fft_fma.h)
+            if constexpr (kFma) {
+                if constexpr (R == 16) {
+                    if (NS > 1) bfly16_fma<DIR, true>(v[i], wq);
+                    else bfly16_fma<DIR, false>(v[i], nullptr);
+                } else {
+                    if (NS > 1) bfly8_fma<DIR, true>(v[i], wq);
+                    else bfly8_fma<DIR, false>(v[i], nullptr);
+                }
+            } else {
+                Butterfly<R, DIR>::run(v[i]);
+            }
             if constexpr (DST_LDS) {
                 // phys(j0 + q*NS): NS == 1 -> 17*bb + q ; NS % 16 == 0 -> phys(j0) + q*WSTR
                 C *dp = buf + jj[i] * SP + j0v[i] + (j0v[i] >> 4);
