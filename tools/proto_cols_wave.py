@@ -98,6 +98,7 @@ def run(S, seed=0, verbose=True):
         print(f"S={S} R1={R1} M={M} slots={SL} region {RS * 8} B, workgroup {4 * RS * 8} B: max rel err {err:.2e}; "
               f"worst bank conflict per access class: {conflicts}")
     assert err < 1e-12
+    assert all(v == 1 for v in conflicts.values()), conflicts  # every LDS access class conflict-free (half-wave model)
     return err
 
 
