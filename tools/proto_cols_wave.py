@@ -5,9 +5,10 @@ S = 64 R1 points per column, tile of 8 columns on 4 waves:
   phase A (cooperative): wave i, lane (cp = lane & 3, bq = lane >> 2) takes butterfly b = 16 i + bq of column
       pair cp: radix-R1 over q of x[b + 64 q], twiddle w_S^(b p), written to region R_cp at [m = c R1 + p][b]
   phase B (wave w owns region R_w, columns 2w, 2w+1): lane (ml = lane & 7, bl = lane >> 3), slots s: m = ml + 8 s
-      stage 2: radix-8 over bh of z[m][bl + 8 bh], twiddle w_64^(bl u), written back IN PLACE at [m][8 u + bl]
-      stage 3: lane (ml, u = lane >> 3): radix-8 over bl -> X[p + R1 (u + 8 v)]; the lane reads its row starting at
-      column u (conflict-free): a rotation of the inputs, i.e. a unit factor on the outputs, invisible in |X|
+      stage 2: radix-8 over bh of z[m][bl + 8 bh], written back IN PLACE at [m][8 u + bl]
+      stage 3: lane (ml, u = lane >> 3): twiddle w_64^(bl u) on the inputs, radix-8 over bl -> X[p + R1 (u + 8 v)]; the lane
+      reads its row starting at column u (conflict-free): a rotation of the inputs, i.e. a unit factor on the outputs,
+      invisible in |X| (like the factor w_64^(u u) the twiddles leave out)
 """
 import sys
 
@@ -74,7 +75,7 @@ def run(S, seed=0, verbose=True):
                 z = regs[(lane, s)]
                 A = np.array([sum(z[bh] * np.exp(2j * np.pi * bh * u / 8) for bh in range(8)) for u in range(8)])
                 for u in range(8):
-                    lds[base + ml * MS + s * 8 * MS + 8 * u + bl] = A[u] * wS(R1 * bl * u)
+                    lds[base + ml * MS + s * 8 * MS + 8 * u + bl] = A[u]
         for s in range(SL):
             for u in range(8):
                 bank_check("B.write2", [base + (l & 7) * MS + s * 8 * MS + 8 * u + (l >> 3) for l in range(64)])
@@ -86,7 +87,9 @@ def run(S, seed=0, verbose=True):
                 c, p = divmod(m, R1)
                 # the lane reads its row starting at column u: register j holds bl = (j + u) & 7; the transform of
                 # the rotated row differs from the true one by the unit factor w_8^(u v), invisible in |X|
-                a = np.array([lds[base + ml * MS + 8 * u + s * 8 * MS + ((j + u) & 7)] for j in range(8)])
+                # the stage-2 twiddle w_64^(bl u) is applied here, to the inputs (bds_fft_fma.h folds it into the butterfly's first
+                # layer), less the common unit factor w_64^(u u)
+                a = np.array([lds[base + ml * MS + 8 * u + s * 8 * MS + ((j + u) & 7)] * wS(R1 * u * (((j + u) & 7) - u)) for j in range(8)])
                 X = np.array([sum(a[j] * np.exp(2j * np.pi * j * v / 8) for j in range(8)) for v in range(8)])
                 for v in range(8):
                     out[p + R1 * (u + 8 * v), 2 * w + c] = X[v]
