@@ -49,6 +49,31 @@ def test_random_acquisition_configs(ctx, seed):
     np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0)
 
 
+_WAVE_PLANS = ["512x4096", "768x4096", "1024x4096", "768x2048", "1024x3072", "1024x2048"]  # all hold the largest case (0.75 M points)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BDS_FUZZ_WAVE_SEEDS", "6"))))
+def test_random_configs_on_the_wave_private_plans(ctx, monkeypatch, seed):
+    """The same random configurations with the factorisation forced onto the plans that take the wave-private passes
+    (column lengths 512 / 768 / 1024: k_cols_wave_f; 4096-point rows: k_rows_wave_f) -- at these sampling rates the planner
+    itself would pick the small 256-column plans.  (BDS_FUZZ_WAVE_SEEDS widens the range for a soak run.)"""
+    s, x, sats = _acq_case(100 + seed)
+    monkeypatch.setenv("BDS_ACQ_FORCE_L1L2", _WAVE_PLANS[seed % len(_WAVE_PLANS)])
+    ctx.reload_tuning()
+    try:
+        fn = oacq.acquisition_b1c if str(s.signal).upper() == "B1C" else oacq.acquisition_b2a
+        ref = fn(x.astype(np.complex128 if np.iscomplexobj(x) else np.float64), s)
+        got = bds_amd.acquisition(x, s, verbose=False)
+        l1, l2 = (int(v) for v in _WAVE_PLANS[seed % len(_WAVE_PLANS)].split("x"))
+        assert ctx.timing()["fft_len"] == l1 * l2
+        np.testing.assert_array_equal(got.codePhase, ref.codePhase)
+        np.testing.assert_array_equal(got.carrFreq, ref.carrFreq)
+        np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0)
+    finally:
+        monkeypatch.delenv("BDS_ACQ_FORCE_L1L2")
+        ctx.reload_tuning()
+
+
 def _trk_case(seed):
     rng = np.random.default_rng(3000 + seed)
     mode = ["B2A", "NB", "WB"][seed % 3]
