@@ -1659,6 +1659,17 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     return BDS_OK;
 }
 
+#ifdef BDS_EXP_PHASES
+// timing build only: the phase-clock sums of the wave-private search kernels (bds_acq_f32.h), read and cleared
+extern "C" __attribute__((visibility("default"))) int bds_debug_phases(unsigned long long *out, int n) {
+    unsigned long long h[128] = {};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 128; ++i) out[i] = h[i];
+    unsigned long long z[128] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int bds_resample_plan(const bds_settings *s, double *new_fs, double *new_if, double *wp) {
     if (!s) return BDS_ERR_ARG;
     const ResamplePlan r = resample_plan(*s);

@@ -35,6 +35,39 @@
 #define BDS_EXP_ROWS_OCC 2
 #endif
 
+// BDS_EXP_PHASES (tools/exp/phases.sh; a timing build, never the product): the wave-private search kernels stamp the shader clock
+// (s_memtime) at their phase boundaries, with explicit waits so that memory / LDS / barrier waits are told apart from issue
+// time, and add the intervals to g_phase[]; read and cleared by bds_debug_phases().
+#ifdef BDS_EXP_PHASES
+__device__ unsigned long long g_phase[128];
+#define PH_DECL(n)                       \
+    unsigned long long ph_acc[n] = {};   \
+    unsigned long long ph_t = __builtin_readcyclecounter()
+#define PH_MARK(i)                                                   \
+    do {                                                             \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        const unsigned long long t_ = __builtin_readcyclecounter();  \
+        ph_acc[i] += t_ - ph_t;                                      \
+        ph_t = t_;                                                   \
+        __builtin_amdgcn_sched_barrier(0);                           \
+    } while (0)
+#define PH_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define PH_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PH_FLUSH(base, n)                                                            \
+    do {                                                                             \
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 127) == 5) { /* sampled: same-line atomics run at ~10 M/s */ \
+            for (int i_ = 0; i_ < (n); ++i_) atomicAdd(&g_phase[(base) + i_], ph_acc[i_]); \
+            atomicAdd(&g_phase[(base) + (n)], 1ull);                                 \
+        }                                                                            \
+    } while (0)
+#else
+#define PH_DECL(n)
+#define PH_MARK(i)
+#define PH_WAIT_VM()
+#define PH_WAIT_LGKM()
+#define PH_FLUSH(base, n)
+#endif
+
 namespace bds {
 
 // Per-stage [q][k] twiddle tables in LDS for the inverse fp32 transforms (bds_fft_t.h tstage TAB) instead of the W_S

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     const int L2 = A.L2;
     const long L = A.L;
     const ClockProbe clkp(A.clk ? A.clk + 2 : nullptr, 255);
+    PH_DECL(24);
 
     // ---- the item of this workgroup ----------------------------------------------------------------------
     // One tile per workgroup, workgroups started by the hardware in list order.  Workgroup id % 8 = XCD; XCD x keeps the
@@ -166,6 +167,10 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         g = g >= A.G ? g - A.G : g;
         c0 = (xcd * TX + tg * 4 + t4) * W::T;
     }
+#ifdef BDS_EXP_PHASES
+    asm volatile("" : "+s"(g), "+s"(c0));
+#endif
+    PH_MARK(16);  // kernel arguments read, item decoded
 
     // ---- rows of both components: in flight before anything else ---------------------------------------------
     // phase A: butterfly b of column pair cp takes rows b + 64 q
@@ -198,7 +203,9 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     };
     Raw pre0[R1], pre1[NCOMP > 1 ? R1 : 1];
     fetch(pre0, 0);
+    PH_MARK(17);  // rows of component 0 requested
     if constexpr (NCOMP > 1) fetch(pre1, 1);
+    PH_MARK(18);  // rows of component 1 requested
     // the cell's maximum so far and the PRN's running bound: read now (L2 / fabric latency), used after the transforms;
     // stale values are lower values, which only costs a redundant visit of the rare path below
     const int cell = A.cell0 + g;
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     float2 twA[R1];  // w_S^(b p), inverse direction
 #pragma unroll
     for (int p = 1; p < R1; ++p) twA[p] = A.wtab[(p - 1) * W::NT + tid];
+    PH_MARK(19);  // running bounds + phase-A constants requested
     float2 *const wrA = ldsf + cp * RS + b;  // + m MS
     // phase B: stage 2 as lane (ml, bl), stage 3 as lane (ml, u) with u = bl
     const int ml = lane & 7, bl = lane >> 3;
@@ -274,6 +282,9 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
 
     float sq[NCOMP][SL][NV];  // |y|^2 per component
     float bmax = 0.f;         // maximum of |y_d|^2 (+ |y_p|^2) over the wave's outputs
+    PH_MARK(15);  // set-up: kernel arguments, item, loads issued
+    PH_WAIT_VM();
+    PH_MARK(0);  // rows of both components + per-lane constants have arrived
 #pragma unroll
     for (int comp = 0; comp < NCOMP; ++comp) {
         {
@@ -287,14 +298,19 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
                     phaseA(pre1, z);
                 }
             }
+            PH_MARK(1 + 6 * comp);  // phase A arithmetic
             if (comp > 0) BDS_WSYNC();  // every wave is through with its region (last reads of the previous component)
+            PH_MARK(2 + 6 * comp);  // (barrier before the writes)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
 #pragma unroll
                 for (int p = 0; p < R1; ++p) wrA[(c * R1 + p) * MS] = z[c][p];
             }
+            PH_WAIT_LGKM();
+            PH_MARK(3 + 6 * comp);  // phase A writes issued and landed
         }
         BDS_WSYNC();
+        PH_MARK(4 + 6 * comp);  // barrier
         // ---- phase B, one slot (= 8 of the wave's rows m) at a time so that only 16-32 points are live:
         //   st2(s): radix 8 over bh, back in place;  st3(s): twiddle, radix 8 over bl (rotated start), magnitudes.
         // Row m is read and written by the 8 lanes of one ml only, all in this wave, and LDS traffic of a wave is in
@@ -338,6 +354,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
             if (s + 1 < SL) st2(s + 1);
             st3(s);
         }
+        PH_MARK(5 + 6 * comp);  // phase B
     }
     // ---- maximum of the wave's two columns, candidates ------------------------------------------
     // Cauchy-Schwarz: (w_d |y_d| + w_p |y_p|)^2 <= (w_d^2 + w_p^2) (|y_d|^2 + |y_p|^2).  If even that bound, over all of the
@@ -426,6 +443,8 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         }
         }
     }
+    PH_MARK(13);  // tail
+    PH_FLUSH(0, 24);
     clkp.finish(tid);
 }
 

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long L = A.L;
     const ClockProbe clkp(A.clk, 63);
+    PH_DECL(17);
     auto wave_sync = [] {  // LDS traffic of one wave is in order; this only stops the compiler from moving it
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) cv[comp][q] = *reinterpret_cast<const uint32_t *>(cr + q * 256);
         }
+        PH_MARK(16);  // workgroup prologue: twiddles, code rows issued
         for (int g = g0; g < g1; ++g) {
 #pragma unroll
             for (int comp = 0; comp < NCOMP; ++comp) {
@@ -126,14 +128,24 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) y[j] = rd1[4 * ((j + bl) & 15)];
                 wave_sync();
+                PH_MARK(8 * comp + 0);  // products, phase 1a, exchange issued
+                PH_WAIT_LGKM();
+                PH_MARK(8 * comp + 1);  // ... landed
                 bfly16_fma<+1, true>(y, twB);  // twiddle w256^(bl u) on the inputs (up to the factor w256^(u u))
+                PH_MARK(8 * comp + 2);  // phase 1b arithmetic
                 if (comp > 0 || g > g0) BDS_SYNC();  // every thread is through with the exchange buffer (previous transform)
+                PH_MARK(8 * comp + 3);  // barrier
 #pragma unroll
                 for (int v = 0; v < 16; ++v) wrx[16 * XS * v] = y[v];
+                PH_WAIT_LGKM();
+                PH_MARK(8 * comp + 4);  // exchange writes
                 BDS_SYNC();
+                PH_MARK(8 * comp + 5);  // barrier
                 // ---- phase 2: twiddle, radix 16 over q', inter-pass twiddle, store
 #pragma unroll
                 for (int q = 0; q < 16; ++q) y[q] = rd2[q];
+                PH_WAIT_LGKM();
+                PH_MARK(8 * comp + 6);  // exchange reads
                 bfly16_fma<+1, true>(y, twC);  // twiddle w4096^(q' e'') on the inputs
 #pragma unroll
                 for (int p = 0; p < 16; ++p) {
@@ -143,10 +155,12 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
 #endif
                     *reinterpret_cast<uint32_t *>(dst + 256 * p) = f2_to_h2(t);
                 }
+                PH_MARK(8 * comp + 7);  // phase 2 arithmetic, stores issued
             }
         }
         if (vb + (int)gridDim.x < A.nvb) BDS_SYNC();
     }
+    PH_FLUSH(32, 17);
     clkp.finish(tid);
 }
 
