@@ -602,7 +602,7 @@ struct SieveOut {
 // ---- fp32-arithmetic search kernels (bds_acq_f32.h): dispatch on the compile-time lengths --------------
 template <int S, int NC, class ST>
 static void launch_rows_f(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs,
-                          void *Bw, float out_scale, const CellList &cl) {
+                          void *Bw, float out_scale, const CellList &cl, bool ilv) {
     const size_t lds = sizeof(float2) * (tspan<S>() + f32_tw_span<S, kF32TabRows>());
     want_lds(ctx, k_rows_inv_f<S, NC, ST>, lds);
     // balanced chunks of at most tune.gchunk cells
@@ -610,14 +610,21 @@ static void launch_rows_f(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const 
     int gc = (G + nch - 1) / nch;
     if (cl.bin) gc = cl.gc, nch = (G + cl.gc - 1) / cl.gc;  // a workgroup stays inside one PRN's cells
     const int nvb = pl.L1 * nch;  // L1 % 8 == 0 on every specialised plan: virtual workgroup vb sits on XCD vb % 8
-    const RowsFArgs A{(const float2 *)(kF32TabRows ? pl.d_ftab2 : pl.d_tw2), pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs, nvb, ctx->tune.clockprobe ? pl.d_clk : nullptr};
+    const RowsFArgs A{(const float2 *)(kF32TabRows ? pl.d_ftab2 : pl.d_tw2), pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs, nvb, ctx->tune.clockprobe ? pl.d_clk : nullptr, ilv ? 1 : 0};
     const int grid = ctx->tune.rows_grid > 0 ? std::min(nvb, (ctx->tune.rows_grid + 7) / 8 * 8) : nvb;
     if constexpr (S == 4096 && std::is_same<ST, __half2>::value) {
         if (ctx->tune.wrows != 0) {  // wave-private row pass (bds_acq_wrows.h): per-lane twiddle constants, 4 barriers per cell
             RowsFArgs B = A;
             B.tw = pl.d_wrtab;
-            want_lds(ctx, k_rows_wave_f<NC>, kWRowsLdsBytes);
-            hipLaunchKernelGGL((k_rows_wave_f<NC>), dim3(grid), dim3(256), kWRowsLdsBytes, sr, B);
+            if constexpr (NC == 2) {
+                if (ilv) {
+                    want_lds(ctx, k_rows_wave_f<NC, true>, kWRowsLdsBytes);
+                    hipLaunchKernelGGL((k_rows_wave_f<NC, true>), dim3(grid), dim3(256), kWRowsLdsBytes, sr, B);
+                    return;
+                }
+            }
+            want_lds(ctx, k_rows_wave_f<NC, false>, kWRowsLdsBytes);
+            hipLaunchKernelGGL((k_rows_wave_f<NC, false>), dim3(grid), dim3(256), kWRowsLdsBytes, sr, B);
             return;
         }
     }
@@ -640,24 +647,33 @@ static void launch_cols_ft(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G
 }
 // wave-private column pass: one tile per workgroup, workgroups started by the hardware in list order (see the kernel's
 // note on item order)
-template <int S, int NC, bool MASKED, class ST, int NV>
+template <int S, int NC, bool MASKED, class ST, int NV, bool ILV = false>
 static void launch_cols_wm(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, const WColsArgs &A) {
     using W = WCols<S>;
-    want_lds(ctx, k_cols_wave_f<S, NC, MASKED, ST, NV>, W::kLdsBytes);
+    want_lds(ctx, k_cols_wave_f<S, NC, MASKED, ST, NV, ILV>, W::kLdsBytes);
     WColsArgs B = A;
     const int quads = A.ntiles / 32;  // per XCD and cell
     B.qchunk = std::max(1, std::min(ctx->tune.wcols_qchunk, quads));
     while (quads % B.qchunk) --B.qchunk;
-    hipLaunchKernelGGL((k_cols_wave_f<S, NC, MASKED, ST, NV>), dim3(A.n_items), dim3(W::NT), W::kLdsBytes, sc, B);
+    hipLaunchKernelGGL((k_cols_wave_f<S, NC, MASKED, ST, NV, ILV>), dim3(A.n_items), dim3(W::NT), W::kLdsBytes, sc, B);
 }
 template <int S, int NC, class ST>
 static void launch_cols_w(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1,
-                          int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl) {
+                          int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl, bool ilv) {
     const int ntiles = pl.L2 / WCols<S>::T;  // L2 % 256 == 0 on every specialised plan: ntiles % 32 == 0 (8 XCDs x quads)
     const WColsArgs A{(const float2 *)pl.d_wtab, pl.L2, ntiles, G, G * ntiles, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, cl.rng,
                       so.cellmax, so.lb, so.lb_div, so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep, 1,
                       ctx->tune.clockprobe ? pl.d_clk : nullptr};
     const bool masked = cl.rng || !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
+    if constexpr (S == 768 && NC == 2 && std::is_same<ST, __half2>::value) {  // (the plan with 4096-point rows: cfg3)
+        if (ilv) {  // k_rows_wave_f<2, true> laid the buffer out [cell][element][component]
+            if (hi1 / pl.L2 < 6 * 8 * WCols<S>::R1)
+                launch_cols_wm<S, NC, false, ST, 6, true>(ctx, sc, pl, A);
+            else
+                launch_cols_wm<S, NC, false, ST, 8, true>(ctx, sc, pl, A);
+            return;
+        }
+    }
     if (masked)
         launch_cols_wm<S, NC, true, ST, 8>(ctx, sc, pl, A);
     else if (hi1 / pl.L2 < 6 * 8 * WCols<S>::R1)  // no searched lag beyond output row 48 R1: outputs v = 6, 7 of the last stage unused
@@ -667,8 +683,8 @@ static void launch_cols_w(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G,
 }
 template <int S, int NC, class ST>
 static void launch_cols_f(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1,
-                          int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl) {
-    if (so.cellmax) return launch_cols_w<S, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl);
+                          int hi1, int lo2, int hi2, const SieveOut &so, const CellList &cl, bool ilv) {
+    if (so.cellmax) return launch_cols_w<S, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl, ilv);
     if (pl.logT == 2)
         launch_cols_ft<S, 4, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl);
     else
@@ -679,11 +695,15 @@ template <int NC, class ST>
 static void launch_fast_f(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const void *Xs, int G, int bin0, const void *Cs,
                           void *Bw, float out_scale, float w0, float w1, int lo1, int hi1, int lo2, int hi2, const SieveOut &so,
                           const CellList &cl = {}) {
+    // both components of an element side by side in the inter-pass buffer: the wave-private pair of the 768 x 4096 plan (cfg3),
+    // unmasked search (one lag range from 0), fp16 storage, two components
+    const bool ilv = NC == 2 && std::is_same<ST, __half2>::value && pl.L1 == 768 && pl.L2 == 4096 && ctx->tune.wrows != 0 &&
+                     so.cellmax && ctx->tune.ilv != 0 && !cl.rng && lo1 == 0 && lo2 > hi2;
     switch (pl.L2) {
-        case 1280: launch_rows_f<1280, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl); break;
-        case 2048: launch_rows_f<2048, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl); break;
-        case 3072: launch_rows_f<3072, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl); break;
-        default: launch_rows_f<4096, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl); break;
+        case 1280: launch_rows_f<1280, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl, false); break;
+        case 2048: launch_rows_f<2048, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl, false); break;
+        case 3072: launch_rows_f<3072, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl, false); break;
+        default: launch_rows_f<4096, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl, ilv); break;
     }
     if (so.mid) (void)hipEventRecord(so.mid, st_);
     hipStream_t sc = st_;
@@ -693,10 +713,10 @@ static void launch_fast_f(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const
         (void)hipStreamWaitEvent(sc, so.ev_rows, 0);
     }
     switch (pl.L1) {
-        case 256: launch_cols_f<256, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
-        case 512: launch_cols_f<512, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
-        case 768: launch_cols_f<768, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
-        default: launch_cols_f<1024, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl); break;
+        case 256: launch_cols_f<256, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl, ilv); break;
+        case 512: launch_cols_f<512, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl, ilv); break;
+        case 768: launch_cols_f<768, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl, ilv); break;
+        default: launch_cols_f<1024, NC, ST>(ctx, sc, pl, G, Bw, w0, w1, lo1, hi1, lo2, hi2, so, cl, ilv); break;
     }
     if (so.cols_stream) (void)hipEventRecord(so.ev_cols, sc);
 }

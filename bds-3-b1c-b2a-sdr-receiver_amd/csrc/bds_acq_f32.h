@@ -133,6 +133,7 @@ struct RowsFArgs {
     const long *cell_cs;   // ... and element offset of its code spectra from Cs
     int nvb;               // virtual workgroups (= L1 * NCH); a launch with fewer workgroups strides over them
     unsigned long long *clk;  // optional (BDS_ACQ_CLOCKPROBE): [0], [1] += shader-clock / reference-clock ticks of sampled workgroups
+    int ilv;                  // k_rows_wave_f with two components: inter-pass buffer laid out [cell][element][component]
 };
 
 // Engine clock under the real load (BDS_ACQ_CLOCKPROBE=1): every (mask + 1)-th workgroup times its own life with the shader

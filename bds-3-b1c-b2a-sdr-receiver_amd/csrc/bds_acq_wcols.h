@@ -129,9 +129,13 @@ __host__ __device__ constexpr int wcols_table_entries() {
     return (WCols<S>::R1 - 1) * WCols<S>::NT + 7 * 64;
 }
 
-template <int S, int NCOMP, bool MASKED, class ST, int NV>
+// ILV: the inter-pass buffer holds both components of an element side by side ([cell][element][component], written so by
+// k_rows_wave_f<2, true>): one 16-byte load per lane and tile row fetches both (64-byte pieces per tile row instead of 32-byte
+// ones, half the load instructions)
+template <int S, int NCOMP, bool MASKED, class ST, int NV, bool ILV = false>
 __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WColsArgs A) {
     static_assert(NV >= 1 && NV <= 8, "outputs of the last radix-8 stage");
+    static_assert(!ILV || (NCOMP == 2 && std::is_same<ST, __half2>::value), "interleaved components: two, fp16 storage");
     using W = WCols<S>;
     constexpr bool HS = std::is_same<ST, __half2>::value;
     constexpr int R1 = W::R1, SL = W::SL, MS = W::MS, RS = W::RS;
@@ -175,15 +179,16 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     // ---- rows of both components: in flight before anything else ---------------------------------------------
     // phase A: butterfly b of column pair cp takes rows b + 64 q
     const int cp = lane & 3, b = 16 * wave + (lane >> 2);
-    using Raw = typename std::conditional<HS, uint2, float4>::type;
+    using Raw = typename std::conditional<ILV, uint4, typename std::conditional<HS, uint2, float4>::type>::type;
     // (buffer loads: the descriptor of (cell, component, tile) and the row offsets live in scalar registers, the lane
     //  offset is one VGPR -- global_load with per-row 64-bit vector addresses cost two dozen VGPRs and their arithmetic;
     //  a flat_load would also count on the LDS counter and every LDS wait of the transform would wait for the rows)
-    const int voff = (b * L2 + 2 * cp) * (int)sizeof(ST);  // < 2^22
+    const int voff = (b * L2 + 2 * cp) * (int)sizeof(ST) * (ILV ? 2 : 1);  // < 2^23
     auto fetch = [&](Raw(&pre)[R1], int comp) {
-        const char *base = (const char *)A.Bw + (((long)g * NCOMP + comp) * L + c0) * (long)sizeof(ST);
+        const char *base = ILV ? (const char *)A.Bw + ((long)g * L + c0) * (long)(2 * sizeof(ST))
+                               : (const char *)A.Bw + (((long)g * NCOMP + comp) * L + c0) * (long)sizeof(ST);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000);
-        const int rowstep = 64 * L2 * (int)sizeof(ST);
+        const int rowstep = 64 * L2 * (int)sizeof(ST) * (ILV ? 2 : 1);
 #pragma unroll
         for (int q = 0; q < R1; ++q) {
 #ifdef BDS_EXP_WC_NOLOAD
@@ -192,7 +197,10 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
                 continue;
             }
 #endif
-            if constexpr (HS) {
+            if constexpr (ILV) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, q * rowstep, 0);
+                pre[q] = make_uint4(v[0], v[1], v[2], v[3]);  // (column 2 cp: data, pilot; column 2 cp + 1: data, pilot)
+            } else if constexpr (HS) {
                 const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, q * rowstep, 0);
                 pre[q] = make_uint2(v[0], v[1]);
             } else {
@@ -201,31 +209,31 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
             }
         }
     };
-    Raw pre0[R1], pre1[NCOMP > 1 ? R1 : 1];
+    // Order of the requests (round 4): a load instruction costs this wave 120 - 290 cycles of issue time while the other
+    // workgroups of the CU keep the vector-memory unit busy (tools/phases.py: 8.3 k of a wave's 24 k cycles went into requesting
+    // 45 loads before anything was computed).  So only what phase A of component 0 needs is requested up front -- the rows
+    // and ONE twiddle w_S^b, the others being its powers (ten complex products; their rounding, a few 1e-7, is far inside
+    // the sieve's tolerance) -- and the rest (component 1's rows unless interleaved, the phase-B constants, the running bounds)
+    // goes out behind phase A's arithmetic, where its latency is covered by phase B of component 0.
+    Raw pre0[R1], pre1[(NCOMP > 1 && !ILV) ? R1 : 1];
+    float2 twA[R1];  // w_S^(b p), inverse direction
+    twA[1] = A.wtab[tid];
     fetch(pre0, 0);
     PH_MARK(17);  // rows of component 0 requested
-    if constexpr (NCOMP > 1) fetch(pre1, 1);
-    PH_MARK(18);  // rows of component 1 requested
-    // the cell's maximum so far and the PRN's running bound: read now (L2 / fabric latency), used after the transforms;
-    // stale values are lower values, which only costs a redundant visit of the rare path below
     const int cell = A.cell0 + g;
     float *const lbp = A.lb + cell / A.lb_div;
-    const float lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
-
-    // ---- per-lane constants (coalesced from the plan's per-lane table) ------------------------------------------
-    float2 twA[R1];  // w_S^(b p), inverse direction
+    {
+        const float2 w = twA[1];
 #pragma unroll
-    for (int p = 1; p < R1; ++p) twA[p] = A.wtab[(p - 1) * W::NT + tid];
-    PH_MARK(19);  // running bounds + phase-A constants requested
+        for (int p = 2; p < R1; ++p) twA[p] = (p & 1) ? cmul(twA[p - 1], w) : cmul(twA[p / 2], twA[p / 2]);
+    }
+    PH_MARK(19);  // phase-A constants formed
     float2 *const wrA = ldsf + cp * RS + b;  // + m MS
     // phase B: stage 2 as lane (ml, bl), stage 3 as lane (ml, u) with u = bl
     const int ml = lane & 7, bl = lane >> 3;
     // stage-2 twiddle w_64^(bl u), applied by stage 3 to its INPUTS (bds_fft_fma.h: folded into the first butterfly layer): input
     // j of lane (ml, u) is bl = (j + u) & 7; the common unit factor w_64^(u u) is left out (invisible in |X|)
     float2 twB[8];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) twB[j] = A.wtab[(R1 - 1) * W::NT + (j - 1) * 64 + lane];
     float2 *const rw2 = ldsf + wave * RS + ml * MS + bl;  // + s 8 MS + 8 bh (read), + 8 u (write back)
     const float2 *rd3[8];                                 // row u from column u on: + s 8 MS
 #pragma unroll
@@ -246,10 +254,13 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     }
 
     // first stage of both columns of the pair, twiddled
-    auto phaseA = [&](const Raw(&pre)[R1], float2(&z)[2][R1]) {
+    auto phaseA = [&](const Raw(&pre)[R1], float2(&z)[2][R1], int comp) {
 #pragma unroll
         for (int q = 0; q < R1; ++q) {
-            if constexpr (HS) {
+            if constexpr (ILV) {
+                z[0][q] = h2_to_f2(comp == 0 ? pre[q].x : pre[q].y);
+                z[1][q] = h2_to_f2(comp == 0 ? pre[q].z : pre[q].w);
+            } else if constexpr (HS) {
                 z[0][q] = h2_to_f2(pre[q].x);
                 z[1][q] = h2_to_f2(pre[q].y);
             } else {
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     auto pin = [](Raw(&pre)[R1]) {
 #pragma unroll
         for (int q = 0; q < R1; ++q) {
-            if constexpr (HS)
+            if constexpr (HS && !ILV)
                 asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y));
             else
                 asm volatile("" : "+v"(pre[q].x), "+v"(pre[q].y), "+v"(pre[q].z), "+v"(pre[q].w));
@@ -282,6 +293,8 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
 
     float sq[NCOMP][SL][NV];  // |y|^2 per component
     float bmax = 0.f;         // maximum of |y_d|^2 (+ |y_p|^2) over the wave's outputs
+    float lbv = 0.f;
+    unsigned cur = 0;
     PH_MARK(15);  // set-up: kernel arguments, item, loads issued
     PH_WAIT_VM();
     PH_MARK(0);  // rows of both components + per-lane constants have arrived
@@ -290,12 +303,25 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         {
             float2 z[2][R1];
             if (comp == 0) {
-                phaseA(pre0, z);
+                phaseA(pre0, z, 0);
+                // the deferred requests (see above): answered while phase B of this component runs
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NCOMP > 1 && !ILV) fetch(pre1, 1);
+#pragma unroll
+                for (int j = 1; j < 8; ++j) twB[j] = A.wtab[(R1 - 1) * W::NT + (j - 1) * 64 + lane];
+                // the cell's maximum so far and the PRN's running bound (L2 / fabric latency), used after the transforms;
+                // stale values are lower values, which only costs a redundant visit of the rare path below
+                lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+                __builtin_amdgcn_sched_barrier(0);
             } else {
                 // (pinned here: moved up into the first component's last stage it doubles the live registers)
-                if constexpr (NCOMP > 1) {
+                if constexpr (ILV) {
+                    pin(pre0);
+                    phaseA(pre0, z, 1);
+                } else if constexpr (NCOMP > 1) {
                     pin(pre1);
-                    phaseA(pre1, z);
+                    phaseA(pre1, z, 1);
                 }
             }
             PH_MARK(1 + 6 * comp);  // phase A arithmetic

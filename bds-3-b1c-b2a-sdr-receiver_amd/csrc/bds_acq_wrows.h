@@ -38,10 +38,15 @@ constexpr int kWRowsRegion = 1024;  // elements of a wave's region (4 q' x 256)
 constexpr int kWRowsXS = 19;        // elements between consecutive e'' of the exchange buffer (38 dwords: conflict-free both ways; 17 costs 7 %)
 constexpr size_t kWRowsLdsBytes = sizeof(float2) * (4 * kWRowsRegion + 256 * kWRowsXS);
 
-template <int NCOMP>
+template <int NCOMP, bool ILV>
 __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
     using ST = __half2;  // fp16 storage only: with fp32 storage the 32-byte load pieces cost more than the stages save (5.2 vs 3.1 ms)
     constexpr int S = 4096, XS = kWRowsXS;
+    // both components of an element side by side in the inter-pass buffer ([cell][element][component]): the column pass fetches
+    // a tile row of both with ONE 16-byte load per lane, this pass stores 8 bytes per lane and output -- half the vector-memory
+    // instructions on either side (ILV; two components only)
+    static_assert(!ILV || NCOMP == 2, "interleaved components: two of them");
+    constexpr bool ILV_OK = ILV;
     extern __shared__ __attribute__((aligned(16))) float2 ldsf[];
     __shared__ float2 s_b[16];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,10 +58,8 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    // per-lane stage twiddles (plan constants)
-    float2 twC[16], twB[16];
-#pragma unroll
-    for (int q = 1; q < 16; ++q) twC[q] = A.tw[(q - 1) * 256 + tid];
+    // per-lane stage twiddles of phase 1b (plan constants); those of phase 2 are completed per row below
+    float2 twB[16];
 #pragma unroll
     for (int u = 1; u < 16; ++u) twB[u] = A.tw[15 * 256 + (u - 1) * 64 + lane];
     const int ql = lane & 3, bl = lane >> 2;  // phase 1a: (ql, bl); phase 1b: (ql, u = bl)
@@ -83,19 +86,30 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) xn[q] = *reinterpret_cast<const uint32_t *>(xr + q * 256);
         };
-        __syncthreads();  // s_b
-        // inter-pass twiddle W_L^(-k1 e) of this thread's outputs e = tid + 256 p', times the storage scale, times the factor
-        // w16^(u v) (u = tid & 15, v = tid >> 4) that undoes the rotated read of phase 1b, times the factor w256^(u u) its
-        // twiddles leave out
-        float2 wo[16];
+        // The inter-pass twiddle W_L^(k1 e) of output e = tid + 256 p' factors into a per-thread part
+        //   wi = W_L^(k1 tid) x storage scale x w16^(u v) (u = tid & 15, v = tid >> 4: undoes the rotated read of phase 1b)
+        //        x w256^(u u) (the factor the phase-1b twiddles leave out)
+        // and a workgroup-uniform part s_b[p'] = W_L^(256 k1 p').  The transform is linear: wi goes into the phase-2 INPUT
+        // twiddles w4096^(q' tid) (once per row), s_b[] into scalar registers -- the 32 VGPRs a per-thread table of all 16
+        // products took (round 3) hold the first component's packed outputs instead (interleaved stores).
+        float2 twC[16];
         {
             float2 wi = A.twl.get<+1>((uint32_t)k1 * (uint32_t)tid);
             wi.x *= A.out_scale;
             wi.y *= A.out_scale;
             wi = cmul(wi, A.tw[15 * 256 + 15 * 64 + (((tid & 15) * (tid >> 4)) & 15)]);
             wi = cmul(wi, A.tw[15 * 256 + 15 * 64 + 16 + (tid & 15)]);
+            twC[0] = wi;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) wo[p] = cmul(wi, s_b[p]);
+            for (int q = 1; q < 16; ++q) twC[q] = cmul(wi, A.tw[(q - 1) * 256 + tid]);
+        }
+        __syncthreads();  // s_b
+        float sbx[16], sby[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float2 t = s_b[p];
+            sbx[p] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t.x)));
+            sby[p] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t.y)));
         }
         // (the rows are fetched after the twiddle set-up: loaded before it, they and its temporaries overflow the register file)
         fetch_x(g0);
@@ -109,52 +123,98 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         }
         PH_MARK(16);  // workgroup prologue: twiddles, code rows issued
         for (int g = g0; g < g1; ++g) {
+            uint32_t r0[ILV_OK ? 16 : 1];  // packed outputs of component 0, held for the interleaved store
 #pragma unroll
             for (int comp = 0; comp < NCOMP; ++comp) {
-                ST *dst = (ST *)A.Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S + tid;
-                // ---- phase 1a: products, radix 16 over bh, twiddle, to the wave's region
-                float2 y[16];
+                // ---- phase 1a: products, radix 16 over bh, to the wave's region.  (Round 4: every exchange is spread over the
+                // butterfly layer that produces / consumes it -- the four outputs of a layer-2 group are written while the next
+                // group is computed, reads are issued in the order the layer-1 groups need them -- instead of 16 writes and 16
+                // reads back to back: a burst from all four waves queues on the LDS store path at ~40 cycles per write against
+                // ~20 spread out, tools/phases.py.)
+                float2 y[16], a[4][4], o[4];
 #pragma unroll
                 for (int q = 0; q < 16; ++q)  // ((xi, xr) is re-formed per component: one v_alignbit against 16 registers held across both)
                     y[q] = cmul_h(xn[q], __builtin_amdgcn_alignbit(xn[q], xn[q], 16), cv[comp][q]);
                 // the last component's products are the last readers of xn: the next cell's row is fetched into the same
                 // registers while the transform and the stores run
                 if (comp == NCOMP - 1 && g + 1 < g1) fetch_x(g + 1);
-                bfly16_fma<+1, false>(y, nullptr);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) wr1[64 * u] = y[u];
+                for (int n2 = 0; n2 < 4; ++n2) bfly16_l1<+1, false>(y, nullptr, n2, a[n2]);
+#define BDS_WR_L2(K1, DST, STEP)                    \
+    bfly16_l2<+1, K1>(a, o);                        \
+    __builtin_amdgcn_sched_barrier(0);              \
+    (DST)[(STEP) * (K1)] = o[0];                    \
+    (DST)[(STEP) * ((K1) + 4)] = o[1];              \
+    (DST)[(STEP) * ((K1) + 8)] = o[2];              \
+    (DST)[(STEP) * ((K1) + 12)] = o[3];             \
+    __builtin_amdgcn_sched_barrier(0)
+                BDS_WR_L2(0, wr1, 64);
+                BDS_WR_L2(1, wr1, 64);
+                BDS_WR_L2(2, wr1, 64);
+                BDS_WR_L2(3, wr1, 64);
                 wave_sync();
                 // ---- phase 1b: radix 16 over bl (rotated start), to the exchange buffer
 #pragma unroll
-                for (int j = 0; j < 16; ++j) y[j] = rd1[4 * ((j + bl) & 15)];
+                for (int n2 = 0; n2 < 4; ++n2) {
+#pragma unroll
+                    for (int mm = 0; mm < 4; ++mm) y[n2 + 4 * mm] = rd1[4 * ((n2 + 4 * mm + bl) & 15)];
+                }
                 wave_sync();
+                __builtin_amdgcn_sched_barrier(0);
                 PH_MARK(8 * comp + 0);  // products, phase 1a, exchange issued
-                PH_WAIT_LGKM();
-                PH_MARK(8 * comp + 1);  // ... landed
-                bfly16_fma<+1, true>(y, twB);  // twiddle w256^(bl u) on the inputs (up to the factor w256^(u u))
-                PH_MARK(8 * comp + 2);  // phase 1b arithmetic
+#pragma unroll
+                for (int n2 = 0; n2 < 4; ++n2) bfly16_l1<+1, true>(y, twB, n2, a[n2]);  // twiddle w256^(bl u) on the inputs (up to the factor w256^(u u))
+                PH_MARK(8 * comp + 2);  // phase 1b layer 1 (waits for its inputs group by group)
                 if (comp > 0 || g > g0) BDS_SYNC();  // every thread is through with the exchange buffer (previous transform)
                 PH_MARK(8 * comp + 3);  // barrier
-#pragma unroll
-                for (int v = 0; v < 16; ++v) wrx[16 * XS * v] = y[v];
-                PH_WAIT_LGKM();
-                PH_MARK(8 * comp + 4);  // exchange writes
+                BDS_WR_L2(0, wrx, 16 * XS);
+                BDS_WR_L2(1, wrx, 16 * XS);
+                BDS_WR_L2(2, wrx, 16 * XS);
+                BDS_WR_L2(3, wrx, 16 * XS);
+#undef BDS_WR_L2
+                PH_MARK(8 * comp + 4);  // phase 1b layer 2 + exchange writes
                 BDS_SYNC();
                 PH_MARK(8 * comp + 5);  // barrier
-                // ---- phase 2: twiddle, radix 16 over q', inter-pass twiddle, store
+                // ---- phase 2: twiddle (wi folded in), radix 16 over q', uniform factor, store
 #pragma unroll
-                for (int q = 0; q < 16; ++q) y[q] = rd2[q];
-                PH_WAIT_LGKM();
-                PH_MARK(8 * comp + 6);  // exchange reads
-                bfly16_fma<+1, true>(y, twC);  // twiddle w4096^(q' e'') on the inputs
+                for (int n2 = 0; n2 < 4; ++n2) {
 #pragma unroll
-                for (int p = 0; p < 16; ++p) {
-                    const float2 t = cmul(y[p], wo[p]);
+                    for (int mm = 0; mm < 4; ++mm) y[n2 + 4 * mm] = rd2[n2 + 4 * mm];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                PH_MARK(8 * comp + 6);  // exchange reads issued
+#pragma unroll
+                for (int n2 = 0; n2 < 4; ++n2) bfly16_l1<+1, true, true>(y, twC, n2, a[n2]);
+                auto emit = [&](int p, float2 yv) {
+                    float2 t;
+                    t.x = fmaf(-yv.y, sby[p], yv.x * sbx[p]);
+                    t.y = fmaf(yv.y, sbx[p], yv.x * sby[p]);
+                    const uint32_t h = f2_to_h2(t);
 #ifdef BDS_EXP_ROWS_NOSTORE
                     if (t.x == 1.2345f)
 #endif
-                    *reinterpret_cast<uint32_t *>(dst + 256 * p) = f2_to_h2(t);
-                }
+                    {
+                        if constexpr (ILV) {
+                            if (comp == 0) {
+                                r0[ILV_OK ? p : 0] = h;
+                            } else {
+                                uint2 *dst2 = (uint2 *)A.Bw + (long)g * L + (long)k1 * S + tid + 256 * p;
+                                *dst2 = make_uint2(r0[ILV_OK ? p : 0], h);
+                            }
+                        } else {
+                            ST *dst = (ST *)A.Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S + tid;
+                            *reinterpret_cast<uint32_t *>(dst + 256 * p) = h;
+                        }
+                    }
+                };
+#define BDS_ST_L2(K1)                                     \
+    bfly16_l2<+1, K1>(a, o);                              \
+    emit((K1), o[0]), emit((K1) + 4, o[1]), emit((K1) + 8, o[2]), emit((K1) + 12, o[3])
+                BDS_ST_L2(0);
+                BDS_ST_L2(1);
+                BDS_ST_L2(2);
+                BDS_ST_L2(3);
+#undef BDS_ST_L2
                 PH_MARK(8 * comp + 7);  // phase 2 arithmetic, stores issued
             }
         }

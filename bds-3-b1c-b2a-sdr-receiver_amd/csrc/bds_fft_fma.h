@@ -36,60 +36,72 @@ __device__ __forceinline__ void radix4_tw(float2 *v, float2 t1, float2 t2, float
     v[3] = csub(q, s);
 }
 
-// v <- DFT16(tw .* v) (TW: tw[1 .. 15] are applied to the inputs, tw[0] is taken as 1) or DFT16(v); DIR as Butterfly<16, DIR>
-template <int DIR, bool TW>
-__device__ __forceinline__ void bfly16_fma(float2 *v, const float2 *tw) {
-#ifdef BDS_EXP_PLAIN_BFLY  // timing experiment: the same transform with separate twiddle products and Butterfly<16, DIR>
+// The 16-point transform in two layers, so that a caller can put LDS or global accesses between the groups of a layer (the
+// first group of layer 1 needs only inputs 0, 4, 8, 12; group k1 of layer 2 delivers outputs k1, k1 + 4, k1 + 8, k1 + 12):
+//   layer 1, group n2: a[n2][.] = DFT4 over (tw .* v)[n2 + 4 m]        (TW: tw[1 .. 15] on the inputs, tw[0] only if TW0)
+//   layer 2, group k1: v[k1 + 4 k2] = DFT4 over W16^(n2 k1) a[n2][k1]
+template <int DIR, bool TW, bool TW0 = false>
+__device__ __forceinline__ void bfly16_l1(const float2 *v, const float2 *tw, int n2, float2 (&a)[4]) {
+    a[0] = v[n2];
+    a[1] = v[n2 + 4];
+    a[2] = v[n2 + 8];
+    a[3] = v[n2 + 12];
     if constexpr (TW) {
-#pragma unroll
-        for (int i = 1; i < 16; ++i) v[i] = cmul(v[i], tw[i]);
+        if (n2 > 0 || TW0) a[0] = cmul(a[0], tw[n2]);
+        radix4_tw<DIR>(a, tw[n2 + 4], tw[n2 + 8], tw[n2 + 12]);
+    } else {
+        Butterfly<4, DIR>::run(a);
     }
-    Butterfly<16, DIR>::run(v);
-    return;
-#endif
+}
+template <int DIR, int K1>
+__device__ __forceinline__ void bfly16_l2(const float2 (&a)[4][4], float2 (&u)[4]) {
     constexpr float sg = DIR > 0 ? 1.f : -1.f;
     const float h = 0.70710678118654752440f;
     const float c = 0.92387953251128675613f;  // cos(pi/8)
     const float s = 0.38268343236508977173f;  // sin(pi/8)
-    float2 a[4][4];
-#pragma unroll
-    for (int n2 = 0; n2 < 4; ++n2) {
-        a[n2][0] = v[n2];
-        a[n2][1] = v[n2 + 4];
-        a[n2][2] = v[n2 + 8];
-        a[n2][3] = v[n2 + 12];
-        if constexpr (TW) {
-            if (n2 > 0) a[n2][0] = cmul(a[n2][0], tw[n2]);
-            radix4_tw<DIR>(a[n2], tw[n2 + 4], tw[n2 + 8], tw[n2 + 12]);
-        } else {
-            Butterfly<4, DIR>::run(a[n2]);
-        }
-    }
-    // second layer: radix 4 over n2 of W16^(n2 k1) a[n2][k1]
-    {
-        float2 u[4] = {a[0][0], a[1][0], a[2][0], a[3][0]};
+    if constexpr (K1 == 0) {
+        u[0] = a[0][0], u[1] = a[1][0], u[2] = a[2][0], u[3] = a[3][0];
         Butterfly<4, DIR>::run(u);
-        v[0] = u[0], v[4] = u[1], v[8] = u[2], v[12] = u[3];
-    }
-    {
-        float2 u[4] = {a[0][1], a[1][1], a[2][1], a[3][1]};
+    } else if constexpr (K1 == 1) {
+        u[0] = a[0][1], u[1] = a[1][1], u[2] = a[2][1], u[3] = a[3][1];
         radix4_tw<DIR>(u, make_float2(c, sg * s), make_float2(h, sg * h), make_float2(s, sg * c));  // W16^1, W16^2, W16^3
-        v[1] = u[0], v[5] = u[1], v[9] = u[2], v[13] = u[3];
-    }
-    {  // W16^2, W16^4 = +-j, W16^6
+    } else if constexpr (K1 == 2) {  // W16^2, W16^4 = +-j, W16^6
         const float2 x0 = a[0][2], jx2 = rot90<DIR>(a[2][2]);
         const float2 p = cadd(x0, jx2), q = csub(x0, jx2);
         const float2 x1 = cmul(a[1][2], make_float2(h, sg * h));
         float2 r, t;
         bf2w(x1, a[3][2], -h, sg * h, r, t);
         t = rot90<DIR>(t);
-        v[2] = cadd(p, r), v[6] = cadd(q, t), v[10] = csub(p, r), v[14] = csub(q, t);
-    }
-    {
-        float2 u[4] = {a[0][3], a[1][3], a[2][3], a[3][3]};
+        u[0] = cadd(p, r), u[1] = cadd(q, t), u[2] = csub(p, r), u[3] = csub(q, t);
+    } else {
+        u[0] = a[0][3], u[1] = a[1][3], u[2] = a[2][3], u[3] = a[3][3];
         radix4_tw<DIR>(u, make_float2(s, sg * c), make_float2(-h, sg * h), make_float2(-c, -sg * s));  // W16^3, W16^6, W16^9
-        v[3] = u[0], v[7] = u[1], v[11] = u[2], v[15] = u[3];
     }
+}
+
+// v <- DFT16(tw .* v) (TW: tw[1 .. 15] are applied to the inputs, tw[0] is taken as 1 unless TW0) or DFT16(v); DIR as Butterfly<16, DIR>
+template <int DIR, bool TW, bool TW0 = false>
+__device__ __forceinline__ void bfly16_fma(float2 *v, const float2 *tw) {
+#ifdef BDS_EXP_PLAIN_BFLY  // timing experiment: the same transform with separate twiddle products and Butterfly<16, DIR>
+    if constexpr (TW) {
+#pragma unroll
+        for (int i = TW0 ? 0 : 1; i < 16; ++i) v[i] = cmul(v[i], tw[i]);
+    }
+    Butterfly<16, DIR>::run(v);
+    return;
+#endif
+    float2 a[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) bfly16_l1<DIR, TW, TW0>(v, tw, n2, a[n2]);
+    float2 u[4];
+    bfly16_l2<DIR, 0>(a, u);
+    v[0] = u[0], v[4] = u[1], v[8] = u[2], v[12] = u[3];
+    bfly16_l2<DIR, 1>(a, u);
+    v[1] = u[0], v[5] = u[1], v[9] = u[2], v[13] = u[3];
+    bfly16_l2<DIR, 2>(a, u);
+    v[2] = u[0], v[6] = u[1], v[10] = u[2], v[14] = u[3];
+    bfly16_l2<DIR, 3>(a, u);
+    v[3] = u[0], v[7] = u[1], v[11] = u[2], v[15] = u[3];
 }
 
 // v <- DFT8(tw .* v) (TW: tw[1 .. 7] on the inputs) or DFT8(v): 72 instructions against 28 + 56, 52 against 56

@@ -101,6 +101,41 @@ __global__ __launch_bounds__(256) void k_burst_late(unsigned long long *out, flo
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
     if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 1.2345f) out[0] = 0;
 }
+
+// the same flops as "16fma" issued as 8 v_pk_fma_f32 (two FMAs per lane and instruction; 4 cycles each on the vector pipe)
+#define PK8 "v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n" \
+            "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pk(unsigned long long *out, float seed, int iters) {
+    extern __shared__ char lds[];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a0 = {seed + threadIdx.x, seed}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    f2 b0 = {seed * 0.5f, seed * 0.5f}, b1 = {seed * 0.25f, seed * 0.25f};
+    const unsigned addr = threadIdx.x * 8u;
+    const double val = seed;
+    double rdv;
+    ((double *)lds)[threadIdx.x] = val;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters / 8; ++it) {
+        if (MODE == 0)
+            asm volatile(X8(PK8) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1) : "memory");
+        else  // 4 pk, write, 4 pk, read
+            asm volatile(X8("v_pk_fma_f32 %0, %0, %9, %10\n v_pk_fma_f32 %1, %1, %9, %10\n v_pk_fma_f32 %2, %2, %9, %10\n v_pk_fma_f32 %3, %3, %9, %10\n"
+                            "ds_write_b64 %11, %12\n"
+                            "v_pk_fma_f32 %4, %4, %9, %10\n v_pk_fma_f32 %5, %5, %9, %10\n v_pk_fma_f32 %6, %6, %9, %10\n v_pk_fma_f32 %7, %7, %9, %10\n"
+                            "ds_read_b64 %8, %11\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(rdv)
+                         : "v"(b0), "v"(b1), "v"(addr), "v"(val)
+                         : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    const f2 sm = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if (sm.x + sm.y == 1.2345f) out[0] = 0;
+}
+
 // role split: even workgroups compute only (16 fma per group), odd workgroups stream LDS only (one write + one read per
 // group, or writes only); with 2 workgroups per CU every SIMD holds one wave of each kind
 template <int MODE>
@@ -157,7 +192,7 @@ void run(const char *name, K kern, unsigned long long *d_out) {
     std::vector<unsigned long long> h(256 * 8 * 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    for (int k : {1, 2, 3, 4}) {
+    for (int k : {1, 2, 3, 4, 6, 8}) {
         const int grid = 256 * k;
         kern<<<grid, 256, 2048>>>(d_out, 1.0f, ITER);
         hipEventRecord(e0);
@@ -179,7 +214,9 @@ int main() {
     unsigned long long *d_out;
     hipMalloc(&d_out, sizeof(unsigned long long) * 256 * 8 * 4);
     run("16fma", k_valu, d_out);
+    run("8pk_fma (= 16 fma)", k_pk<0>, d_out);
     run("8fma,w,8fma,r", k_spread_wr, d_out);
+    run("4pk,w,4pk,r", k_pk<1>, d_out);
     run("16fma,w", k_spread_w, d_out);
     run("16fma,r", k_spread_r, d_out);
     run("8fma,w32,8fma,w32", k_spread_w32x2, d_out);
