@@ -104,6 +104,36 @@ __device__ __forceinline__ void bfly16_fma(float2 *v, const float2 *tw) {
     v[3] = u[0], v[7] = u[1], v[11] = u[2], v[15] = u[3];
 }
 
+// The 8-point transform in two layers (as the 16-point one above): layer 1 = DFT4 over the even inputs (a0) and over the odd
+// inputs (a1), each with its input twiddles; layer 2, group k1: (v[k1], v[k1 + 4]) = a0[k1] +- W8^k1 a1[k1]
+template <int DIR, bool TW>
+__device__ __forceinline__ void bfly8_l1(const float2 *v, const float2 *tw, int odd, float2 (&a)[4]) {
+    a[0] = v[odd], a[1] = v[2 + odd], a[2] = v[4 + odd], a[3] = v[6 + odd];
+    if constexpr (TW) {
+        if (odd) a[0] = cmul(a[0], tw[1]);
+        radix4_tw<DIR>(a, tw[2 + odd], tw[4 + odd], tw[6 + odd]);
+    } else {
+        Butterfly<4, DIR>::run(a);
+    }
+}
+template <int DIR, int K1>
+__device__ __forceinline__ void bfly8_l2(const float2 (&a0)[4], const float2 (&a1)[4], float2 &lo, float2 &hi) {
+    constexpr float sg = DIR > 0 ? 1.f : -1.f;
+    const float h = 0.70710678118654752440f;
+    if constexpr (K1 == 0) {
+        lo = cadd(a0[0], a1[0]);
+        hi = csub(a0[0], a1[0]);
+    } else if constexpr (K1 == 1) {
+        bf2w(a0[1], a1[1], h, sg * h, lo, hi);
+    } else if constexpr (K1 == 2) {
+        const float2 j2 = rot90<DIR>(a1[2]);
+        lo = cadd(a0[2], j2);
+        hi = csub(a0[2], j2);
+    } else {
+        bf2w(a0[3], a1[3], -h, sg * h, lo, hi);
+    }
+}
+
 // v <- DFT8(tw .* v) (TW: tw[1 .. 7] on the inputs) or DFT8(v): 72 instructions against 28 + 56, 52 against 56
 template <int DIR, bool TW>
 __device__ __forceinline__ void bfly8_fma(float2 *v, const float2 *tw) {
@@ -115,26 +145,13 @@ __device__ __forceinline__ void bfly8_fma(float2 *v, const float2 *tw) {
     Butterfly<8, DIR>::run(v);
     return;
 #endif
-    constexpr float sg = DIR > 0 ? 1.f : -1.f;
-    const float h = 0.70710678118654752440f;
-    float2 a0[4] = {v[0], v[2], v[4], v[6]};
-    float2 a1[4] = {v[1], v[3], v[5], v[7]};
-    if constexpr (TW) {
-        radix4_tw<DIR>(a0, tw[2], tw[4], tw[6]);
-        a1[0] = cmul(a1[0], tw[1]);
-        radix4_tw<DIR>(a1, tw[3], tw[5], tw[7]);
-    } else {
-        Butterfly<4, DIR>::run(a0);
-        Butterfly<4, DIR>::run(a1);
-    }
-    // v[k1], v[k1 + 4] = a0[k1] +- W8^k1 a1[k1]
-    v[0] = cadd(a0[0], a1[0]);
-    v[4] = csub(a0[0], a1[0]);
-    bf2w(a0[1], a1[1], h, sg * h, v[1], v[5]);
-    const float2 j2 = rot90<DIR>(a1[2]);
-    v[2] = cadd(a0[2], j2);
-    v[6] = csub(a0[2], j2);
-    bf2w(a0[3], a1[3], -h, sg * h, v[3], v[7]);
+    float2 a0[4], a1[4];
+    bfly8_l1<DIR, TW>(v, tw, 0, a0);
+    bfly8_l1<DIR, TW>(v, tw, 1, a1);
+    bfly8_l2<DIR, 0>(a0, a1, v[0], v[4]);
+    bfly8_l2<DIR, 1>(a0, a1, v[1], v[5]);
+    bfly8_l2<DIR, 2>(a0, a1, v[2], v[6]);
+    bfly8_l2<DIR, 3>(a0, a1, v[3], v[7]);
 }
 
 }  // namespace bds
