@@ -616,15 +616,20 @@ static void launch_rows_f(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const 
         if (ctx->tune.wrows != 0) {  // wave-private row pass (bds_acq_wrows.h): per-lane twiddle constants, 4 barriers per cell
             RowsFArgs B = A;
             B.tw = pl.d_wrtab;
+            const bool pk = ctx->tune.pk != 0;  // packed-fp32 butterflies (bds_fft_pk.h)
+            auto go = [&](auto kern) {
+                want_lds(ctx, kern, kWRowsLdsBytes);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kWRowsLdsBytes, sr, B);
+            };
             if constexpr (NC == 2) {
                 if (ilv) {
-                    want_lds(ctx, k_rows_wave_f<NC, true>, kWRowsLdsBytes);
-                    hipLaunchKernelGGL((k_rows_wave_f<NC, true>), dim3(grid), dim3(256), kWRowsLdsBytes, sr, B);
+                    if (pk) go(k_rows_wave_f<NC, true, true>);
+                    else go(k_rows_wave_f<NC, true, false>);
                     return;
                 }
             }
-            want_lds(ctx, k_rows_wave_f<NC, false>, kWRowsLdsBytes);
-            hipLaunchKernelGGL((k_rows_wave_f<NC, false>), dim3(grid), dim3(256), kWRowsLdsBytes, sr, B);
+            if (pk) go(k_rows_wave_f<NC, false, true>);
+            else go(k_rows_wave_f<NC, false, false>);
             return;
         }
     }

@@ -25,7 +25,7 @@
 #pragma once
 
 #include "bds_acq_f32.h"
-#include "bds_fft_fma.h"
+#include "bds_fft_pk.h"
 
 namespace bds {
 
@@ -38,8 +38,10 @@ constexpr int kWRowsRegion = 1024;  // elements of a wave's region (4 q' x 256)
 constexpr int kWRowsXS = 19;        // elements between consecutive e'' of the exchange buffer (38 dwords: conflict-free both ways; 17 costs 7 %)
 constexpr size_t kWRowsLdsBytes = sizeof(float2) * (4 * kWRowsRegion + 256 * kWRowsXS);
 
-template <int NCOMP, bool ILV>
+// PK: the butterflies and twiddle products on packed fp32 pairs (bds_fft_pk.h: half the vector issue slots for the same pipe time)
+template <int NCOMP, bool ILV, bool PK>
 __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
+    using C = typename std::conditional<PK, v2f, float2>::type;
     using ST = __half2;  // fp16 storage only: with fp32 storage the 32-byte load pieces cost more than the stages save (5.2 vs 3.1 ms)
     constexpr int S = 4096, XS = kWRowsXS;
     // both components of an element side by side in the inter-pass buffer ([cell][element][component]): the column pass fetches
@@ -59,16 +61,20 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     // per-lane stage twiddles of phase 1b (plan constants); those of phase 2 are completed per row below
-    float2 twB[16];
+    C twB[16];
 #pragma unroll
-    for (int u = 1; u < 16; ++u) twB[u] = A.tw[15 * 256 + (u - 1) * 64 + lane];
+    for (int u = 1; u < 16; ++u) {
+        const float2 t = A.tw[15 * 256 + (u - 1) * 64 + lane];
+        cx_set(twB[u], t.x, t.y);
+    }
     const int ql = lane & 3, bl = lane >> 2;  // phase 1a: (ql, bl); phase 1b: (ql, u = bl)
     const int qp = 4 * wave + ql;             // this lane's q' in phase 1
     const int xoff = 16 * bl + qp;            // its inputs: xoff + 256 bh
-    float2 *const wr1 = ldsf + wave * kWRowsRegion + lane;                     // + 64 u
-    const float2 *const rd1 = ldsf + wave * kWRowsRegion + 64 * bl + ql;       // + 4 ((j + u) & 15)
-    float2 *const wrx = ldsf + 4 * kWRowsRegion + XS * bl + qp;                // + 16 XS v
-    const float2 *const rd2 = ldsf + 4 * kWRowsRegion + XS * tid;              // + q'
+    C *const ldsc = reinterpret_cast<C *>(ldsf);
+    C *const wr1 = ldsc + wave * kWRowsRegion + lane;                     // + 64 u
+    const C *const rd1 = ldsc + wave * kWRowsRegion + 64 * bl + ql;       // + 4 ((j + u) & 15)
+    C *const wrx = ldsc + 4 * kWRowsRegion + XS * bl + qp;                // + 16 XS v
+    const C *const rd2 = ldsc + 4 * kWRowsRegion + XS * tid;              // + q'
 
     for (int vb = (int)blockIdx.x; vb < A.nvb; vb += (int)gridDim.x) {
         const int xcd = vb & 7, m = vb >> 3;
@@ -92,16 +98,19 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         // and a workgroup-uniform part s_b[p'] = W_L^(256 k1 p').  The transform is linear: wi goes into the phase-2 INPUT
         // twiddles w4096^(q' tid) (once per row), s_b[] into scalar registers -- the 32 VGPRs a per-thread table of all 16
         // products took (round 3) hold the first component's packed outputs instead (interleaved stores).
-        float2 twC[16];
+        C twC[16];
         {
             float2 wi = A.twl.get<+1>((uint32_t)k1 * (uint32_t)tid);
             wi.x *= A.out_scale;
             wi.y *= A.out_scale;
             wi = cmul(wi, A.tw[15 * 256 + 15 * 64 + (((tid & 15) * (tid >> 4)) & 15)]);
             wi = cmul(wi, A.tw[15 * 256 + 15 * 64 + 16 + (tid & 15)]);
-            twC[0] = wi;
+            cx_set(twC[0], wi.x, wi.y);
 #pragma unroll
-            for (int q = 1; q < 16; ++q) twC[q] = cmul(wi, A.tw[(q - 1) * 256 + tid]);
+            for (int q = 1; q < 16; ++q) {
+                const float2 t = cmul(wi, A.tw[(q - 1) * 256 + tid]);
+                cx_set(twC[q], t.x, t.y);
+            }
         }
         __syncthreads();  // s_b
         float sbx[16], sby[16];
@@ -131,17 +140,19 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
                 // group is computed, reads are issued in the order the layer-1 groups need them -- instead of 16 writes and 16
                 // reads back to back: a burst from all four waves queues on the LDS store path at ~40 cycles per write against
                 // ~20 spread out, tools/phases.py.)
-                float2 y[16], a[4][4], o[4];
+                C y[16], a[4][4], o[4];
 #pragma unroll
-                for (int q = 0; q < 16; ++q)  // ((xi, xr) is re-formed per component: one v_alignbit against 16 registers held across both)
-                    y[q] = cmul_h(xn[q], __builtin_amdgcn_alignbit(xn[q], xn[q], 16), cv[comp][q]);
+                for (int q = 0; q < 16; ++q) {  // ((xi, xr) is re-formed per component: one v_alignbit against 16 registers held across both)
+                    const float2 t = cmul_h(xn[q], __builtin_amdgcn_alignbit(xn[q], xn[q], 16), cv[comp][q]);
+                    cx_set(y[q], t.x, t.y);
+                }
                 // the last component's products are the last readers of xn: the next cell's row is fetched into the same
                 // registers while the transform and the stores run
                 if (comp == NCOMP - 1 && g + 1 < g1) fetch_x(g + 1);
 #pragma unroll
-                for (int n2 = 0; n2 < 4; ++n2) bfly16_l1<+1, false>(y, nullptr, n2, a[n2]);
+                for (int n2 = 0; n2 < 4; ++n2) cx_bfly16_l1<false>(y, (const C *)nullptr, n2, a[n2]);
 #define BDS_WR_L2(K1, DST, STEP)                    \
-    bfly16_l2<+1, K1>(a, o);                        \
+    cx_bfly16_l2<K1>(a, o);                         \
     __builtin_amdgcn_sched_barrier(0);              \
     (DST)[(STEP) * (K1)] = o[0];                    \
     (DST)[(STEP) * ((K1) + 4)] = o[1];              \
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
                 __builtin_amdgcn_sched_barrier(0);
                 PH_MARK(8 * comp + 0);  // products, phase 1a, exchange issued
 #pragma unroll
-                for (int n2 = 0; n2 < 4; ++n2) bfly16_l1<+1, true>(y, twB, n2, a[n2]);  // twiddle w256^(bl u) on the inputs (up to the factor w256^(u u))
+                for (int n2 = 0; n2 < 4; ++n2) cx_bfly16_l1<true>(y, twB, n2, a[n2]);  // twiddle w256^(bl u) on the inputs (up to the factor w256^(u u))
                 PH_MARK(8 * comp + 2);  // phase 1b layer 1 (waits for its inputs group by group)
                 if (comp > 0 || g > g0) BDS_SYNC();  // every thread is through with the exchange buffer (previous transform)
                 PH_MARK(8 * comp + 3);  // barrier
@@ -184,11 +195,9 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
                 __builtin_amdgcn_sched_barrier(0);
                 PH_MARK(8 * comp + 6);  // exchange reads issued
 #pragma unroll
-                for (int n2 = 0; n2 < 4; ++n2) bfly16_l1<+1, true, true>(y, twC, n2, a[n2]);
-                auto emit = [&](int p, float2 yv) {
-                    float2 t;
-                    t.x = fmaf(-yv.y, sby[p], yv.x * sbx[p]);
-                    t.y = fmaf(yv.y, sbx[p], yv.x * sby[p]);
+                for (int n2 = 0; n2 < 4; ++n2) cx_bfly16_l1<true, true>(y, twC, n2, a[n2]);
+                auto emit = [&](int p, C yv) {
+                    const float2 t = cx_f2(cx_mul_uniform(yv, sbx[p], sby[p]));
                     const uint32_t h = f2_to_h2(t);
 #ifdef BDS_EXP_ROWS_NOSTORE
                     if (t.x == 1.2345f)
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
                     }
                 };
 #define BDS_ST_L2(K1)                                     \
-    bfly16_l2<+1, K1>(a, o);                              \
+    cx_bfly16_l2<K1>(a, o);                               \
     emit((K1), o[0]), emit((K1) + 4, o[1]), emit((K1) + 8, o[2]), emit((K1) + 12, o[3])
                 BDS_ST_L2(0);
                 BDS_ST_L2(1);

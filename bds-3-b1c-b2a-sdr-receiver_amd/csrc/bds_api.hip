@@ -55,6 +55,7 @@ Tuning tuning_from_env() {
     t.wcols = geti("BDS_ACQ_WCOLS", -1);
     t.wrows = geti("BDS_ACQ_WROWS", -1);
     t.ilv = geti("BDS_ACQ_ILV", 1);
+    t.pk = geti("BDS_ACQ_PK", 1);
     t.clockprobe = geti("BDS_ACQ_CLOCKPROBE", 0);
     t.wcols_qchunk = std::max(1, geti("BDS_ACQ_WCOLS_QCHUNK", 4));
     t.verbose = has("BDS_VERBOSE");

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "bds_fft_fma.h"
+#include "bds_fft_pk.h"
 using namespace bds;
 
 __global__ void k(float2 *io, const float2 *tw, int mode) {
@@ -24,7 +25,18 @@ __global__ void k(float2 *io, const float2 *tw, int mode) {
     else if (mode == 6) bfly8_fma<+1, false>(v, nullptr);
     else if (mode == 7) bfly8_fma<+1, true>(v, t);
     else if (mode == 8) bfly8_fma<-1, false>(v, nullptr);
-    else bfly8_fma<-1, true>(v, t);
+    else if (mode == 9) bfly8_fma<-1, true>(v, t);
+    else if (mode == 10) bfly16_fma<+1, true, true>(v, t);
+    else {  // the packed-fp32 versions (bds_fft_pk.h), inverse direction
+        v2f pv[16], pt[16];
+        for (int i = 0; i < 16; ++i) pv[i] = to_v2f(v[i]), pt[i] = to_v2f(t[i]);
+        if (mode == 11) pk_bfly16<false>(pv, nullptr);
+        else if (mode == 12) pk_bfly16<true>(pv, pt);
+        else if (mode == 13) pk_bfly16<true, true>(pv, pt);
+        else if (mode == 14) pk_bfly8<false>(pv, nullptr);
+        else pk_bfly8<true>(pv, pt);
+        for (int i = 0; i < 16; ++i) v[i] = to_f2(pv[i]);
+    }
     for (int i = 0; i < 16; ++i) io[threadIdx.x * 16 + i] = v[i];
 }
 
@@ -36,29 +48,31 @@ int main() {
     for (auto &e : x) e = make_float2(nd(rng), nd(rng));
     for (int i = 0; i < NT * 16; ++i) {
         const double a = 6.283185307179586 * (rng() % 4096) / 4096.0;
-        tw[i] = (i % 16) ? make_float2((float)cos(a), (float)sin(a)) : make_float2(1.f, 0.f);
+        tw[i] = make_float2((float)cos(a), (float)sin(a));  // (entry 0 is used by the tw0 variants only)
     }
     float2 *d_x, *d_t;
     (void)hipMalloc(&d_x, sizeof(float2) * NT * 16);
     (void)hipMalloc(&d_t, sizeof(float2) * NT * 16);
     (void)hipMemcpy(d_t, tw.data(), sizeof(float2) * NT * 16, hipMemcpyHostToDevice);
-    const char *names[10] = {"Butterfly<16,+1>", "bfly16_fma<+1,false>", "bfly16_fma<+1,true>", "Butterfly<16,-1>", "bfly16_fma<-1,false>", "bfly16_fma<-1,true>",
-                             "bfly8_fma<+1,false>", "bfly8_fma<+1,true>", "bfly8_fma<-1,false>", "bfly8_fma<-1,true>"};
+    const char *names[16] = {"Butterfly<16,+1>", "bfly16_fma<+1,false>", "bfly16_fma<+1,true>", "Butterfly<16,-1>", "bfly16_fma<-1,false>", "bfly16_fma<-1,true>",
+                             "bfly8_fma<+1,false>", "bfly8_fma<+1,true>", "bfly8_fma<-1,false>", "bfly8_fma<-1,true>", "bfly16_fma<+1,true,tw0>",
+                             "pk_bfly16<false>", "pk_bfly16<true>", "pk_bfly16<true,tw0>", "pk_bfly8<false>", "pk_bfly8<true>"};
     int bad = 0;
-    for (int mode = 0; mode < 10; ++mode) {
+    for (int mode = 0; mode < 16; ++mode) {
         (void)hipMemcpy(d_x, x.data(), sizeof(float2) * NT * 16, hipMemcpyHostToDevice);
         hipLaunchKernelGGL(k, dim3(1), dim3(NT), 0, 0, d_x, d_t, mode);
         (void)hipMemcpy(y.data(), d_x, sizeof(float2) * NT * 16, hipMemcpyDeviceToHost);
-        const int R = mode < 6 ? 16 : 8;
-        const int dir = mode < 3 || mode == 6 || mode == 7 ? +1 : -1;
-        const bool twd = mode == 2 || mode == 5 || mode == 7 || mode == 9;
+        const int R = (mode < 6 || (mode >= 10 && mode <= 13)) ? 16 : 8;
+        const int dir = mode < 3 || mode == 6 || mode == 7 || mode >= 10 ? +1 : -1;
+        const bool twd = mode == 2 || mode == 5 || mode == 7 || mode == 9 || mode == 10 || mode == 12 || mode == 13 || mode == 15;
+        const bool tw0 = mode == 10 || mode == 13;
         double worst = 0, big = 0;
         for (int t = 0; t < NT; ++t)
             for (int kk = 0; kk < R; ++kk) {
                 std::complex<double> acc = 0;
                 for (int n = 0; n < R; ++n) {
                     std::complex<double> v(x[t * 16 + n].x, x[t * 16 + n].y);
-                    if (twd) v *= std::complex<double>(tw[t * 16 + n].x, tw[t * 16 + n].y);
+                    if (twd && (n > 0 || tw0)) v *= std::complex<double>(tw[t * 16 + n].x, tw[t * 16 + n].y);
                     acc += v * std::polar(1.0, dir * 6.283185307179586 * n * kk / (double)R);
                 }
                 worst = std::max(worst, std::abs(acc - std::complex<double>(y[t * 16 + kk].x, y[t * 16 + kk].y)));
