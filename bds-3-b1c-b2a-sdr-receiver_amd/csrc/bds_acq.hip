@@ -652,15 +652,15 @@ static void launch_cols_ft(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G
 }
 // wave-private column pass: one tile per workgroup, workgroups started by the hardware in list order (see the kernel's
 // note on item order)
-template <int S, int NC, bool MASKED, class ST, int NV, bool ILV = false>
+template <int S, int NC, bool MASKED, class ST, int NV, bool ILV = false, bool PK = false>
 static void launch_cols_wm(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, const WColsArgs &A) {
     using W = WCols<S>;
-    want_lds(ctx, k_cols_wave_f<S, NC, MASKED, ST, NV, ILV>, W::kLdsBytes);
+    want_lds(ctx, k_cols_wave_f<S, NC, MASKED, ST, NV, ILV, PK>, W::kLdsBytes);
     WColsArgs B = A;
     const int quads = A.ntiles / 32;  // per XCD and cell
     B.qchunk = std::max(1, std::min(ctx->tune.wcols_qchunk, quads));
     while (quads % B.qchunk) --B.qchunk;
-    hipLaunchKernelGGL((k_cols_wave_f<S, NC, MASKED, ST, NV, ILV>), dim3(A.n_items), dim3(W::NT), W::kLdsBytes, sc, B);
+    hipLaunchKernelGGL((k_cols_wave_f<S, NC, MASKED, ST, NV, ILV, PK>), dim3(A.n_items), dim3(W::NT), W::kLdsBytes, sc, B);
 }
 template <int S, int NC, class ST>
 static void launch_cols_w(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G, const void *Bw, float w0, float w1, int lo1,
@@ -672,10 +672,14 @@ static void launch_cols_w(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, int G,
     const bool masked = cl.rng || !(lo1 == 0 && lo2 > hi2);  // anything but "one range starting at lag 0"
     if constexpr (S == 768 && NC == 2 && std::is_same<ST, __half2>::value) {  // (the plan with 4096-point rows: cfg3)
         if (ilv) {  // k_rows_wave_f<2, true> laid the buffer out [cell][element][component]
-            if (hi1 / pl.L2 < 6 * 8 * WCols<S>::R1)
-                launch_cols_wm<S, NC, false, ST, 6, true>(ctx, sc, pl, A);
-            else
-                launch_cols_wm<S, NC, false, ST, 8, true>(ctx, sc, pl, A);
+            const bool pk = ctx->tune.pk != 0 && ctx->tune.pk != 2;  // packed-fp32 butterflies (BDS_ACQ_PK=2: row pass only)
+            if (hi1 / pl.L2 < 6 * 8 * WCols<S>::R1) {
+                if (pk) launch_cols_wm<S, NC, false, ST, 6, true, true>(ctx, sc, pl, A);
+                else launch_cols_wm<S, NC, false, ST, 6, true>(ctx, sc, pl, A);
+            } else {
+                if (pk) launch_cols_wm<S, NC, false, ST, 8, true, true>(ctx, sc, pl, A);
+                else launch_cols_wm<S, NC, false, ST, 8, true>(ctx, sc, pl, A);
+            }
             return;
         }
     }

@@ -32,7 +32,7 @@
 #pragma once
 
 #include "bds_acq_f32.h"
-#include "bds_fft_fma.h"
+#include "bds_fft_pk.h"
 
 // Timing experiments (tools/exp_wparts.sh; results are INVALID with any of these defined):
 //   BDS_EXP_WC_NOTAIL  nothing after the wave maximum (no bounds, no list, no atomics)
@@ -132,8 +132,10 @@ __host__ __device__ constexpr int wcols_table_entries() {
 // ILV: the inter-pass buffer holds both components of an element side by side ([cell][element][component], written so by
 // k_rows_wave_f<2, true>): one 16-byte load per lane and tile row fetches both (64-byte pieces per tile row instead of 32-byte
 // ones, half the load instructions)
-template <int S, int NCOMP, bool MASKED, class ST, int NV, bool ILV = false>
+// PK: butterflies and twiddle products on packed fp32 pairs (bds_fft_pk.h)
+template <int S, int NCOMP, bool MASKED, class ST, int NV, bool ILV = false, bool PK = false>
 __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WColsArgs A) {
+    using C = typename std::conditional<PK, v2f, float2>::type;
     static_assert(NV >= 1 && NV <= 8, "outputs of the last radix-8 stage");
     static_assert(!ILV || (NCOMP == 2 && std::is_same<ST, __half2>::value), "interleaved components: two, fp16 storage");
     using W = WCols<S>;
@@ -216,28 +218,32 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     // the sieve's tolerance) -- and the rest (component 1's rows unless interleaved, the phase-B constants, the running bounds)
     // goes out behind phase A's arithmetic, where its latency is covered by phase B of component 0.
     Raw pre0[R1], pre1[(NCOMP > 1 && !ILV) ? R1 : 1];
-    float2 twA[R1];  // w_S^(b p), inverse direction
-    twA[1] = A.wtab[tid];
+    C twA[R1];  // w_S^(b p), inverse direction
+    {
+        const float2 t = A.wtab[tid];
+        cx_set(twA[1], t.x, t.y);
+    }
     fetch(pre0, 0);
     PH_MARK(17);  // rows of component 0 requested
     const int cell = A.cell0 + g;
     float *const lbp = A.lb + cell / A.lb_div;
     {
-        const float2 w = twA[1];
+        const C w = twA[1];
 #pragma unroll
-        for (int p = 2; p < R1; ++p) twA[p] = (p & 1) ? cmul(twA[p - 1], w) : cmul(twA[p / 2], twA[p / 2]);
+        for (int p = 2; p < R1; ++p) twA[p] = (p & 1) ? cx_mul(twA[p - 1], w) : cx_mul(twA[p / 2], twA[p / 2]);
     }
     PH_MARK(19);  // phase-A constants formed
-    float2 *const wrA = ldsf + cp * RS + b;  // + m MS
+    C *const ldsc = reinterpret_cast<C *>(ldsf);
+    C *const wrA = ldsc + cp * RS + b;  // + m MS
     // phase B: stage 2 as lane (ml, bl), stage 3 as lane (ml, u) with u = bl
     const int ml = lane & 7, bl = lane >> 3;
     // stage-2 twiddle w_64^(bl u), applied by stage 3 to its INPUTS (bds_fft_fma.h: folded into the first butterfly layer): input
     // j of lane (ml, u) is bl = (j + u) & 7; the common unit factor w_64^(u u) is left out (invisible in |X|)
-    float2 twB[8];
-    float2 *const rw2 = ldsf + wave * RS + ml * MS + bl;  // + s 8 MS + 8 bh (read), + 8 u (write back)
-    const float2 *rd3[8];                                 // row u from column u on: + s 8 MS
+    C twB[8];
+    C *const rw2 = ldsc + wave * RS + ml * MS + bl;  // + s 8 MS + 8 bh (read), + 8 u (write back)
+    const C *rd3[8];                                 // row u from column u on: + s 8 MS
 #pragma unroll
-    for (int j = 0; j < 8; ++j) rd3[j] = ldsf + wave * RS + ml * MS + 8 * bl + ((j + bl) & 7);
+    for (int j = 0; j < 8; ++j) rd3[j] = ldsc + wave * RS + ml * MS + 8 * bl + ((j + bl) & 7);
     // lag of output (s, v) of this lane: row e = p + R1 u + 8 R1 v of column 2 wave + c (m = ml + 8 s = c R1 + p), i.e.
     // lbase[s] + v vstep                                                                            (L < 2^31)
     int lbase[SL];
@@ -254,25 +260,26 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     }
 
     // first stage of both columns of the pair, twiddled
-    auto phaseA = [&](const Raw(&pre)[R1], float2(&z)[2][R1], int comp) {
+    auto phaseA = [&](const Raw(&pre)[R1], C(&z)[2][R1], int comp) {
+        auto set = [](C &d, float2 t) { cx_set(d, t.x, t.y); };
 #pragma unroll
         for (int q = 0; q < R1; ++q) {
             if constexpr (ILV) {
-                z[0][q] = h2_to_f2(comp == 0 ? pre[q].x : pre[q].y);
-                z[1][q] = h2_to_f2(comp == 0 ? pre[q].z : pre[q].w);
+                set(z[0][q], h2_to_f2(comp == 0 ? pre[q].x : pre[q].y));
+                set(z[1][q], h2_to_f2(comp == 0 ? pre[q].z : pre[q].w));
             } else if constexpr (HS) {
-                z[0][q] = h2_to_f2(pre[q].x);
-                z[1][q] = h2_to_f2(pre[q].y);
+                set(z[0][q], h2_to_f2(pre[q].x));
+                set(z[1][q], h2_to_f2(pre[q].y));
             } else {
-                z[0][q] = make_float2(pre[q].x, pre[q].y);
-                z[1][q] = make_float2(pre[q].z, pre[q].w);
+                cx_set(z[0][q], pre[q].x, pre[q].y);
+                cx_set(z[1][q], pre[q].z, pre[q].w);
             }
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            Butterfly<R1, +1>::run(z[c]);
+            cx_bfly<R1>(z[c]);
 #pragma unroll
-            for (int p = 1; p < R1; ++p) z[c][p] = cmul(z[c][p], twA[p]);
+            for (int p = 1; p < R1; ++p) z[c][p] = cx_mul(z[c][p], twA[p]);
         }
     };
     // opaque to the scheduler: the raw rows are "produced" where this stands, nothing consuming them moves above it
@@ -301,14 +308,17 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
 #pragma unroll
     for (int comp = 0; comp < NCOMP; ++comp) {
         {
-            float2 z[2][R1];
+            C z[2][R1];
             if (comp == 0) {
                 phaseA(pre0, z, 0);
                 // the deferred requests (see above): answered while phase B of this component runs
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NCOMP > 1 && !ILV) fetch(pre1, 1);
 #pragma unroll
-                for (int j = 1; j < 8; ++j) twB[j] = A.wtab[(R1 - 1) * W::NT + (j - 1) * 64 + lane];
+                for (int j = 1; j < 8; ++j) {
+                    const float2 t = A.wtab[(R1 - 1) * W::NT + (j - 1) * 64 + lane];
+                    cx_set(twB[j], t.x, t.y);
+                }
                 // the cell's maximum so far and the PRN's running bound (L2 / fabric latency), used after the transforms;
                 // stale values are lower values, which only costs a redundant visit of the rare path below
                 lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -344,21 +354,21 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         // The units are software-pipelined by hand (st2(s + 1) sits between the write and the read-back of slot s)
         // and fenced, so that the scheduler neither serialises the LDS latency nor hoists every read to the top.
         auto st2 = [&](int s) {
-            float2 y[8];
+            C y[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) y[q] = rw2[s * 8 * MS + 8 * q];
             wave_sync();
-            bfly8_fma<+1, false>(y, nullptr);
+            cx_bfly8<false>(y, (const C *)nullptr);
 #pragma unroll
             for (int u = 0; u < 8; ++u) rw2[s * 8 * MS + 8 * u] = y[u];
             wave_sync();
         };
         auto st3 = [&](int s) {
-            float2 y[8];
+            C y[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = rd3[j][s * 8 * MS];
             wave_sync();
-            bfly8_fma<+1, true>(y, twB);
+            cx_bfly8<true>(y, twB);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 // Only |y|^2 is formed here; the square roots, the lag masks and the exact maximum belong to the (rare)
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
                 // test per v against 174 without.  Output v covers rows 8 R1 v .. 8 R1 (v + 1) - 1; the host instantiates
                 // NV = 6 when no searched lag lies beyond row 48 R1 -- the padded transform is ~1.6 N long -- and the
                 // unused outputs of the last butterfly fall away at compile time.)
-                const float2 t = y[v];
+                const float2 t = cx_f2(y[v]);
                 const float q2 = t.x * t.x + t.y * t.y;
                 sq[comp][s][v] = q2;
                 if (comp == NCOMP - 1) bmax = fmaxf(bmax, NCOMP > 1 ? sq[0][s][v] + q2 : q2);

@@ -186,6 +186,48 @@ __device__ __forceinline__ void pk_bfly8(v2f *v, const v2f *tw) {
     pk_bfly8_l2<3>(a0, a1, v[3], v[7]);
 }
 
+// 3-point inverse transform: X0 = a + t, X1,2 = (a - t / 2) +- j s d  with t = b + c, d = b - c, s = sin(2 pi / 3)     (6 instead of 14)
+__device__ __forceinline__ void pk_radix3(v2f &x0, v2f &x1, v2f &x2) {
+    const v2f ks = {0.86602540378443864676f, 0.86602540378443864676f};
+    const v2f t = x1 + x2, d = x1 - x2;
+    v2f m;
+    asm("v_pk_fma_f32 %0, %1, -0.5, %2 op_sel_hi:[1,0,1]" : "=v"(m) : "v"(t), "v"(x0));
+    x0 = x0 + t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(x1) : "v"(d), "s"(ks), "v"(m));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(x2) : "v"(d), "s"(ks), "v"(m));
+}
+// 12-point inverse transform (n = 3 a + b, k = c + 4 d, as Butterfly<12, +1> of bds_acq_wcols.h)
+__device__ __forceinline__ void pk_bfly12(v2f *v) {
+    const float h = 0.5f, s = 0.86602540378443864676f;
+    v2f t[3][4];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[b][0] = v[b], t[b][1] = v[b + 3], t[b][2] = v[b + 6], t[b][3] = v[b + 9];
+        pk_radix4(t[b]);
+    }
+    t[1][1] = pk_cmul_k(t[1][1], (v2f){s, h});   // W12^1
+    t[1][2] = pk_cmul_k(t[1][2], (v2f){h, s});   // W12^2
+    t[2][1] = pk_cmul_k(t[2][1], (v2f){h, s});   // W12^2
+    t[2][2] = pk_cmul_k(t[2][2], (v2f){-h, s});  // W12^4
+    // W12^3 = j on t[1][3], W12^6 = -1 on t[2][3]: folded into the 3-point transform of c = 3 below
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pk_radix3(t[0][c], t[1][c], t[2][c]);
+        v[c] = t[0][c], v[c + 4] = t[1][c], v[c + 8] = t[2][c];
+    }
+    {   // c = 3: inputs a = t0, b = j t1, c = -t2:  t = j t1 - t2, d = j t1 + t2
+        const v2f ks = {s, s};
+        const v2f a = t[0][3];
+        v2f tt, d, m;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,1] neg_hi:[0,1]" : "=v"(tt) : "v"(t[1][3]), "v"(t[2][3]));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(d) : "v"(t[1][3]), "v"(t[2][3]));
+        asm("v_pk_fma_f32 %0, %1, -0.5, %2 op_sel_hi:[1,0,1]" : "=v"(m) : "v"(tt), "v"(a));
+        v[3] = a + tt;
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(v[7]) : "v"(d), "s"(ks), "v"(m));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(v[11]) : "v"(d), "s"(ks), "v"(m));
+    }
+}
+
 // a w with w in a scalar register pair (a workgroup-uniform factor)
 __device__ __forceinline__ v2f pk_cmul_s(v2f a, v2f w) { return pk_cmul_k(a, w); }
 
@@ -201,6 +243,34 @@ __device__ __forceinline__ float2 cx_mul_uniform(float2 a, float sx, float sy) {
     return make_float2(fmaf(-a.y, sy, a.x * sx), fmaf(a.y, sx, a.x * sy));
 }
 __device__ __forceinline__ v2f cx_mul_uniform(v2f a, float sx, float sy) { return pk_cmul_s(a, (v2f){sx, sy}); }
+// untwiddled R-point inverse transform (first stage of the column pass)
+template <int R>
+__device__ __forceinline__ void cx_bfly(float2 *v) {
+    Butterfly<R, +1>::run(v);
+}
+template <int R>
+__device__ __forceinline__ void cx_bfly(v2f *v) {
+    static_assert(R == 4 || R == 8 || R == 12 || R == 16, "radix of the column pass's first stage");
+    if constexpr (R == 4) {
+        v2f a[4] = {v[0], v[1], v[2], v[3]};
+        pk_radix4(a);
+        v[0] = a[0], v[1] = a[1], v[2] = a[2], v[3] = a[3];
+    } else if constexpr (R == 8) {
+        pk_bfly8<false>(v, nullptr);
+    } else if constexpr (R == 12) {
+        pk_bfly12(v);
+    } else {
+        pk_bfly16<false>(v, nullptr);
+    }
+}
+template <bool TW>
+__device__ __forceinline__ void cx_bfly8(float2 *v, const float2 *tw) {
+    bfly8_fma<+1, TW>(v, tw);
+}
+template <bool TW>
+__device__ __forceinline__ void cx_bfly8(v2f *v, const v2f *tw) {
+    pk_bfly8<TW>(v, tw);
+}
 template <bool TW, bool TW0 = false>
 __device__ __forceinline__ void cx_bfly16_l1(const float2 *v, const float2 *tw, int n2, float2 (&a)[4]) {
     bfly16_l1<+1, TW, TW0>(v, tw, n2, a);

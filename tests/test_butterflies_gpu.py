@@ -24,6 +24,6 @@ def test_fma_butterflies_against_double_dft(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if "max |err|" in l]
-    assert len(lines) == 16 and r.stdout.strip().endswith("ok"), r.stdout
+    assert len(lines) == 18 and r.stdout.strip().endswith("ok"), r.stdout
     for l in lines:
         assert float(l.split("=")[-1]) < 1e-6, l

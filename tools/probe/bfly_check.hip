@@ -10,7 +10,7 @@
 #include <vector>
 
 #include "bds_fft_fma.h"
-#include "bds_fft_pk.h"
+#include "bds_acq_wcols.h"
 using namespace bds;
 
 __global__ void k(float2 *io, const float2 *tw, int mode) {
@@ -27,6 +27,7 @@ __global__ void k(float2 *io, const float2 *tw, int mode) {
     else if (mode == 8) bfly8_fma<-1, false>(v, nullptr);
     else if (mode == 9) bfly8_fma<-1, true>(v, t);
     else if (mode == 10) bfly16_fma<+1, true, true>(v, t);
+    else if (mode == 17) Butterfly<12, +1>::run(v);
     else {  // the packed-fp32 versions (bds_fft_pk.h), inverse direction
         v2f pv[16], pt[16];
         for (int i = 0; i < 16; ++i) pv[i] = to_v2f(v[i]), pt[i] = to_v2f(t[i]);
@@ -34,7 +35,8 @@ __global__ void k(float2 *io, const float2 *tw, int mode) {
         else if (mode == 12) pk_bfly16<true>(pv, pt);
         else if (mode == 13) pk_bfly16<true, true>(pv, pt);
         else if (mode == 14) pk_bfly8<false>(pv, nullptr);
-        else pk_bfly8<true>(pv, pt);
+        else if (mode == 15) pk_bfly8<true>(pv, pt);
+        else pk_bfly12(pv);
         for (int i = 0; i < 16; ++i) v[i] = to_f2(pv[i]);
     }
     for (int i = 0; i < 16; ++i) io[threadIdx.x * 16 + i] = v[i];
@@ -54,15 +56,15 @@ int main() {
     (void)hipMalloc(&d_x, sizeof(float2) * NT * 16);
     (void)hipMalloc(&d_t, sizeof(float2) * NT * 16);
     (void)hipMemcpy(d_t, tw.data(), sizeof(float2) * NT * 16, hipMemcpyHostToDevice);
-    const char *names[16] = {"Butterfly<16,+1>", "bfly16_fma<+1,false>", "bfly16_fma<+1,true>", "Butterfly<16,-1>", "bfly16_fma<-1,false>", "bfly16_fma<-1,true>",
+    const char *names[18] = {"Butterfly<16,+1>", "bfly16_fma<+1,false>", "bfly16_fma<+1,true>", "Butterfly<16,-1>", "bfly16_fma<-1,false>", "bfly16_fma<-1,true>",
                              "bfly8_fma<+1,false>", "bfly8_fma<+1,true>", "bfly8_fma<-1,false>", "bfly8_fma<-1,true>", "bfly16_fma<+1,true,tw0>",
-                             "pk_bfly16<false>", "pk_bfly16<true>", "pk_bfly16<true,tw0>", "pk_bfly8<false>", "pk_bfly8<true>"};
+                             "pk_bfly16<false>", "pk_bfly16<true>", "pk_bfly16<true,tw0>", "pk_bfly8<false>", "pk_bfly8<true>", "pk_bfly12", "Butterfly<12,+1>"};
     int bad = 0;
-    for (int mode = 0; mode < 16; ++mode) {
+    for (int mode = 0; mode < 18; ++mode) {
         (void)hipMemcpy(d_x, x.data(), sizeof(float2) * NT * 16, hipMemcpyHostToDevice);
         hipLaunchKernelGGL(k, dim3(1), dim3(NT), 0, 0, d_x, d_t, mode);
         (void)hipMemcpy(y.data(), d_x, sizeof(float2) * NT * 16, hipMemcpyDeviceToHost);
-        const int R = (mode < 6 || (mode >= 10 && mode <= 13)) ? 16 : 8;
+        const int R = mode >= 16 ? 12 : (mode < 6 || (mode >= 10 && mode <= 13)) ? 16 : 8;
         const int dir = mode < 3 || mode == 6 || mode == 7 || mode >= 10 ? +1 : -1;
         const bool twd = mode == 2 || mode == 5 || mode == 7 || mode == 9 || mode == 10 || mode == 12 || mode == 13 || mode == 15;
         const bool tw0 = mode == 10 || mode == 13;

@@ -9,3 +9,4 @@
 #endif
 template __global__ void bds::k_cols_wave_f<WC_S, 2, false, __half2, WC_NV>(bds::WColsArgs);
 template __global__ void bds::k_cols_wave_f<WC_S, 2, false, __half2, WC_NV, true>(bds::WColsArgs);
+template __global__ void bds::k_cols_wave_f<WC_S, 2, false, __half2, WC_NV, true, true>(bds::WColsArgs);
