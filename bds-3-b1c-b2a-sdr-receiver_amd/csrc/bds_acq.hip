@@ -1089,9 +1089,13 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     }
     const Tuning &tune = ctx->tune;
     const bool fsearch = pl.fast && !a.no_fast_search;  // fp32-arithmetic specialised kernels (default)
-    // sieve tolerance: every lag within kDelta of a PRN's maximum is re-evaluated in f64.  fp32 storage errs by
-    // ~1e-7 of the output RMS, fp16 storage by ~3e-4 (tools/sieve_error.py, tools/sieve_error_cfg3.py)
-    const double kDelta = tune.kdelta > 0 ? tune.kdelta : a.half ? 2e-3 : 2e-5;
+    // sieve tolerance: every lag within kDelta of a PRN's maximum is re-evaluated in f64.  fp32 storage errs by ~1e-7 of the
+    // PRN maximum.  fp16 storage: three roundings lie between the exact value and the sieve's (signal spectrum, code spectrum,
+    // inter-pass buffer; 2^-11 relative each).  On noise-like spectra they average out -- 2.5e-4 of the PRN maximum at worst
+    // over 63 x 201 rows -- but a spectrum dominated by ONE line (a CW interferer) carries them coherently: 6.4e-4 / 7.9e-4
+    // measured at J/N = +20 / +40 dB (tools/sieve_stress.py, profiles/r04_sieve_error.txt), bounded by 3 x 2^-11 = 1.46e-3.
+    // kDelta / 2 = 2e-3 lies above that bound and 2.5x above the worst measured case (round 3 used 2e-3: 1.3x).
+    const double kDelta = tune.kdelta > 0 ? tune.kdelta : a.half ? 4e-3 : 2e-5;
     // overflow list of the column pass: lags within kDelta of their tile's maximum (other than the tile's record)
     constexpr int kExtraCap = 1 << 22;
     {
@@ -1309,6 +1313,9 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             fprintf(stderr, "  (sX %g sC %g sB %g)\n", a.sX, a.sC, a.sB);
         }
         if (a.half && ((bad && !tune.no_selfcheck) || tune.test_force_fallback)) return rerun(false, bad ? "non-finite row maximum" : "test hook");
+        // (with fp16 storage the tolerance band is 200x wider than with fp32 storage: a nearly flat surface -- an interferer
+        //  40 dB above the noise -- fills the list; fp32 storage first, the run-time-plan kernels only if that runs over too)
+        if (n_extra > kExtraCap && a.half) return rerun(false, "overflow list of the sieve ran over at the fp16-storage tolerance");
         if (n_extra > kExtraCap && !a.no_fast_search) return rerun(true, "overflow list of the sieve ran over");
     }
     std::vector<Extra> h_extra((size_t)std::min(n_extra, kExtraCap));
@@ -1491,6 +1498,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, st(ctx)));
         BDS_HIP(ctx, hipMemcpyAsync(&n_extra2, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, st(ctx)));
         BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+        if (n_extra2 > kExtraCap && a.half) return rerun(false, "overflow list of the second-peak pass ran over at the fp16-storage tolerance");
         if (n_extra2 > kExtraCap && !a.no_fast_search) return rerun(true, "overflow list of the second-peak pass ran over");
         std::vector<Extra> h_extra2((size_t)std::min(n_extra2, kExtraCap));
         if (!h_extra2.empty()) {

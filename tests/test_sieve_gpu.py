@@ -14,7 +14,7 @@ from helpers import medium_b2a, small_b1c
 
 pytestmark = pytest.mark.gpu
 
-KDELTA = {0: 2e-5, 1: 2e-3}  # bds_acq.hip, per timing()["half_storage"]
+KDELTA = {0: 2e-5, 1: 4e-3}  # bds_acq.hip, per timing()["half_storage"]
 
 
 def _oracle_matrix(s, x, prn):
