@@ -368,7 +368,7 @@ struct AcqState {
     std::map<int, PrnResult> last;
     // (PRN, bin) cells per launch pair; 0 = all Doppler bins of the PRN that fit the work-buffer budget.
     // Measured on the B1C plan (us/cell): 1 -> 41, 4 -> 25, 16 -> 21 without the row-pass cell loop;
-    // with it 16 -> 17.5, 48 -> 16.5, 201 -> 15.9 (tools/exp_gchunk.sh)
+    // with it 16 -> 17.5, 48 -> 16.5, 201 -> 15.9 (tools/exp/exp_gchunk.sh)
     int group_env = 0;
     int group = 16;
     bool half = false;         // spectra + inter-pass buffer stored as fp16 complex (specialised plans only)
@@ -1693,6 +1693,15 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     t.n_prn = P;
     t.n_comp = ncomp;
     t.half_storage = a.half ? 1 : 0;  // 0 fp32; 1 fp16 storage (fp32 arithmetic either way)
+    t.plan_l1 = pl.L1;
+    t.plan_l2 = pl.L2;
+    {
+        const bool wrows_on = fsearch && a.half && pl.L2 == 4096 && tune.wrows != 0;
+        t.rows_kernel = !fsearch ? 0 : wrows_on ? 2 : 1;
+        t.cols_kernel = !fsearch ? 0 : wcols ? 2 : 1;
+        const bool ilv_on = wrows_on && wcols && ncomp == 2 && pl.L1 == 768 && tune.ilv != 0;
+        t.kernel_flags = (ilv_on ? 1 : 0) | (wrows_on && tune.pk != 0 ? 2 : 0);
+    }
     return BDS_OK;
 }
 

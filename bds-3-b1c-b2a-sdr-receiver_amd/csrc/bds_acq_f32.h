@@ -19,7 +19,7 @@
 
 #include "bds_acq_fast.h"
 
-// Timing experiments (tools/exp_parts.sh; results are INVALID with any of these defined):
+// Timing experiments (tools/exp/exp_parts.sh; results are INVALID with any of these defined):
 //   BDS_EXP_NOBARRIER  __syncthreads() of the two search kernels compiled out
 //   BDS_EXP_ROWS_NOSTORE / BDS_EXP_COLS_NOLOAD  no inter-pass buffer traffic
 //   BDS_EXP_ROWS_OCC   launch bound (waves per SIMD) of the row pass

@@ -34,7 +34,7 @@
 #include "bds_acq_f32.h"
 #include "bds_fft_pk.h"
 
-// Timing experiments (tools/exp_wparts.sh; results are INVALID with any of these defined):
+// Timing experiments (tools/exp/exp_wparts.sh; results are INVALID with any of these defined):
 //   BDS_EXP_WC_NOTAIL  nothing after the wave maximum (no bounds, no list, no atomics)
 //   BDS_EXP_WC_NOLOAD  the inter-pass buffer is not read
 //   BDS_EXP_WC_NOBAR   workgroup barriers compiled out

@@ -17,7 +17,7 @@ TRACK_MODE = {"B2A": 0, "NB": 1, "WB": 2}
 CODE_KIND = {"data": 0, "pilot": 1, "data_boc11": 2, "pilot_boc11": 3, "pilot_boc61": 4, "pilot_secondary": 5}
 CODE_LEN = {0: 10230, 1: 10230, 2: 20460, 3: 20460, 4: 122760, 5: 1800}
 
-# BDS_LIB_PATH: load another build of the library (tools/exp_parts.sh timing variants); default = the in-tree build
+# BDS_LIB_PATH: load another build of the library (tools/exp/exp_parts.sh timing variants); default = the in-tree build
 _LIB_PATH = os.environ.get("BDS_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbds_mi355x.so")
 
 
@@ -69,7 +69,9 @@ class Timing(C.Structure):
                 ("refine_ms", C.c_double), ("cell_pair_ms", C.c_double), ("cells_per_pair", C.c_double),
                 ("n_pairs", C.c_int64), ("fft_len", C.c_int64), ("n_circ", C.c_int64),
                 ("n_bins", C.c_int32), ("n_prn", C.c_int32), ("n_comp", C.c_int32), ("half_storage", C.c_int32),
-                ("rows_ms", C.c_double), ("cols_ms", C.c_double), ("n_extra", C.c_int64), ("shader_clock_GHz", C.c_double)]
+                ("rows_ms", C.c_double), ("cols_ms", C.c_double), ("n_extra", C.c_int64), ("shader_clock_GHz", C.c_double),
+                ("plan_l1", C.c_int32), ("plan_l2", C.c_int32), ("rows_kernel", C.c_int32), ("cols_kernel", C.c_int32),
+                ("kernel_flags", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class AcqJob(C.Structure):
@@ -458,7 +460,7 @@ class Context:
     def timing(self) -> dict:
         t = Timing()
         self._check(self._lib.bds_get_timing(self._h, C.byref(t)))
-        return {f: getattr(t, f) for f, _ in Timing._fields_ if f != "reserved0"}
+        return {f: getattr(t, f) for f, _ in Timing._fields_ if not f.startswith("reserved")}
 
     # -- tracking --------------------------------------------------------------------
     def track(self, settings, source, channels, n_epochs, n_cno, fields):

@@ -349,6 +349,49 @@ def strict_f32_leg(local_rank, s, x, n_cells_samples, ncomp, n_circ):
             "note": "fp32 storage AND arithmetic end to end (one extra call); the headline stores spectra and the inter-pass buffer as fp16 complex"}
 
 
+ROWS_KERNEL = {0: "k_rows_inv (run-time plan)", 1: "k_rows_inv_f", 2: "k_rows_wave_f"}
+COLS_KERNEL = {0: "k_cols_inv_max (run-time plan)", 1: "k_cols_inv_max_f (tile)", 2: "k_cols_wave_f"}
+
+
+def kernel_label(tm):
+    """Which row / column kernels the library launched for this plan (bds_timing: plan_l1 x plan_l2, rows_kernel, cols_kernel)."""
+    fl = int(tm.get("kernel_flags", 0))
+    extra = [n for b, n in ((1, "components interleaved in the inter-pass buffer"), (2, "packed-fp32 butterflies")) if fl & b]
+    return "%s<%d> + %s<%d> (plan %d x %d%s)" % (ROWS_KERNEL.get(tm.get("rows_kernel"), "?"), tm.get("plan_l2", 0),
+                                                  COLS_KERNEL.get(tm.get("cols_kernel"), "?"), tm.get("plan_l1", 0),
+                                                  tm.get("plan_l1", 0), tm.get("plan_l2", 0), "; " + ", ".join(extra) if extra else "")
+
+
+def b2a_leg(local_rank, steps=5):
+    """Extra key `b2a` (BASELINE.json configs[1], never `value`): the B2a full acquisition -- 63 PRNs x 26 Doppler bins, 1 ms code,
+    99.375 MS/s -- timed like the headline (block resident in HBM, code spectra cached, `steps` complete bds_acq_run calls)."""
+    import bds_amd
+
+    s, x, sats, label = build_workload("b2a")
+    c = bds_amd.native.Context(local_rank)
+    try:
+        c.acq_load(s, x)
+        c.acq_prepare(s)
+        res = c.acq_run(s)
+        tims = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = c.acq_run(s)
+            tims.append(c.timing())
+        dt = (time.perf_counter() - t0) / steps
+        tm = tims[-1]
+    finally:
+        c.close()
+    n, d, p, nc = tm["n_circ"], tm["n_bins"], tm["n_prn"], tm["n_comp"]
+    b_alg = 9.0 * n * d + 8.0 * (1 + nc) * n * p * d
+    return {"workload": label, "ms_per_step": dt * 1e3, "steps": steps, "value": float(n) * p * d / dt / 1e6, "unit": "Msamples/s",
+            "stage_ms": {k: float(np.mean([t[k] for t in tims])) for k in ("total_ms", "forward_ms", "search_ms", "refine_ms")},
+            "whole_job_frac_of_hbm_peak": b_alg / dt / 1e9 / HBM_PEAK_GBS, "kernel": kernel_label(tm),
+            "pair_ms": tm["cell_pair_ms"], "cells_per_pair": tm["cells_per_pair"], "n_pairs": tm["n_pairs"],
+            "satellites_detected": sorted(int(q) for q in np.nonzero(res[0])[0] + 1),
+            "satellites_injected": sorted(sat.prn for sat in sats)}
+
+
 def clock_leg(local_rank, s, x):
     """Engine clock the search kernels actually run at (extra call, never `value`): with BDS_ACQ_CLOCKPROBE=1 sampled workgroups of
     the row and column pass time their own life with the shader clock against the constant reference clock
@@ -380,9 +423,10 @@ def main():
     ap.add_argument("--workload", default="b1c", choices=["b1c", "b2a", "joint"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="skip the (untimed) tracking leg")
-    ap.add_argument("--no-strict-f32", "--no-fast-path", dest="no_fast_path", action="store_true",
+    ap.add_argument("--no-strict-f32", dest="no_fast_path", action="store_true",
                     help="skip the extra (never the headline) call with fp32 storage end to end")
     ap.add_argument("--no-tracking-full", action="store_true", help="skip the cfg4 leg (12 channels x 3 600 epochs from a 3.6 GB file)")
+    ap.add_argument("--no-b2a", action="store_true", help="skip the extra cfg2 leg (B2a full acquisition, key `b2a`)")
     ap.add_argument("--prns", type=int, default=63, help="tuning only: search PRNs 1..N instead of all 63")
     args = ap.parse_args()
 
@@ -507,12 +551,14 @@ def main():
     # HBM traffic per launch pair: measured separately with rocprofv3 --pmc (FETCH_SIZE x2 gfx950
     # correction + WRITE_SIZE, tools/pmc_run.sh) and committed under profiles/; null if no
     # measurement exists for this workload / cells-per-pair.
-    traffic = None
+    traffic = traffic_source = None
     tpath = os.path.join(ROOT, "profiles", f"traffic_{names[0]}.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if int(tj.get("cells_per_pair", -1)) == int(cells_per_pair):
             traffic = tj["bytes_per_pair"] / 1e9  # GB per launch pair
+            traffic_source = ("replayed from profiles/traffic_%s.json (the builder's rocprofv3 --pmc run of %s), NOT measured in this run"
+                              % (names[0], tj.get("round", "an earlier round")))
 
     # What binds the launch pair: SIMD issue, not HBM.  profiles/valu_<workload>.json (tools/make_valu.py) holds, per kernel,
     # the vector instructions per dispatch counted by the hardware (PMC SQ_INSTS_VALU) and the issue cycles per instruction
@@ -524,12 +570,10 @@ def main():
     if os.path.exists(vpath):
         vj = json.load(open(vpath))
         if int(vj.get("cells_per_pair", -1)) == int(cells_per_pair):
-            valu = {k: vj[k] for k in ("insts_per_pair", "cycles_per_inst", "lds_issue_cycles_per_simd", "valu_issue_cycles_per_simd",
-                                       "clock_GHz", "bound_ms", "kernels")}
+            valu = dict(vj)
+            valu["source"] = ("replayed from profiles/valu_%s.json (hardware instruction counts of the builder's rocprofv3 --pmc run, %s; static "
+                              "instruction classes from the compiler's ISA), NOT measured in this run" % (names[0], vj.get("round", "an earlier round")))
             valu["frac_of_issue_bound"] = vj["bound_ms"] / pair_ms if pair_ms > 0 else None
-            valu["note"] = ("SIMD-issue bound of the launch pair at the peak clock: (VALU cycles + LDS-instruction issue cycles) per SIMD / clock; "
-                            "frac_of_issue_bound = bound_ms / measured pair_ms.  An fp32 transform of 2 x 3.1 M points per cell does not fit "
-                            "into the HBM time of its operands (DESIGN.md section 1.6): 0.80 of the HBM roofline would need pair_ms <= 1.50")
 
     detected = sorted(int(p) for p in np.nonzero(res[0])[0] + 1)
     out = {
@@ -558,9 +602,13 @@ def main():
         "whole_job_frac_of_hbm_peak": b_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         "stage_ms": {k: float(np.mean([t[k] for t in tim])) for k in ("total_ms", "forward_ms", "search_ms", "refine_ms")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     # the same pair at the bytes it really stores (fp16 complex spectra: 4 B per element instead of the model's 8)
+                     "frac_at_stored_bytes": achieved * (0.5 if tm.get("half_storage") else 1.0) / HBM_PEAK_GBS,
+                     "frac_strict_f32": None,  # filled from the strict_f32 leg below: fp32 storage AND arithmetic end to end
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_unit": "GB per launch pair (PMC)", "algorithmic_GB_per_pair": bytes_per_pair / 1e9,
-                     "kernel": "row-pass + column-pass launch pair (k_rows_wave_f + k_cols_wave_f; one pair = %d (PRN, bin) cells)" % int(cells_per_pair),
+                     "kernel": "launch pair %s; one pair = %d (PRN, bin) cells" % (kernel_label(tm), int(cells_per_pair)),
                      "valu": valu,
                      "pair_ms": pair_ms, "rows_ms": tm.get("rows_ms"), "cols_ms": tm.get("cols_ms"), "n_extra": tm.get("n_extra"),
                      "storage": "fp16 complex" if tm.get("half_storage") else "fp32 complex",
@@ -583,14 +631,16 @@ def main():
                                            for g, r in zip(sigs, res_all)}
         out["strict_f32"] = (strict_f32_leg(local_rank, s, x, float(n_circ) * p_total * n_bins, ncomp, n_circ)
                              if world == 1 and len(sigs) == 1 and not args.no_fast_path else None)
+        if out["strict_f32"]:
+            out["roofline"]["frac_strict_f32"] = out["strict_f32"]["frac"]
         if valu is not None and world == 1 and len(sigs) == 1 and not args.no_fast_path:
             ck = clock_leg(local_rank, s, x)
             if ck["shader_clock_GHz"]:
                 valu["shader_clock_GHz"] = ck["shader_clock_GHz"]
+                valu["shader_clock_source"] = "measured in this run (one extra call, BDS_ACQ_CLOCKPROBE=1: sampled workgroups, s_memtime against s_memrealtime)"
                 valu["bound_ms_at_shader_clock"] = valu["bound_ms"] * valu["clock_GHz"] / ck["shader_clock_GHz"]
                 valu["frac_of_issue_bound_at_shader_clock"] = valu["bound_ms_at_shader_clock"] / ck["pair_ms"] if ck["pair_ms"] else None
-                valu["note"] += ("; shader_clock_GHz = the engine clock measured inside the two kernels during one extra call "
-                                 "(sampled workgroups, s_memtime against s_memrealtime): the same bound at the clock the chip sustains under this load")
+        out["b2a"] = b2a_leg(local_rank) if world == 1 and names == ["b1c"] and not args.no_b2a and args.prns == 63 else None
         if len(sigs) > 1:
             out["config"]["satellites_detected_per_signal"] = {g["name"]: sorted(int(p) for p in np.nonzero(r[0])[0] + 1)
                                                                 for g, r in zip(sigs, res_all)}

@@ -134,12 +134,17 @@ typedef struct bds_timing {
     int64_t n_circ;         /* N: the reference's circular correlation length       */
     int32_t n_bins, n_prn, n_comp;
     int32_t half_storage;   /* 0: fp32 search on fp32 storage; 1: fp32 arithmetic, spectra + inter-pass buffer
-                               held as fp16 complex (default); 2: packed-fp16 arithmetic (opt-in)       */
+                               held as fp16 complex (default)                                           */
     double rows_ms;         /* average duration of the row-pass kernel of a sampled launch pair        */
     double cols_ms;         /* ... and of its column-pass kernel                                       */
     int64_t n_extra;        /* entries of the sieve's overflow list in the last search                 */
     double shader_clock_GHz; /* engine clock the search kernels ran at (sampled workgroups time themselves with the shader
                                 clock against the reference clock); 0 unless BDS_ACQ_CLOCKPROBE=1              */
+    int32_t plan_l1, plan_l2; /* two-pass factorisation of fft_len: column length x row length                          */
+    int32_t rows_kernel;    /* row pass of the search: 0 run-time plan (k_rows_inv), 1 k_rows_inv_f, 2 k_rows_wave_f      */
+    int32_t cols_kernel;    /* column pass: 0 run-time plan (k_cols_inv_max), 1 tile kernel k_cols_inv_max_f, 2 k_cols_wave_f */
+    int32_t kernel_flags;   /* bit 0: components interleaved in the inter-pass buffer; bit 1: packed-fp32 butterflies     */
+    int32_t reserved1;
 } bds_timing;
 
 typedef struct bds_ctx bds_ctx;

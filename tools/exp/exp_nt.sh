@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"
 P=${PRNS:-6}
 run() {
-  env "$@" timeout 600 python bench.py --workload b1c --prns $P --steps 2 --warmup 1 --no-cpu-baseline --no-tracking --no-fast-path 2>&1 | python -c "
+  env "$@" timeout 600 python bench.py --workload b1c --prns $P --steps 2 --warmup 1 --no-cpu-baseline --no-tracking --no-strict-f32 2>&1 | python -c "
 import sys,json
 tag=sys.argv[1]
 for l in sys.stdin:

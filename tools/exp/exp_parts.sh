@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"
 P=${PRNS:-6}
 for v in "" $(ls tools/variants/libbds_*.so 2>/dev/null); do
-  env BDS_ACQ_NO_SELFCHECK=1 BDS_LIB_PATH=$v timeout 600 python bench.py --workload b1c --prns $P --steps 2 --warmup 1 --no-cpu-baseline --no-tracking --no-fast-path 2>&1 | python -c "
+  env BDS_ACQ_NO_SELFCHECK=1 BDS_LIB_PATH=$v timeout 600 python bench.py --workload b1c --prns $P --steps 2 --warmup 1 --no-cpu-baseline --no-tracking --no-strict-f32 2>&1 | python -c "
 import sys,json
 tag=sys.argv[1] if len(sys.argv)>1 else 'in-tree'
 for l in sys.stdin:

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for q in 1 2 4 8 16; do
-  BDS_ACQ_WCOLS_QCHUNK=$q timeout 300 python bench.py --prns 8 --no-cpu-baseline --no-tracking --no-fast-path --steps 3 --warmup 1 2>/dev/null | python -c "
+  BDS_ACQ_WCOLS_QCHUNK=$q timeout 300 python bench.py --prns 8 --no-cpu-baseline --no-tracking --no-strict-f32 --steps 3 --warmup 1 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() { tag=$1; shift
-  env "$@" timeout 300 python bench.py --no-cpu-baseline --no-tracking --no-fast-path $ARGS 2>&1 | python -c "
+  env "$@" timeout 300 python bench.py --no-cpu-baseline --no-tracking --no-strict-f32 $ARGS 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

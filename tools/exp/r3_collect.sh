@@ -1,5 +1,5 @@
 #!/bin/bash
-# copy the summaries of a tools/r3_profile.sh pass from gpurun_out/ into profiles/ (run here, after the gpurun call) and rebuild
+# copy the summaries of a tools/exp/r3_profile.sh pass from gpurun_out/ into profiles/ (run here, after the gpurun call) and rebuild
 # the derived files (traffic_b1c.json, valu_b1c.json)
 cd "$(dirname "${BASH_SOURCE[0]}")/.."
 cp gpurun_out/kernel_stats_b1c.txt profiles/r03_b1c_kernel_stats.txt

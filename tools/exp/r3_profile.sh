@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 bash tools/pmc_run.sh > gpurun_out/pmc_run.log 2>&1; tail -2 gpurun_out/pmc_run.log
 cp gpurun_out/pmc_summary.txt gpurun_out/pmc_summary_default.txt
 # fp32 storage: HBM traffic only
-ARGS="--workload b1c --steps 1 --warmup 0 --no-cpu-baseline --no-tracking --no-fast-path --prns 2"
+ARGS="--workload b1c --steps 1 --warmup 0 --no-cpu-baseline --no-tracking --no-strict-f32 --prns 2"
 i=0
 for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT TCC_MISS"; do
   i=$((i+1))
