@@ -979,79 +979,123 @@ static inline double combine(const AcqState &a, const double2 *v) {
 
 }  // namespace bds
 
-extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t *prn_list, int n_prn, int max_prn,
-                           double *carrFreq, double *codePhase, double *peakMetric, int32_t *detected) {
-    if (!ctx || !s_in || !carrFreq || !codePhase || !peakMetric) return BDS_ERR_ARG;
-    if (int rc0 = check_settings(ctx, *s_in)) return rc0;  // (the resampling band edges are only visible here)
-    bds_settings eff;
-    const bds_settings *s = effective(s_in, &eff);
-    int rc = acq_configure(ctx, *s);
-    if (rc) return rc;
-    AcqState &a = *ctx->acq;
-    if (!a.d_sig || a.n_samples < a.N) return fail(ctx, BDS_ERR_ARG, "bds_acq_run: no IF block loaded (bds_acq_load)");
-    if (a.rs.on != resample_plan(*s_in).on || (a.rs.on && a.rs.new_fs != s->samplingFreq))
-        return fail(ctx, BDS_ERR_ARG, "bds_acq_run: the loaded block was conditioned for different resampling settings");
-    if ((rc = bds_acq_prepare(ctx, s))) return rc;
-    std::vector<int> prns;
-    if (prn_list && n_prn > 0)
-        prns.assign(prn_list, prn_list + n_prn);
-    else
-        prns.assign(s->acqSatelliteList, s->acqSatelliteList + s->n_acq);
-    int list_max = 0;
-    for (int i = 0; i < s->n_acq; ++i) list_max = std::max(list_max, (int)s->acqSatelliteList[i]);
-    if (max_prn < list_max) return fail(ctx, BDS_ERR_ARG, "max_prn %d < max(acqSatelliteList) %d", max_prn, list_max);
-    for (int p : prns)
-        if (!a.cs_slot.count(p)) return fail(ctx, BDS_ERR_ARG, "PRN %d of the shard is not in settings.acqSatelliteList", p);
-    for (int i = 0; i < max_prn; ++i) {
-        carrFreq[i] = codePhase[i] = peakMetric[i] = 0.0;  // acquisition.m:161-165
-        if (detected) detected[i] = 0;
+namespace bds {
+namespace {
+
+constexpr int kExtraCap = 1 << 22;  // entries of the sieve's candidate list (wave-private pass) / overflow list (tile pass)
+constexpr int kSamples = 32;        // launch pairs of a run bracketed by timing events
+
+// events of one run; released on every exit path
+struct EventPool {
+    std::vector<hipEvent_t> all;
+    hipError_t make(hipEvent_t *e, unsigned flags = 0) {
+        const hipError_t rc_ = flags ? hipEventCreateWithFlags(e, flags) : hipEventCreate(e);
+        if (rc_ == hipSuccess) all.push_back(*e);
+        return rc_;
     }
-    Plan2D &pl = a.plan;
-    const int D = (int)m_round(s->acqSearchBand * 2 / s->acqStep) + 1;  // numberOfFrqBins :150
-    const double f0 = s->IF - s->acqSearchBand;                         // frqBins :190-191
-    a.D = D;
-    const int P = (int)prns.size();
-    const int ncomp = a.ncomp;
-    pick_group(a, *s);
-    const int G = a.group;
-    if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a) * (size_t)pl.L))) return rc;
-    if ((rc = ensure(ctx, &a.d_Xs, &a.xs_cap, (size_t)D * pl.L))) return rc;
-    if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * D * pl.ntiles))) return rc;
-    if (a.rows_cap < (size_t)P * D) {
-        if (a.d_rowmax) (void)hipFree(a.d_rowmax), a.d_rowmax = nullptr;
-        if (a.d_rowarg) (void)hipFree(a.d_rowarg), a.d_rowarg = nullptr;
-        size_t d0 = 0, d1 = 0;
-        if ((rc = ensure(ctx, &a.d_rowmax, &d0, (size_t)P * D))) return rc;
-        if ((rc = ensure(ctx, &a.d_rowarg, &d1, (size_t)P * D))) return rc;
-        a.rows_cap = (size_t)P * D;
+    ~EventPool() {
+        for (hipEvent_t e : all) (void)hipEventDestroy(e);
+    }
+};
+
+// packed cell maximum -> (value, 0-based lag); nothing searched / nothing written: (-1, -1)
+void unpack_cell(unsigned long long pk, float *v, int *lag) {
+    if (pk == 0) {
+        *v = -1.f, *lag = -1;
+        return;
+    }
+    const uint32_t hi = (uint32_t)(pk >> 32);
+    memcpy(v, &hi, sizeof(float));
+    *lag = (int)~(uint32_t)(pk & 0xffffffffu);
+}
+
+// What a stage asks of bds_acq_run when the sieve cannot be trusted with the storage / kernels it ran on (never returned
+// through the C ABI): redo the call with fp32 storage, or on the run-time-plan kernels (one record per tile, first-index ties)
+//  * a non-finite row maximum (an fp16 value overflowed; Parseval bounds every fp16 value by sqrt(L) x its unit RMS < 2^11, so
+//    int8 input cannot get here -- kept for non-finite f64 input, exercised by a test hook);
+//  * the f64 peak disagrees with the sieve's maximum beyond kDelta / 2: the error model does not hold for this input;
+//  * the candidate list ran over: at the fp16 tolerance (a nearly flat surface: an interferer 40 dB above the noise) fp32
+//    storage first; with fp32 storage (massive exact ties, e.g. an all-zero block) the run-time-plan kernels.
+constexpr int kRedoFp32 = -1000, kRedoPlain = -1001;
+
+// One bds_acq_run attempt: inputs, the quantities its stages share, and the stages in call order.
+struct AcqRun {
+    bds_ctx *ctx;
+    AcqState &a;
+    const bds_settings *s;  // effective settings (after the resampling branch)
+    std::vector<int> prns;
+    double *carrFreq, *codePhase, *peakMetric;
+    int32_t *detected;
+    std::string why;  // reason of a kRedo* return
+
+    int P = 0, D = 0, G = 0, ncomp = 0;
+    double f0 = 0, kDelta = 0;
+    float w0 = 1.f, w1 = 1.f;
+    bool fsearch = false, wcols = false, multiprn = false, overlap = false;
+    size_t elem = 8;  // bytes of one stored complex value
+    int PB = 1;
+    long n_pairs_total = 0, cells_per_pair = 0;
+    SieveOut so{};
+    // timing
+    EventPool evp;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    hipEvent_t sa[kSamples], sb[kSamples], sm[kSamples];
+    hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
+    int nsamp = 0;
+    bool mids = false;  // the sampled pairs carry a mid event (fp32-arithmetic kernels)
+    size_t half_bytes = 0;  // one group of cells in the inter-pass buffer
+    // the sieve's output and the decisions made on it
+    int n_extra = 0;
+    std::vector<Extra> h_extra;
+    std::vector<float> thr_of, max_of;
+    std::vector<std::vector<Cell>> cells;
+    std::vector<PrnResult> res;
+
+    AcqRun(bds_ctx *c, AcqState &st_, const bds_settings *s_) : ctx(c), a(st_), s(s_) {}
+    hipStream_t stream() const { return st(ctx); }
+    double bin_freq(int b) const { return f0 + s->acqStep * (double)b; }
+    int redo(int code, const char *reason) {
+        why = reason;
+        return code;
     }
 
-    // events of this run; released on every exit path
-    struct EventPool {
-        std::vector<hipEvent_t> all;
-        hipError_t make(hipEvent_t *e, unsigned flags = 0) {
-            const hipError_t rc_ = flags ? hipEventCreateWithFlags(e, flags) : hipEventCreate(e);
-            if (rc_ == hipSuccess) all.push_back(*e);
-            return rc_;
-        }
-        ~EventPool() {
-            for (hipEvent_t e : all) (void)hipEventDestroy(e);
-        }
-    } evp;
-    hipEvent_t ev0, ev1, ev2, ev3;
+    int setup();        // sizes, work buffers, events, storage scales, the sieve's lists
+    int forward_all();  // carrier wipe-off + forward transform of every Doppler bin
+    void launch_cells(int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2, int cell0, hipEvent_t mid, int buf = -1);
+    void launch_list(int ncells, Rec *recs, const CellList &cl, int cell0, hipEvent_t mid);
+    int search();          // all (PRN, bin) cells: row pass + column pass per group
+    int collect();         // row maxima + list to the host; can the sieve be trusted?
+    int refine();          // candidates -> f64 coherent sums -> peak, bin, code phase per PRN
+    int metric_b1c();      // GLRT normaliser
+    int second_peak_b2a(); // second peak of the winning bin
+    int fine_search();     // threshold + fine-Doppler search, results
+    int finish();          // timing record
+};
+
+int AcqRun::setup() {
+    Plan2D &pl = a.plan;
+    const Tuning &tune = ctx->tune;
+    int rc;
+    D = (int)m_round(s->acqSearchBand * 2 / s->acqStep) + 1;  // numberOfFrqBins :150
+    f0 = s->IF - s->acqSearchBand;                            // frqBins :190-191
+    a.D = D;
+    P = (int)prns.size();
+    ncomp = a.ncomp;
+    pick_group(a, *s);
+    G = a.group;
+    if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a) * (size_t)pl.L))) return rc;
+    if ((rc = ensure(ctx, &a.d_Xs, &a.xs_cap, (size_t)D * pl.L))) return rc;
+
     BDS_HIP(ctx, evp.make(&ev0));
     BDS_HIP(ctx, evp.make(&ev1));
     BDS_HIP(ctx, evp.make(&ev2));
     BDS_HIP(ctx, evp.make(&ev3));
-    constexpr int kSamples = 32;
-    hipEvent_t sa[kSamples], sb[kSamples], sm[kSamples];
-    int nsamp = 0;
     for (int i = 0; i < kSamples; ++i) {
         BDS_HIP(ctx, evp.make(&sa[i]));
         BDS_HIP(ctx, evp.make(&sb[i]));
         BDS_HIP(ctx, evp.make(&sm[i]));
     }
-    BDS_HIP(ctx, hipEventRecord(ev0, st(ctx)));
+    BDS_HIP(ctx, hipEventRecord(ev0, stream()));
 
     // ---- storage scales (fp16 mode): powers of two from exact sums of the block ----------
     a.sX = a.sB = 1.f;
@@ -1064,20 +1108,8 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         a.sB = (float)std::exp2(std::floor(std::log2(32768.0 / (64.0 * std::max(1e-30, b_rms) * a.sX * a.sC))));
     }
 
-    // ---- forward transforms, once per Doppler bin -------------------------------------
-    {
-        const int chunk = (int)bw_batches(a);
-        for (int b0 = 0; b0 < D; b0 += chunk) {
-            const int nb = std::min(chunk, D - b0);
-            SignalLoader ld{a.sview(), a.N, a.n_ext, f0, s->acqStep, 1.0 / a.fs, b0};
-            float2 *xs_dst = a.half ? (float2 *)((__half2 *)a.d_Xs + (size_t)b0 * pl.L) : a.d_Xs + (size_t)b0 * pl.L;
-            if ((rc = forward(ctx, a, ld, nb, xs_dst, pl.L, 0, a.sX))) return rc;
-        }
-    }
-    BDS_HIP(ctx, hipEventRecord(ev1, st(ctx)));
-
-    // ---- PRN x bin search --------------------------------------------------------------
-    float w0 = 1.f, w1 = 1.f;
+    // ---- the search's knobs and lists ------------------------------------------------------
+    w0 = w1 = 1.f;
     if (a.signal == BDS_SIGNAL_B1C && ncomp == 2) {
         w0 = (float)(std::sqrt(11.0) / std::sqrt(40.0));
         w1 = (float)(std::sqrt(29.0) / std::sqrt(40.0));
@@ -1087,141 +1119,159 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         w0 *= inv;
         w1 *= inv;
     }
-    const Tuning &tune = ctx->tune;
-    const bool fsearch = pl.fast && !a.no_fast_search;  // fp32-arithmetic specialised kernels (default)
+    fsearch = pl.fast && !a.no_fast_search;  // fp32-arithmetic specialised kernels (default)
     // sieve tolerance: every lag within kDelta of a PRN's maximum is re-evaluated in f64.  fp32 storage errs by ~1e-7 of the
     // PRN maximum.  fp16 storage: three roundings lie between the exact value and the sieve's (signal spectrum, code spectrum,
     // inter-pass buffer; 2^-11 relative each).  On noise-like spectra they average out -- 2.5e-4 of the PRN maximum at worst
     // over 63 x 201 rows -- but a spectrum dominated by ONE line (a CW interferer) carries them coherently: 6.4e-4 / 7.9e-4
     // measured at J/N = +20 / +40 dB (tools/sieve_stress.py, profiles/r04_sieve_error.txt), bounded by 3 x 2^-11 = 1.46e-3.
     // kDelta / 2 = 2e-3 lies above that bound and 2.5x above the worst measured case (round 3 used 2e-3: 1.3x).
-    const double kDelta = tune.kdelta > 0 ? tune.kdelta : a.half ? 4e-3 : 2e-5;
-    // overflow list of the column pass: lags within kDelta of their tile's maximum (other than the tile's record)
-    constexpr int kExtraCap = 1 << 22;
+    kDelta = tune.kdelta > 0 ? tune.kdelta : a.half ? 4e-3 : 2e-5;
     {
         size_t cap = a.extra_cap;
         if ((rc = ensure(ctx, &a.d_extra, &cap, (size_t)kExtraCap))) return rc;
         a.extra_cap = cap;
         if (!a.d_extra_count) BDS_HIP(ctx, hipMalloc((void **)&a.d_extra_count, sizeof(int)));
-        BDS_HIP(ctx, hipMemsetAsync(a.d_extra_count, 0, sizeof(int), st(ctx)));
+        BDS_HIP(ctx, hipMemsetAsync(a.d_extra_count, 0, sizeof(int), stream()));
     }
-    SieveOut so{a.d_recs, a.d_extra, a.d_extra_count, kExtraCap, 0, (float)(1.0 - kDelta)};
     // wave-private column pass (default for the fp32-arithmetic search): per-cell packed maxima and per-PRN running
     // bounds instead of per-tile records
     // (the 256-point plans keep the tile kernel unless forced with BDS_ACQ_WCOLS=1: a workgroup's share of such a tile is
     //  8 points per lane and the per-workgroup constants and barriers dominate -- measured at cfg2 2.18 vs 1.39 ms per launch)
-    const bool wcols = fsearch && tune.wcols != 0 && (pl.L1 != 256 || tune.wcols > 0);
+    wcols = fsearch && tune.wcols != 0 && (pl.L1 != 256 || tune.wcols > 0);
+    so = SieveOut{nullptr, a.d_extra, a.d_extra_count, kExtraCap, 0, (float)(1.0 - kDelta)};
     if (wcols) {
         if ((rc = ensure(ctx, &a.d_cellmax, &a.cellmax_cap, (size_t)std::max(P, 1) * D))) return rc;
         if ((rc = ensure(ctx, &a.d_lb, &a.lb_cap, (size_t)std::max(P, 1)))) return rc;
-        BDS_HIP(ctx, hipMemsetAsync(a.d_cellmax, 0, sizeof(unsigned long long) * (size_t)std::max(P, 1) * D, st(ctx)));
-        BDS_HIP(ctx, hipMemsetAsync(a.d_lb, 0, sizeof(float) * (size_t)std::max(P, 1), st(ctx)));
+        BDS_HIP(ctx, hipMemsetAsync(a.d_cellmax, 0, sizeof(unsigned long long) * (size_t)std::max(P, 1) * D, stream()));
+        BDS_HIP(ctx, hipMemsetAsync(a.d_lb, 0, sizeof(float) * (size_t)std::max(P, 1), stream()));
         so.cellmax = a.d_cellmax;
         so.lb = a.d_lb;
         so.lb_div = D;
-    }
-    // packed cell maximum -> (value, 0-based lag); nothing searched / nothing written: (-1, -1)
-    auto unpack_cell = [](unsigned long long pk, float *v, int *lag) {
-        if (pk == 0) {
-            *v = -1.f, *lag = -1;
-            return;
+    } else {  // per-tile records + per-row reduction (tile kernel, run-time-plan kernels)
+        if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * D * pl.ntiles))) return rc;
+        if (a.rows_cap < (size_t)P * D) {
+            if (a.d_rowmax) (void)hipFree(a.d_rowmax), a.d_rowmax = nullptr;
+            if (a.d_rowarg) (void)hipFree(a.d_rowarg), a.d_rowarg = nullptr;
+            size_t d0 = 0, d1 = 0;
+            if ((rc = ensure(ctx, &a.d_rowmax, &d0, (size_t)P * D))) return rc;
+            if ((rc = ensure(ctx, &a.d_rowarg, &d1, (size_t)P * D))) return rc;
+            a.rows_cap = (size_t)P * D;
         }
-        const uint32_t hi = (uint32_t)(pk >> 32);
-        memcpy(v, &hi, sizeof(float));
-        *lag = (int)~(uint32_t)(pk & 0xffffffffu);
-    };
-    const size_t elem = a.half ? 4 : 8;  // bytes of one stored complex value
+        so.recs = a.d_recs;
+    }
+    elem = a.half ? 4 : 8;
     // Small Doppler grids (B2a: 26 bins): one launch pair carries the whole rows of several PRNs through
     // a cell list, so that the grids fill the chip and a row workgroup still walks one PRN's bins.
-    const bool multiprn = fsearch && (D <= 104 || tune.multi_any) && P > 1 && !tune.nomulti;
+    multiprn = fsearch && (D <= 104 || tune.multi_any) && P > 1 && !tune.nomulti;
     // (measured at cfg2, 63 PRNs x 26 bins: 104 cells per pair 3.9 ms, 208 -> 3.6, 416 -> 3.2, 832 -> 3.1, all 1638 -> 3.0;
     //  the fused fp16 chain of round 2 4.0); the work buffer is capped at 8 GiB
     const long pb_cap = std::max<long>(1, (long)(tune.pbcap_gb * 1073741824.0 / ((double)ncomp * (double)pl.L * (double)elem)));
     const long pb_cells = tune.pbcells ? tune.pbcells : pb_cap;
-    const int PB = multiprn ? (int)std::min<long>(P, std::max<long>(2, std::min(pb_cells, pb_cap) / D)) : 1;
-    long n_pairs_total = (long)P * ((D + G - 1) / G);
-    long cells_per_pair = G;
+    PB = multiprn ? (int)std::min<long>(P, std::max<long>(2, std::min(pb_cells, pb_cap) / D)) : 1;
+    n_pairs_total = (long)P * ((D + G - 1) / G);
+    cells_per_pair = G;
     if (multiprn) n_pairs_total = (P + PB - 1) / PB, cells_per_pair = (long)PB * D;
-    const long sample_every = std::max<long>(1, n_pairs_total / kSamples);
-    long pair_idx = 0;
-    const hipStream_t s_main = st(ctx);
-    // one group of cells of one PRN (consecutive bins b0 .. b0+nb-1, or one bin with lag ranges): both passes on the
-    // main stream; cell0 = run-wide index of the first cell (overflow-list bookkeeping)
-    bool mids = false;  // the sampled pairs carry a mid event (fp32-arithmetic kernels)
-    // Overlapped passes (BDS_ACQ_OVERLAP=1, fp32-arithmetic kernels): the row pass is HBM-bound, the column pass
-    // VALU / barrier-bound; group k's column pass runs on a second stream beside group k+1's row pass, the two
-    // working in different halves of the inter-pass buffer.
-    const bool overlap = fsearch && tune.overlap && !multiprn;
-    hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
+    // Overlapped passes (BDS_ACQ_OVERLAP=1, fp32-arithmetic kernels): group k's column pass runs on a second stream beside
+    // group k+1's row pass, the two working in different halves of the inter-pass buffer.
+    overlap = fsearch && tune.overlap && !multiprn;
     if (overlap)
         for (int i = 0; i < 2; ++i) {
             BDS_HIP(ctx, evp.make(&ev_rows[i], hipEventDisableTiming));
             BDS_HIP(ctx, evp.make(&ev_cols[i], hipEventDisableTiming));
         }
-    const size_t half_bytes = (size_t)G * ncomp * pl.L * elem;  // one group of cells in the inter-pass buffer
-    long group_idx = 0;
-    auto launch_cells = [&](int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2, int cell0, hipEvent_t mid,
-                            int buf = -1) {
-        const size_t cs_off = (size_t)a.cs_slot[prn] * ncomp * pl.L;
-        SieveOut so1 = so;
-        so1.recs = recs;
-        so1.cell0 = cell0;
-        so1.mid = mid;
-        if (mid && fsearch) mids = true;
-        void *const Bw_ = buf > 0 ? (void *)((char *)a.d_Bw + half_bytes) : (void *)a.d_Bw;
-        if (buf >= 0) {
-            so1.cols_stream = (hipStream_t)ctx->stream2;
-            so1.ev_rows = ev_rows[buf];
-            so1.ev_cols = ev_cols[buf];
-        }
-        if (fsearch && a.half) {
-            const void *Ch = (const __half2 *)a.d_Cs + cs_off;
-            if (ncomp == 2)
-                launch_fast_f<2, __half2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
-            else
-                launch_fast_f<1, __half2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
-        } else if (fsearch) {
-            const void *Cf = a.d_Cs + cs_off;
-            if (ncomp == 2)
-                launch_fast_f<2, float2>(ctx, s_main, pl, a.d_Xs, nb, b0, Cf, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
-            else
-                launch_fast_f<1, float2>(ctx, s_main, pl, a.d_Xs, nb, b0, Cf, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
+    half_bytes = (size_t)G * ncomp * pl.L * elem;
+    return BDS_OK;
+}
+
+int AcqRun::forward_all() {
+    Plan2D &pl = a.plan;
+    const int chunk = (int)bw_batches(a);
+    for (int b0 = 0; b0 < D; b0 += chunk) {
+        const int nb = std::min(chunk, D - b0);
+        SignalLoader ld{a.sview(), a.N, a.n_ext, f0, s->acqStep, 1.0 / a.fs, b0};
+        float2 *xs_dst = a.half ? (float2 *)((__half2 *)a.d_Xs + (size_t)b0 * pl.L) : a.d_Xs + (size_t)b0 * pl.L;
+        if (int rc = forward(ctx, a, ld, nb, xs_dst, pl.L, 0, a.sX)) return rc;
+    }
+    BDS_HIP(ctx, hipEventRecord(ev1, stream()));
+    return BDS_OK;
+}
+
+// one group of cells of one PRN (consecutive bins b0 .. b0+nb-1, or one bin with lag ranges): both passes on the
+// main stream; cell0 = run-wide index of the first cell (list bookkeeping)
+void AcqRun::launch_cells(int prn, int b0, int nb, Rec *recs, int lo1, int hi1, int lo2, int hi2, int cell0, hipEvent_t mid, int buf) {
+    Plan2D &pl = a.plan;
+    const hipStream_t s_main = stream();
+    const size_t cs_off = (size_t)a.cs_slot[prn] * ncomp * pl.L;
+    SieveOut so1 = so;
+    so1.recs = recs;
+    so1.cell0 = cell0;
+    so1.mid = mid;
+    if (mid && fsearch) mids = true;
+    void *const Bw_ = buf > 0 ? (void *)((char *)a.d_Bw + half_bytes) : (void *)a.d_Bw;
+    if (buf >= 0) {
+        so1.cols_stream = (hipStream_t)ctx->stream2;
+        so1.ev_rows = ev_rows[buf];
+        so1.ev_cols = ev_cols[buf];
+    }
+    if (fsearch && a.half) {
+        const void *Ch = (const __half2 *)a.d_Cs + cs_off;
+        if (ncomp == 2)
+            launch_fast_f<2, __half2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
+        else
+            launch_fast_f<1, __half2>(ctx, s_main, pl, a.d_Xs, nb, b0, Ch, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
+    } else if (fsearch) {
+        const void *Cf = a.d_Cs + cs_off;
+        if (ncomp == 2)
+            launch_fast_f<2, float2>(ctx, s_main, pl, a.d_Xs, nb, b0, Cf, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
+        else
+            launch_fast_f<1, float2>(ctx, s_main, pl, a.d_Xs, nb, b0, Cf, Bw_, a.sB, w0, w1, lo1, hi1, lo2, hi2, so1);
+    } else {
+        const float2 *Cs = a.d_Cs + cs_off;
+        dim3 gr(pl.L1, nb), gc(pl.ntiles, nb);
+        if (ncomp == 2) {
+            hipLaunchKernelGGL(k_rows_inv<2>, gr, dim3(pl.nt_rows), pl.lds_rows, s_main, pl.p2, pl.twl,
+                               (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
+            hipLaunchKernelGGL(k_cols_inv_max<2>, gc, dim3(pl.nt_cols), pl.lds_cols, s_main, pl.p1, pl.L2, pl.logT,
+                               pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
         } else {
-            const float2 *Cs = a.d_Cs + cs_off;
-            dim3 gr(pl.L1, nb), gc(pl.ntiles, nb);
-            if (ncomp == 2) {
-                hipLaunchKernelGGL(k_rows_inv<2>, gr, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, pl.twl,
-                                   (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
-                hipLaunchKernelGGL(k_cols_inv_max<2>, gc, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.L2, pl.logT,
-                                   pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
-            } else {
-                hipLaunchKernelGGL(k_rows_inv<1>, gr, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, pl.twl,
-                                   (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
-                hipLaunchKernelGGL(k_cols_inv_max<1>, gc, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.L2, pl.logT,
-                                   pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
-            }
+            hipLaunchKernelGGL(k_rows_inv<1>, gr, dim3(pl.nt_rows), pl.lds_rows, s_main, pl.p2, pl.twl,
+                               (const float2 *)a.d_Xs, pl.L, b0, Cs, a.d_Bw);
+            hipLaunchKernelGGL(k_cols_inv_max<1>, gc, dim3(pl.nt_cols), pl.lds_cols, s_main, pl.p1, pl.L2, pl.logT,
+                               pl.Spad, (const float2 *)a.d_Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, recs, pl.ntiles);
         }
-    };
-    // cells described by a list (whole rows of several PRNs, or one (PRN, winning bin) cell per PRN)
-    auto launch_list = [&](int ncells, Rec *recs, const CellList &cl, int cell0, hipEvent_t mid) {
-        SieveOut so1 = so;
-        so1.recs = recs;
-        so1.cell0 = cell0;
-        so1.mid = mid;
-        if (mid) mids = true;
-        const int hi1 = cl.rng ? -1 : (int)a.N - 1, lo2 = cl.rng ? 0 : 1, hi2 = cl.rng ? -1 : 0;
-        if (a.half) {
-            if (ncomp == 2)
-                launch_fast_f<2, __half2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
-            else
-                launch_fast_f<1, __half2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
-        } else {
-            if (ncomp == 2)
-                launch_fast_f<2, float2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
-            else
-                launch_fast_f<1, float2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
-        }
-    };
+    }
+}
+
+// cells described by a list (whole rows of several PRNs, or one (PRN, winning bin) cell per PRN)
+void AcqRun::launch_list(int ncells, Rec *recs, const CellList &cl, int cell0, hipEvent_t mid) {
+    Plan2D &pl = a.plan;
+    const hipStream_t s_main = stream();
+    SieveOut so1 = so;
+    so1.recs = recs;
+    so1.cell0 = cell0;
+    so1.mid = mid;
+    if (mid) mids = true;
+    const int hi1 = cl.rng ? -1 : (int)a.N - 1, lo2 = cl.rng ? 0 : 1, hi2 = cl.rng ? -1 : 0;
+    if (a.half) {
+        if (ncomp == 2)
+            launch_fast_f<2, __half2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
+        else
+            launch_fast_f<1, __half2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
+    } else {
+        if (ncomp == 2)
+            launch_fast_f<2, float2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
+        else
+            launch_fast_f<1, float2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
+    }
+}
+
+int AcqRun::search() {
+    Plan2D &pl = a.plan;
+    const hipStream_t s_main = stream();
+    int rc;
+    const long sample_every = std::max<long>(1, n_pairs_total / kSamples);
+    long pair_idx = 0, group_idx = 0;
     if (multiprn) {
         // float2-sized elements the PB*D cells of one launch pair occupy
         const size_t need = ((size_t)PB * D * ncomp * elem + 7) / 8;
@@ -1237,8 +1287,8 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         if ((rc = ensure(ctx, &a.d_cells, &a.cells_cap, (sizeof(long) + sizeof(int)) * nc_ + 64))) return rc;
         long *d_cs = (long *)a.d_cells;
         int *d_bin = (int *)(d_cs + nc_);
-        BDS_HIP(ctx, hipMemcpyAsync(d_cs, h_cs.data(), sizeof(long) * nc_, hipMemcpyHostToDevice, st(ctx)));
-        BDS_HIP(ctx, hipMemcpyAsync(d_bin, h_bin.data(), sizeof(int) * nc_, hipMemcpyHostToDevice, st(ctx)));
+        BDS_HIP(ctx, hipMemcpyAsync(d_cs, h_cs.data(), sizeof(long) * nc_, hipMemcpyHostToDevice, s_main));
+        BDS_HIP(ctx, hipMemcpyAsync(d_bin, h_bin.data(), sizeof(int) * nc_, hipMemcpyHostToDevice, s_main));
         for (int pi0 = 0; pi0 < P; pi0 += PB, ++pair_idx) {
             const int np_ = std::min(PB, P - pi0);
             CellList cl;
@@ -1246,9 +1296,9 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             cl.cs = d_cs + (size_t)pi0 * D;
             cl.gc = D;
             const bool sample = np_ == PB && (pair_idx % sample_every) == 0 && nsamp < kSamples;
-            if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], st(ctx)));
-            launch_list(np_ * D, a.d_recs + (size_t)pi0 * D * pl.ntiles, cl, pi0 * D, sample ? sm[nsamp] : nullptr);
-            if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], st(ctx)));
+            if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], s_main));
+            launch_list(np_ * D, wcols ? nullptr : a.d_recs + (size_t)pi0 * D * pl.ntiles, cl, pi0 * D, sample ? sm[nsamp] : nullptr);
+            if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], s_main));
         }
     } else {
         for (int pi = 0; pi < P; ++pi) {
@@ -1258,10 +1308,10 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
                 // the row pass of group k re-uses the buffer half the column pass of group k-2 read
                 if (overlap && group_idx >= 2) BDS_HIP(ctx, hipStreamWaitEvent(s_main, ev_cols[buf], 0));
                 const bool sample = !overlap && nb == G && (pair_idx % sample_every) == 0 && nsamp < kSamples;
-                if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], st(ctx)));
-                launch_cells(prns[pi], b0, nb, a.d_recs + ((size_t)pi * D + b0) * pl.ntiles, 0, (int)a.N - 1, 1, 0, pi * D + b0,
-                             sample ? sm[nsamp] : nullptr, buf);
-                if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], st(ctx)));
+                if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], s_main));
+                launch_cells(prns[pi], b0, nb, wcols ? nullptr : a.d_recs + ((size_t)pi * D + b0) * pl.ntiles, 0, (int)a.N - 1, 1, 0,
+                             pi * D + b0, sample ? sm[nsamp] : nullptr, buf);
+                if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], s_main));
             }
         }
         if (overlap)  // join: everything after this is ordered on the main stream again
@@ -1269,39 +1319,29 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     }
     BDS_HIP(ctx, hipGetLastError());
     if (!wcols)
-        hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)(P * D)), dim3(256), 0, st(ctx), (const Rec *)a.d_recs,
+        hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)(P * D)), dim3(256), 0, s_main, (const Rec *)a.d_recs,
                            pl.ntiles, pl.ntiles, a.d_rowmax, a.d_rowarg);
-    BDS_HIP(ctx, hipEventRecord(ev2, st(ctx)));
+    BDS_HIP(ctx, hipEventRecord(ev2, s_main));
+    return BDS_OK;
+}
+
+int AcqRun::collect() {
+    const Tuning &tune = ctx->tune;
     a.h_rowmax.resize((size_t)P * D);
     a.h_rowarg.resize((size_t)P * D);
-    int n_extra = 0;
+    n_extra = 0;
     std::vector<unsigned long long> h_cellmax(wcols ? (size_t)P * D : 0);
     if (wcols) {
-        BDS_HIP(ctx, hipMemcpyAsync(h_cellmax.data(), a.d_cellmax, sizeof(unsigned long long) * P * D, hipMemcpyDeviceToHost, st(ctx)));
+        BDS_HIP(ctx, hipMemcpyAsync(h_cellmax.data(), a.d_cellmax, sizeof(unsigned long long) * P * D, hipMemcpyDeviceToHost, stream()));
     } else {
-        BDS_HIP(ctx, hipMemcpyAsync(a.h_rowmax.data(), a.d_rowmax, sizeof(float) * P * D, hipMemcpyDeviceToHost, st(ctx)));
-        BDS_HIP(ctx, hipMemcpyAsync(a.h_rowarg.data(), a.d_rowarg, sizeof(int) * P * D, hipMemcpyDeviceToHost, st(ctx)));
+        BDS_HIP(ctx, hipMemcpyAsync(a.h_rowmax.data(), a.d_rowmax, sizeof(float) * P * D, hipMemcpyDeviceToHost, stream()));
+        BDS_HIP(ctx, hipMemcpyAsync(a.h_rowarg.data(), a.d_rowarg, sizeof(int) * P * D, hipMemcpyDeviceToHost, stream()));
     }
-    BDS_HIP(ctx, hipMemcpyAsync(&n_extra, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, st(ctx)));
-    BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+    BDS_HIP(ctx, hipMemcpyAsync(&n_extra, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    BDS_HIP(ctx, hipStreamSynchronize(stream()));
     for (size_t i = 0; i < h_cellmax.size(); ++i) unpack_cell(h_cellmax[i], &a.h_rowmax[i], &a.h_rowarg[i]);
     a.run_prns = prns;
     a.last.clear();
-    // Re-run with wider storage / plainer kernels when the sieve cannot be trusted:
-    //  * a non-finite row maximum (an fp16 value overflowed; Parseval bounds every fp16 value by sqrt(L) x its
-    //    unit RMS < 2^11, so int8 input cannot get here -- kept for non-finite f64 input, exercised by a test hook);
-    //  * the overflow list ran over (a surface with massive exact ties): the run-time-plan kernels keep one
-    //    record per tile with MATLAB's first-index tie rule.
-    auto rerun = [&](bool plain_kernels, const char *why) -> int {
-        if (tune.verbose) fprintf(stderr, "[bds] search re-run (%s): %s\n", plain_kernels ? "run-time-plan kernels" : "fp32 storage", why);
-        a.half = false;
-        a.no_fast_search = a.no_fast_search || plain_kernels;
-        a.sC = 1.f;
-        a.cs_slot.clear();
-        // (the flags stay until the configuration changes: acq_configure keeps them for the same key)
-        if (int rc2 = bds_acq_prepare(ctx, s_in)) return rc2;
-        return bds_acq_run(ctx, s_in, prn_list, n_prn, max_prn, carrFreq, codePhase, peakMetric, detected);
-    };
     {
         bool bad = false;
         for (float v : a.h_rowmax) bad = bad || !std::isfinite(v);
@@ -1312,24 +1352,28 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             for (size_t i = 0; i < std::min<size_t>(8, a.h_rowmax.size()); ++i) fprintf(stderr, " %g", a.h_rowmax[i]);
             fprintf(stderr, "  (sX %g sC %g sB %g)\n", a.sX, a.sC, a.sB);
         }
-        if (a.half && ((bad && !tune.no_selfcheck) || tune.test_force_fallback)) return rerun(false, bad ? "non-finite row maximum" : "test hook");
-        // (with fp16 storage the tolerance band is 200x wider than with fp32 storage: a nearly flat surface -- an interferer
-        //  40 dB above the noise -- fills the list; fp32 storage first, the run-time-plan kernels only if that runs over too)
-        if (n_extra > kExtraCap && a.half) return rerun(false, "overflow list of the sieve ran over at the fp16-storage tolerance");
-        if (n_extra > kExtraCap && !a.no_fast_search) return rerun(true, "overflow list of the sieve ran over");
+        if (a.half && ((bad && !tune.no_selfcheck) || tune.test_force_fallback)) return redo(kRedoFp32, bad ? "non-finite row maximum" : "test hook");
+        if (n_extra > kExtraCap && a.half) return redo(kRedoFp32, "overflow list of the sieve ran over at the fp16-storage tolerance");
+        if (n_extra > kExtraCap && !a.no_fast_search) return redo(kRedoPlain, "overflow list of the sieve ran over");
     }
-    std::vector<Extra> h_extra((size_t)std::min(n_extra, kExtraCap));
+    h_extra.resize((size_t)std::min(n_extra, kExtraCap));
     if (!h_extra.empty())
-        BDS_HIP(ctx, hipMemcpyAsync(h_extra.data(), a.d_extra, sizeof(Extra) * h_extra.size(), hipMemcpyDeviceToHost, st(ctx)));
+        BDS_HIP(ctx, hipMemcpyAsync(h_extra.data(), a.d_extra, sizeof(Extra) * h_extra.size(), hipMemcpyDeviceToHost, stream()));
     a.n_extra_last = n_extra;
+    return BDS_OK;
+}
 
-    // ---- f64 refinement of the sieve's candidates ---------------------------------------
-    auto bin_freq = [&](int b) { return f0 + s->acqStep * (double)b; };
-    std::vector<std::vector<Cell>> cells(P);
+// ---- f64 refinement of the sieve's candidates ---------------------------------------
+int AcqRun::refine() {
+    Plan2D &pl = a.plan;
+    const Tuning &tune = ctx->tune;
+    int rc;
+    cells.assign(P, {});
     std::vector<CorrJob> jobs;
     // only the per-workgroup records of rows that reach the tolerance band travel to the host
-    // (the full record array is P*D*tiles*8 B: 104 MB at the B1C config)
-    std::vector<float> thr_of(P), max_of(P);
+    // (the full record array is P*D*tiles*8 B: 104 MB at the B1C config); the wave-private pass keeps no tile records: its list is complete
+    thr_of.assign(P, 0.f);
+    max_of.assign(P, 0.f);
     std::map<std::pair<int, int>, size_t> row_at;
     std::vector<Rec> h_recs;
     {
@@ -1339,13 +1383,15 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
             for (int b = 0; b < D; ++b) M = std::max(M, a.h_rowmax[(size_t)pi * D + b]);
             max_of[pi] = M;
             thr_of[pi] = (float)((1.0 - kDelta) * (double)M);
-            for (int b = 0; b < D && !wcols; ++b)  // (the wave-private pass keeps no tile records: its list is complete)
+            for (int b = 0; b < D && !wcols; ++b)
                 if (!(a.h_rowmax[(size_t)pi * D + b] < thr_of[pi])) rows.push_back({pi, b});
         }
         const size_t all = (size_t)P * D * pl.ntiles;
-        if (all * sizeof(Rec) <= (16u << 20)) {  // small grid (B2a): one copy beats many row copies
+        if (wcols) {
+            // nothing to fetch
+        } else if (all * sizeof(Rec) <= (16u << 20)) {  // small grid (B2a): one copy beats many row copies
             h_recs.resize(all);
-            BDS_HIP(ctx, hipMemcpyAsync(h_recs.data(), a.d_recs, sizeof(Rec) * all, hipMemcpyDeviceToHost, st(ctx)));
+            BDS_HIP(ctx, hipMemcpyAsync(h_recs.data(), a.d_recs, sizeof(Rec) * all, hipMemcpyDeviceToHost, stream()));
             for (auto &r : rows) row_at[r] = ((size_t)r.first * D + r.second) * pl.ntiles;
         } else {
             h_recs.resize(rows.size() * (size_t)pl.ntiles);
@@ -1353,10 +1399,10 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
                 row_at[rows[r]] = r * (size_t)pl.ntiles;
                 BDS_HIP(ctx, hipMemcpyAsync(&h_recs[r * (size_t)pl.ntiles],
                                             a.d_recs + ((size_t)rows[r].first * D + rows[r].second) * pl.ntiles,
-                                            sizeof(Rec) * pl.ntiles, hipMemcpyDeviceToHost, st(ctx)));
+                                            sizeof(Rec) * pl.ntiles, hipMemcpyDeviceToHost, stream()));
             }
         }
-        BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
+        BDS_HIP(ctx, hipStreamSynchronize(stream()));  // (also: h_extra has arrived)
     }
     {
         std::vector<std::set<Cell>> cs(P);
@@ -1377,7 +1423,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
                     if (rr[t].lag >= 0 && !(rr[t].v < thr)) add(pi, b, rr[t].lag);
             }
         }
-        // lags the column pass reported beside their tile's record (within kDelta of the tile maximum)
+        // lags the column pass put on its list (wave-private pass: every candidate; tile pass: those beside their tile's record)
         for (const Extra &e : h_extra) {
             const int pi = e.cell / D, b = e.cell % D;
             if (pi >= 0 && pi < P && e.lag >= 0 && !(e.v < thr_of[pi])) add(pi, b, e.lag);
@@ -1403,153 +1449,162 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     }
     std::vector<double2> jout;
     if ((rc = run_jobs(ctx, a, *s, jobs, jout))) return rc;
-    std::vector<PrnResult> res(P);
-    {
-        size_t k = 0;
-        for (int pi = 0; pi < P; ++pi) {
-            double best = -1;
-            Cell bc{0, 0};
-            for (const Cell &c : cells[pi]) {
-                const double v = combine(a, &jout[k]);
-                k += ncomp;
-                // ties: first row / first column, as MATLAB max does (acquisition.m:218-221)
-                if (v > best || (v == best && (c.b < bc.b || (c.b == bc.b && c.lag < bc.lag)))) best = v, bc = c;
-            }
-            res[pi].peak = best;
-            res[pi].fbin = bc.b + 1;
-            res[pi].codePhase = bc.lag + 1;
-            // The sieve's maximum must agree with the f64 value to well inside the tolerance band it was
-            // searched with; otherwise its error model does not hold for this input: redo with fp32 storage.
-            if (a.half && !tune.no_selfcheck && !cells[pi].empty() && std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
-                char why[160];
-                snprintf(why, sizeof(why), "PRN %d: sieve maximum %.9g vs f64 %.9g (rel %.3g > %.3g)", prns[pi], (double)max_of[pi], best,
-                         std::fabs(best - (double)max_of[pi]) / best, 0.5 * kDelta);
-                return rerun(false, why);
-            }
+    res.assign(P, PrnResult{});
+    size_t k = 0;
+    for (int pi = 0; pi < P; ++pi) {
+        double best = -1;
+        Cell bc{0, 0};
+        for (const Cell &c : cells[pi]) {
+            const double v = combine(a, &jout[k]);
+            k += ncomp;
+            // ties: first row / first column, as MATLAB max does (acquisition.m:218-221)
+            if (v > best || (v == best && (c.b < bc.b || (c.b == bc.b && c.lag < bc.lag)))) best = v, bc = c;
+        }
+        res[pi].peak = best;
+        res[pi].fbin = bc.b + 1;
+        res[pi].codePhase = bc.lag + 1;
+        // The sieve's maximum must agree with the f64 value to well inside the tolerance band it was
+        // searched with; otherwise its error model does not hold for this input: redo with fp32 storage.
+        if (a.half && !tune.no_selfcheck && !cells[pi].empty() && std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
+            char msg[160];
+            snprintf(msg, sizeof(msg), "PRN %d: sieve maximum %.9g vs f64 %.9g (rel %.3g > %.3g)", prns[pi], (double)max_of[pi], best,
+                     std::fabs(best - (double)max_of[pi]) / best, 0.5 * kDelta);
+            return redo(kRedoFp32, msg);
         }
     }
+    return BDS_OK;
+}
 
-    // ---- detection metric -----------------------------------------------------------------
-    if (a.signal == BDS_SIGNAL_B1C) {
-        // sigPower = sqrt(var(sig(1:X)) * X), unbiased variance (B1C/acquisition.m:150)
-        // (complex input: var = sum |x - mean|^2 / (X-1), as MATLAB's var of a complex vector)
-        const double mean = (a.h_prefix[a.X] - a.h_prefix[0]) / (double)a.X;
-        const double mean_q = a.cplx ? (a.h_prefix_q[a.X] - a.h_prefix_q[0]) / (double)a.X : 0.0;
-        long double acc = 0;
-        for (long i = 0; i < a.X; ++i) {
-            const double d = a.h_re[(size_t)i] - mean;
-            const double dq = a.cplx ? a.h_im[(size_t)i] - mean_q : 0.0;
-            acc += (long double)(d * d + dq * dq);
-        }
-        const double var = (double)(acc / (long double)(a.X - 1));
-        const double sigPower = std::sqrt(var * (double)a.X);
-        for (int pi = 0; pi < P; ++pi) {
-            res[pi].denom = sigPower;
-            if (res[pi].codePhase + a.spc - 1 > a.n_samples) res[pi].codePhase -= a.spc;  // :239-241
-        }
-    } else {
-        // second peak in the winning bin, outside +-2 chips and within +-1 code (B2a/acquisition.m:224-249)
-        // (one cell per PRN, a single round of workgroups: the tile kernel with its per-tile records serves this pass; the
-        //  wave-private kernel's running bounds have nothing to run on)
-        so.cellmax = nullptr;
-        so.lb = nullptr;
-        const long s2c = (long)std::ceil(s->samplingFreq / s->codeFreqBasis) * 2;  // samples2CodeChip :137
-        std::vector<std::array<long, 4>> rng(P);
-        if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * D * pl.ntiles))) return rc;
-        // specialised kernels: all PRNs' (PRN, winning bin) cells in one launch pair through a cell list
-        // (63 tiny launch pairs were ~1 ms of the 2.7 ms refinement at cfg2)
-        const size_t cap_cells = a.bw_cap / (size_t)pl.L * 8 / elem / (size_t)ncomp;  // cells the work buffer holds
-        const bool batched = fsearch && (size_t)P <= cap_cells;
-        BDS_HIP(ctx, hipMemsetAsync(a.d_extra_count, 0, sizeof(int), st(ctx)));  // overflow list of this pass: cell = PRN index
-        std::vector<int> h_bin(P);
-        std::vector<long> h_cs(P);
-        std::vector<int4> h_rng(P);
-        for (int pi = 0; pi < P; ++pi) {
-            const long cp = res[pi].codePhase;
-            const long e1 = cp - s2c, e2 = cp + s2c, e3 = cp - a.spc + s2c, e4 = cp + a.spc - s2c;
-            long lo1 = 1, hi1 = 0, lo2 = 1, hi2 = 0;  // 1-based inclusive, empty when lo > hi
-            if (e1 >= 1) lo1 = std::max<long>(1, e3), hi1 = e1;
-            if (e2 < a.N) lo2 = e2, hi2 = std::min<long>(e4, a.N);
-            rng[pi] = {lo1 - 1, hi1 - 1, lo2 - 1, hi2 - 1};  // 0-based
-            if (hi1 < lo1 && hi2 < lo2)
-                return fail(ctx, BDS_ERR_ARG, "PRN %d: empty second-peak range (acquisition.m:248 would fail)", prns[pi]);
-            h_bin[pi] = res[pi].fbin - 1;
-            h_cs[pi] = (long)a.cs_slot[prns[pi]] * ncomp * pl.L;
-            h_rng[pi] = make_int4((int)rng[pi][0], (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3]);
-            if (!batched)
-                launch_cells(prns[pi], res[pi].fbin - 1, 1, a.d_recs + (size_t)pi * pl.ntiles, (int)rng[pi][0],
-                             (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3], pi, nullptr);
-        }
-        if (batched && P > 0) {
-            const size_t nb_ = sizeof(int) * P + sizeof(long) * P + sizeof(int4) * P + 64;
-            if ((rc = ensure(ctx, &a.d_cells, &a.cells_cap, nb_))) return rc;
-            int4 *d_rng = (int4 *)a.d_cells;                       // 16-byte aligned first
-            long *d_cs = (long *)(d_rng + P);
-            int *d_bin = (int *)(d_cs + P);
-            BDS_HIP(ctx, hipMemcpyAsync(d_rng, h_rng.data(), sizeof(int4) * P, hipMemcpyHostToDevice, st(ctx)));
-            BDS_HIP(ctx, hipMemcpyAsync(d_cs, h_cs.data(), sizeof(long) * P, hipMemcpyHostToDevice, st(ctx)));
-            BDS_HIP(ctx, hipMemcpyAsync(d_bin, h_bin.data(), sizeof(int) * P, hipMemcpyHostToDevice, st(ctx)));
-            const CellList cl{d_bin, d_cs, d_rng};
-            launch_list(P, a.d_recs, cl, 0, nullptr);
-        }
-        BDS_HIP(ctx, hipGetLastError());
-        std::vector<Rec> r2((size_t)P * pl.ntiles);
-        int n_extra2 = 0;
-        BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, st(ctx)));
-        BDS_HIP(ctx, hipMemcpyAsync(&n_extra2, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, st(ctx)));
-        BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
-        if (n_extra2 > kExtraCap && a.half) return rerun(false, "overflow list of the second-peak pass ran over at the fp16-storage tolerance");
-        if (n_extra2 > kExtraCap && !a.no_fast_search) return rerun(true, "overflow list of the second-peak pass ran over");
-        std::vector<Extra> h_extra2((size_t)std::min(n_extra2, kExtraCap));
-        if (!h_extra2.empty()) {
-            BDS_HIP(ctx, hipMemcpyAsync(h_extra2.data(), a.d_extra, sizeof(Extra) * h_extra2.size(), hipMemcpyDeviceToHost, st(ctx)));
-            BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
-        }
+// sigPower = sqrt(var(sig(1:X)) * X), unbiased variance (B1C/acquisition.m:150)
+// (complex input: var = sum |x - mean|^2 / (X-1), as MATLAB's var of a complex vector)
+int AcqRun::metric_b1c() {
+    const double mean = (a.h_prefix[a.X] - a.h_prefix[0]) / (double)a.X;
+    const double mean_q = a.cplx ? (a.h_prefix_q[a.X] - a.h_prefix_q[0]) / (double)a.X : 0.0;
+    long double acc = 0;
+    for (long i = 0; i < a.X; ++i) {
+        const double d = a.h_re[(size_t)i] - mean;
+        const double dq = a.cplx ? a.h_im[(size_t)i] - mean_q : 0.0;
+        acc += (long double)(d * d + dq * dq);
+    }
+    const double var = (double)(acc / (long double)(a.X - 1));
+    const double sigPower = std::sqrt(var * (double)a.X);
+    for (int pi = 0; pi < P; ++pi) {
+        res[pi].denom = sigPower;
+        if (res[pi].codePhase + a.spc - 1 > a.n_samples) res[pi].codePhase -= a.spc;  // :239-241
+    }
+    return BDS_OK;
+}
 
-        jobs.clear();
-        std::vector<std::vector<long>> lags(P);
-        for (int pi = 0; pi < P; ++pi) {
-            float M = -1.f;
-            for (int t = 0; t < pl.ntiles; ++t) M = std::max(M, r2[(size_t)pi * pl.ntiles + t].v);
-            const float thr = (float)((1.0 - kDelta) * (double)M);
-            std::set<long> ls;
-            auto inrange = [&](long l) {
-                return (l >= rng[pi][0] && l <= rng[pi][1]) || (l >= rng[pi][2] && l <= rng[pi][3]);
-            };
-            for (int t = 0; t < pl.ntiles; ++t) {
-                const Rec &r = r2[(size_t)pi * pl.ntiles + t];
-                if (r.lag < 0 || r.v < thr) continue;
+// second peak in the winning bin, outside +-2 chips and within +-1 code (B2a/acquisition.m:224-249)
+// (one cell per PRN, a single round of workgroups: the tile kernel with its per-tile records serves this pass; the
+//  wave-private kernel's running bounds have nothing to run on)
+int AcqRun::second_peak_b2a() {
+    Plan2D &pl = a.plan;
+    int rc;
+    so.cellmax = nullptr;
+    so.lb = nullptr;
+    const long s2c = (long)std::ceil(s->samplingFreq / s->codeFreqBasis) * 2;  // samples2CodeChip :137
+    std::vector<std::array<long, 4>> rng(P);
+    if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * pl.ntiles))) return rc;
+    so.recs = a.d_recs;
+    // specialised kernels: all PRNs' (PRN, winning bin) cells in one launch pair through a cell list
+    // (63 tiny launch pairs were ~1 ms of the 2.7 ms refinement at cfg2)
+    const size_t cap_cells = a.bw_cap / (size_t)pl.L * 8 / elem / (size_t)ncomp;  // cells the work buffer holds
+    const bool batched = fsearch && (size_t)P <= cap_cells;
+    BDS_HIP(ctx, hipMemsetAsync(a.d_extra_count, 0, sizeof(int), stream()));  // overflow list of this pass: cell = PRN index
+    std::vector<int> h_bin(P);
+    std::vector<long> h_cs(P);
+    std::vector<int4> h_rng(P);
+    for (int pi = 0; pi < P; ++pi) {
+        const long cp = res[pi].codePhase;
+        const long e1 = cp - s2c, e2 = cp + s2c, e3 = cp - a.spc + s2c, e4 = cp + a.spc - s2c;
+        long lo1 = 1, hi1 = 0, lo2 = 1, hi2 = 0;  // 1-based inclusive, empty when lo > hi
+        if (e1 >= 1) lo1 = std::max<long>(1, e3), hi1 = e1;
+        if (e2 < a.N) lo2 = e2, hi2 = std::min<long>(e4, a.N);
+        rng[pi] = {lo1 - 1, hi1 - 1, lo2 - 1, hi2 - 1};  // 0-based
+        if (hi1 < lo1 && hi2 < lo2)
+            return fail(ctx, BDS_ERR_ARG, "PRN %d: empty second-peak range (acquisition.m:248 would fail)", prns[pi]);
+        h_bin[pi] = res[pi].fbin - 1;
+        h_cs[pi] = (long)a.cs_slot[prns[pi]] * ncomp * pl.L;
+        h_rng[pi] = make_int4((int)rng[pi][0], (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3]);
+        if (!batched)
+            launch_cells(prns[pi], res[pi].fbin - 1, 1, a.d_recs + (size_t)pi * pl.ntiles, (int)rng[pi][0],
+                         (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3], pi, nullptr);
+    }
+    if (batched && P > 0) {
+        const size_t nb_ = sizeof(int) * P + sizeof(long) * P + sizeof(int4) * P + 64;
+        if ((rc = ensure(ctx, &a.d_cells, &a.cells_cap, nb_))) return rc;
+        int4 *d_rng = (int4 *)a.d_cells;                       // 16-byte aligned first
+        long *d_cs = (long *)(d_rng + P);
+        int *d_bin = (int *)(d_cs + P);
+        BDS_HIP(ctx, hipMemcpyAsync(d_rng, h_rng.data(), sizeof(int4) * P, hipMemcpyHostToDevice, stream()));
+        BDS_HIP(ctx, hipMemcpyAsync(d_cs, h_cs.data(), sizeof(long) * P, hipMemcpyHostToDevice, stream()));
+        BDS_HIP(ctx, hipMemcpyAsync(d_bin, h_bin.data(), sizeof(int) * P, hipMemcpyHostToDevice, stream()));
+        const CellList cl{d_bin, d_cs, d_rng};
+        launch_list(P, a.d_recs, cl, 0, nullptr);
+    }
+    BDS_HIP(ctx, hipGetLastError());
+    std::vector<Rec> r2((size_t)P * pl.ntiles);
+    int n_extra2 = 0;
+    BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, stream()));
+    BDS_HIP(ctx, hipMemcpyAsync(&n_extra2, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    BDS_HIP(ctx, hipStreamSynchronize(stream()));
+    if (n_extra2 > kExtraCap && a.half) return redo(kRedoFp32, "overflow list of the second-peak pass ran over at the fp16-storage tolerance");
+    if (n_extra2 > kExtraCap && !a.no_fast_search) return redo(kRedoPlain, "overflow list of the second-peak pass ran over");
+    std::vector<Extra> h_extra2((size_t)std::min(n_extra2, kExtraCap));
+    if (!h_extra2.empty()) {
+        BDS_HIP(ctx, hipMemcpyAsync(h_extra2.data(), a.d_extra, sizeof(Extra) * h_extra2.size(), hipMemcpyDeviceToHost, stream()));
+        BDS_HIP(ctx, hipStreamSynchronize(stream()));
+    }
+
+    std::vector<CorrJob> jobs;
+    std::vector<std::vector<long>> lags(P);
+    for (int pi = 0; pi < P; ++pi) {
+        float M = -1.f;
+        for (int t = 0; t < pl.ntiles; ++t) M = std::max(M, r2[(size_t)pi * pl.ntiles + t].v);
+        const float thr = (float)((1.0 - kDelta) * (double)M);
+        std::set<long> ls;
+        auto inrange = [&](long l) {
+            return (l >= rng[pi][0] && l <= rng[pi][1]) || (l >= rng[pi][2] && l <= rng[pi][3]);
+        };
+        for (int t = 0; t < pl.ntiles; ++t) {
+            const Rec &r = r2[(size_t)pi * pl.ntiles + t];
+            if (r.lag < 0 || r.v < thr) continue;
+            for (long dl = -1; dl <= 1; ++dl)
+                if (inrange(r.lag + dl)) ls.insert(r.lag + dl);
+        }
+        for (const Extra &e : h_extra2)
+            if (e.cell == pi && e.lag >= 0 && !(e.v < thr))
                 for (long dl = -1; dl <= 1; ++dl)
-                    if (inrange(r.lag + dl)) ls.insert(r.lag + dl);
+                    if (inrange(e.lag + dl)) ls.insert(e.lag + dl);
+        lags[pi].assign(ls.begin(), ls.end());
+        for (long l : lags[pi])
+            for (int comp = 0; comp < ncomp; ++comp) {
+                CorrJob j{};
+                j.start = l;
+                j.len = a.X;
+                j.freq = bin_freq(res[pi].fbin - 1);
+                j.slot = (prns[pi] - 1) * 2 + comp;
+                j.circ = 1;
+                j.mode = 0;
+                jobs.push_back(j);
             }
-            for (const Extra &e : h_extra2)
-                if (e.cell == pi && e.lag >= 0 && !(e.v < thr))
-                    for (long dl = -1; dl <= 1; ++dl)
-                        if (inrange(e.lag + dl)) ls.insert(e.lag + dl);
-            lags[pi].assign(ls.begin(), ls.end());
-            for (long l : lags[pi])
-                for (int comp = 0; comp < ncomp; ++comp) {
-                    CorrJob j{};
-                    j.start = l;
-                    j.len = a.X;
-                    j.freq = bin_freq(res[pi].fbin - 1);
-                    j.slot = (prns[pi] - 1) * 2 + comp;
-                    j.circ = 1;
-                    j.mode = 0;
-                    jobs.push_back(j);
-                }
-        }
-        if ((rc = run_jobs(ctx, a, *s, jobs, jout))) return rc;
-        size_t k = 0;
-        for (int pi = 0; pi < P; ++pi) {
-            double second = -1;
-            for (size_t i = 0; i < lags[pi].size(); ++i, k += ncomp) second = std::max(second, combine(a, &jout[k]));
-            res[pi].denom = second;
-        }
     }
+    std::vector<double2> jout;
+    if ((rc = run_jobs(ctx, a, *s, jobs, jout))) return rc;
+    size_t k = 0;
+    for (int pi = 0; pi < P; ++pi) {
+        double second = -1;
+        for (size_t i = 0; i < lags[pi].size(); ++i, k += ncomp) second = std::max(second, combine(a, &jout[k]));
+        res[pi].denom = second;
+    }
+    return BDS_OK;
+}
 
-    // ---- threshold + fine-Doppler search ---------------------------------------------------
-    jobs.clear();
+// ---- threshold + fine-Doppler search ---------------------------------------------------
+int AcqRun::fine_search() {
+    int rc;
+    std::vector<CorrJob> jobs;
     std::vector<int> fine_of(P, -1);
     int nfine = 0;
     std::vector<std::vector<double>> fine_frq(P);
@@ -1608,44 +1663,49 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         }
         fine_of[pi] = 1;
     }
+    std::vector<double2> jout;
     if ((rc = run_jobs(ctx, a, *s, jobs, jout))) return rc;
-    {
-        size_t k = 0;
-        for (int pi = 0; pi < P; ++pi) {
-            if (fine_of[pi] < 0) continue;
-            double best = -1;
-            int kbest = 0;
-            for (int kf = 0; kf < nfine; ++kf) {
-                double v;
-                if (a.signal == BDS_SIGNAL_B1C) {
-                    v = cabs2(jout[k]);
-                    if (ncomp == 2) v = (v * 11 + cabs2(jout[k + 1]) * 29) / 40;  // :291-292
-                    k += ncomp;
-                } else {
-                    double sd = 0, sp = 0;
-                    for (int seg = 0; seg < s->fineNoncoh; ++seg, k += 2) sd += cabs2(jout[k]), sp += cabs2(jout[k + 1]);
-                    v = sd + sp;  // :321
-                }
-                if (v > best) best = v, kbest = kf;
+    size_t k = 0;
+    for (int pi = 0; pi < P; ++pi) {
+        if (fine_of[pi] < 0) continue;
+        double best = -1;
+        int kbest = 0;
+        for (int kf = 0; kf < nfine; ++kf) {
+            double v;
+            if (a.signal == BDS_SIGNAL_B1C) {
+                v = cabs2(jout[k]);
+                if (ncomp == 2) v = (v * 11 + cabs2(jout[k + 1]) * 29) / 40;  // :291-292
+                k += ncomp;
+            } else {
+                double sd = 0, sp = 0;
+                for (int seg = 0; seg < s->fineNoncoh; ++seg, k += 2) sd += cabs2(jout[k]), sp += cabs2(jout[k + 1]);
+                v = sd + sp;  // :321
             }
-            double cf = fine_frq[pi][kbest];
-            if (cf == 0) cf = 1;  // :333-335
-            carrFreq[prns[pi] - 1] = cf;
-            codePhase[prns[pi] - 1] = (double)res[pi].codePhase;
-            if (a.rs.on) {
-                // results back at the original sampling rate (B2a/acquisition.m:339-356, B1C :311-328)
-                codePhase[prns[pi] - 1] = std::floor((double)(res[pi].codePhase - 1) / s->samplingFreq * a.rs.old_fs) + 1;
-                double doppler;
-                if (s->IF >= s->samplingFreq / 2)
-                    doppler = (s->samplingFreq - s->IF) - cf;
-                else
-                    doppler = cf - s->IF;
-                carrFreq[prns[pi] - 1] = doppler + a.rs.old_if;
-            }
-            if (detected) detected[prns[pi] - 1] = 1;
+            if (v > best) best = v, kbest = kf;
         }
+        double cf = fine_frq[pi][kbest];
+        if (cf == 0) cf = 1;  // :333-335
+        carrFreq[prns[pi] - 1] = cf;
+        codePhase[prns[pi] - 1] = (double)res[pi].codePhase;
+        if (a.rs.on) {
+            // results back at the original sampling rate (B2a/acquisition.m:339-356, B1C :311-328)
+            codePhase[prns[pi] - 1] = std::floor((double)(res[pi].codePhase - 1) / s->samplingFreq * a.rs.old_fs) + 1;
+            double doppler;
+            if (s->IF >= s->samplingFreq / 2)
+                doppler = (s->samplingFreq - s->IF) - cf;
+            else
+                doppler = cf - s->IF;
+            carrFreq[prns[pi] - 1] = doppler + a.rs.old_if;
+        }
+        if (detected) detected[prns[pi] - 1] = 1;
     }
-    BDS_HIP(ctx, hipEventRecord(ev3, st(ctx)));
+    return BDS_OK;
+}
+
+int AcqRun::finish() {
+    Plan2D &pl = a.plan;
+    const Tuning &tune = ctx->tune;
+    BDS_HIP(ctx, hipEventRecord(ev3, stream()));
     BDS_HIP(ctx, hipEventSynchronize(ev3));
     for (int pi = 0; pi < P; ++pi) a.last[prns[pi]] = res[pi];
 
@@ -1675,7 +1735,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
     t.cols_ms = nsamp && mids ? acc_c / nsamp : 0;
     t.n_extra = a.n_extra_last;
     t.shader_clock_GHz = 0;
-    if (ctx->tune.clockprobe && pl.d_clk) {  // sampled workgroups of the wave-private passes: shader-clock over reference-clock ticks
+    if (tune.clockprobe && pl.d_clk) {  // sampled workgroups of the wave-private passes: shader-clock over reference-clock ticks
         unsigned long long h[4];
         int wall_khz = 0;
         BDS_HIP(ctx, hipMemcpy(h, pl.d_clk, sizeof(h), hipMemcpyDeviceToHost));
@@ -1703,6 +1763,68 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         t.kernel_flags = (ilv_on ? 1 : 0) | (wrows_on && tune.pk != 0 ? 2 : 0);
     }
     return BDS_OK;
+}
+
+// one attempt of bds_acq_run with the storage / kernels the context is set to; kRedoFp32 / kRedoPlain: see above
+int acq_run_once(bds_ctx *ctx, const bds_settings *s_in, const int32_t *prn_list, int n_prn, int max_prn, double *carrFreq,
+                 double *codePhase, double *peakMetric, int32_t *detected, std::string *why) {
+    if (int rc0 = check_settings(ctx, *s_in)) return rc0;  // (the resampling band edges are only visible here)
+    bds_settings eff;
+    const bds_settings *s = effective(s_in, &eff);
+    int rc = acq_configure(ctx, *s);
+    if (rc) return rc;
+    AcqState &a = *ctx->acq;
+    if (!a.d_sig || a.n_samples < a.N) return fail(ctx, BDS_ERR_ARG, "bds_acq_run: no IF block loaded (bds_acq_load)");
+    if (a.rs.on != resample_plan(*s_in).on || (a.rs.on && a.rs.new_fs != s->samplingFreq))
+        return fail(ctx, BDS_ERR_ARG, "bds_acq_run: the loaded block was conditioned for different resampling settings");
+    if ((rc = bds_acq_prepare(ctx, s))) return rc;
+    AcqRun r(ctx, a, s);
+    if (prn_list && n_prn > 0)
+        r.prns.assign(prn_list, prn_list + n_prn);
+    else
+        r.prns.assign(s->acqSatelliteList, s->acqSatelliteList + s->n_acq);
+    int list_max = 0;
+    for (int i = 0; i < s->n_acq; ++i) list_max = std::max(list_max, (int)s->acqSatelliteList[i]);
+    if (max_prn < list_max) return fail(ctx, BDS_ERR_ARG, "max_prn %d < max(acqSatelliteList) %d", max_prn, list_max);
+    for (int p : r.prns)
+        if (!a.cs_slot.count(p)) return fail(ctx, BDS_ERR_ARG, "PRN %d of the shard is not in settings.acqSatelliteList", p);
+    for (int i = 0; i < max_prn; ++i) {
+        carrFreq[i] = codePhase[i] = peakMetric[i] = 0.0;  // acquisition.m:161-165
+        if (detected) detected[i] = 0;
+    }
+    r.carrFreq = carrFreq, r.codePhase = codePhase, r.peakMetric = peakMetric, r.detected = detected;
+    if ((rc = r.setup())) return rc;
+    if ((rc = r.forward_all())) return rc;
+    if ((rc = r.search())) return rc;
+    if (!(rc = r.collect()) && !(rc = r.refine()) && !(rc = a.signal == BDS_SIGNAL_B1C ? r.metric_b1c() : r.second_peak_b2a()) &&
+        !(rc = r.fine_search()))
+        rc = r.finish();
+    if (rc == kRedoFp32 || rc == kRedoPlain) *why = r.why;
+    return rc;
+}
+
+}  // namespace
+}  // namespace bds
+
+extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t *prn_list, int n_prn, int max_prn,
+                           double *carrFreq, double *codePhase, double *peakMetric, int32_t *detected) {
+    if (!ctx || !s_in || !carrFreq || !codePhase || !peakMetric) return BDS_ERR_ARG;
+    // at most three attempts: fp16 storage -> fp32 storage -> run-time-plan kernels
+    for (int attempt = 0;; ++attempt) {
+        std::string why;
+        const int rc = acq_run_once(ctx, s_in, prn_list, n_prn, max_prn, carrFreq, codePhase, peakMetric, detected, &why);
+        if (rc != kRedoFp32 && rc != kRedoPlain) return rc;
+        if (attempt >= 2) return fail(ctx, BDS_ERR_UNSUPPORTED, "bds_acq_run: the search could not be completed (%s)", why.c_str());
+        AcqState &a = *ctx->acq;
+        const bool plain_kernels = rc == kRedoPlain;
+        if (ctx->tune.verbose) fprintf(stderr, "[bds] search re-run (%s): %s\n", plain_kernels ? "run-time-plan kernels" : "fp32 storage", why.c_str());
+        a.half = false;
+        a.no_fast_search = a.no_fast_search || plain_kernels;
+        a.sC = 1.f;
+        a.cs_slot.clear();
+        // (the flags stay until the configuration changes: acq_configure keeps them for the same key)
+        if (int rc2 = bds_acq_prepare(ctx, s_in)) return rc2;
+    }
 }
 
 #ifdef BDS_EXP_PHASES

@@ -265,7 +265,10 @@ extern "C" int bds_pre_run_device(bds_ctx *ctx, const bds_settings *s, int max_p
                                   const double *codePhase, const double *peakMetric, bds_channel *channel) {
     if (!ctx || !s || !carrFreq || !codePhase || !peakMetric || !channel || max_prn < 1 || max_prn > BDS_MAX_PRN) return BDS_ERR_ARG;
     const int nch = s->numberOfChannels;
-    if (nch < 1 || nch > 64) return bds::fail(ctx, BDS_ERR_ARG, "numberOfChannels = %d outside 1..64", nch);
+    if (nch < 1) return bds::fail(ctx, BDS_ERR_ARG, "numberOfChannels = %d < 1", nch);
+    // (the kernel is one wave: it fills up to 64 channels -- one more than there are PRNs; a larger table is filled by the
+    //  host loop, which produces the same bits)
+    if (nch > 64) return bds_pre_run(s, max_prn, carrFreq, codePhase, peakMetric, channel);
     BDS_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)ctx->stream;
     double *d_in = nullptr;

@@ -152,7 +152,11 @@ extern "C" bds_multi *bds_multi_create(int n_devices, const int *device_ids) {
     // Test hook BDS_MULTI_TEST_ALIAS=1 (a one-GPU box): device ids may repeat / wrap round the visible devices, so that the
     // thread-per-device partition, the concurrent contexts and the reassembly run with n > 1; RCCL refuses two ranks on
     // one device, so the exchange of such a handle is the same sum taken on the host.
-    const bool alias = std::getenv("BDS_MULTI_TEST_ALIAS") != nullptr;
+    // (only the exact value "1" arms it, and it says so on stderr: a deployment that merely inherits the variable gets the
+    //  duplicate-device check and RCCL as usual)
+    const char *alias_env = std::getenv("BDS_MULTI_TEST_ALIAS");
+    const bool alias = alias_env && std::strcmp(alias_env, "1") == 0;
+    if (alias) fprintf(stderr, "[bds] BDS_MULTI_TEST_ALIAS=1: test hook active -- repeated device ids accepted, exchange summed on the host instead of RCCL\n");
     if (n_devices <= 0) n_devices = n;  // all visible devices
     if (n_devices > n && !device_ids && !alias) {
         mfail(nullptr, BDS_ERR_ARG, "bds_multi_create: " + std::to_string(n_devices) + " devices requested, " + std::to_string(n) + " visible");

@@ -281,7 +281,8 @@ BDS_API int bds_pre_run(const bds_settings *s, int max_prn, const double *carrFr
                         const double *codePhase, const double *peakMetric, bds_channel *channel);
 /* The same allocation as a device kernel (stable descending rank of peakMetric by counting, one wave): replaces the host
  * loop of include/preRun.m:61-76 (either receiver) when acquisition and tracking are chained inside the library; `channel` (host,
- * numberOfChannels entries) receives a copy.  Bit-identical to bds_pre_run. */
+ * numberOfChannels entries) receives a copy.  Bit-identical to bds_pre_run; settings.numberOfChannels > 64 (more channels than
+ * PRNs: the extra ones stay idle) is served by the host loop. */
 BDS_API int bds_pre_run_device(bds_ctx *ctx, const bds_settings *s, int max_prn, const double *carrFreq,
                                const double *codePhase, const double *peakMetric, bds_channel *channel);
 /* acquisition -> preRun -> tracking in ONE call (B2a/postProcessing.m:100-123, B1C/postProcessing.m:105-143 without the

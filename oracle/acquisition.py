@@ -237,38 +237,6 @@ def b1c_coarse_rows(long_signal, settings, prn, bins=None):
         yield b, row
 
 
-def coarse_rows_batched(long_signal, settings, prn, bins, workers=1):
-    """rows[k, :] = results(bins[k], :) of B1C/acquisition.m:191-222 / B2a/acquisition.m:187-211 for several Doppler bins at
-    once: the same arithmetic as b1c_coarse_rows / b2a_coarse_rows, row for row, on 2-D arrays so that scipy.fft spreads the
-    independent rows over `workers` threads (a single 1-D transform does not parallelise).  Used by the CPU baseline of
-    bench.py (all host cores) and checked against the generators in tests/test_oracle_codes.py."""
-    b1c = str(settings.signal).upper() == "B1C"
-    if b1c:
-        spc, x_len, n = _b1c_sizes(settings)
-        data_tab = codes.make_data_table(settings, prn)[:x_len]
-        pilot_tab = codes.make_pilot_table(settings, prn)[:x_len] if settings.pilotACQflag == 1 else None
-    else:
-        spc = codes.samples_per_code(settings)
-        x_len, n = spc, 2 * spc
-        data_tab = codes.make_b2a_data_table(prn, settings)
-        pilot_tab = codes.make_b2a_pilot_table(prn, settings)
-    sig = np.asarray(long_signal[:n])
-    ts = 1.0 / settings.samplingFreq
-    phase_points = np.arange(n, dtype=np.float64) * 2 * np.pi * ts
-    cd = np.conj(sfft.fft(np.concatenate([data_tab, np.zeros(n - x_len)])))
-    cp = None if pilot_tab is None else np.conj(sfft.fft(np.concatenate([pilot_tab, np.zeros(n - x_len)])))
-    frq = freq_bins(settings)[np.asarray(list(bins), dtype=np.int64)]
-    carr = np.exp(1j * frq[:, None] * phase_points[None, :])
-    x = sfft.fft(carr * sig[None, :], axis=1, workers=workers)
-    rd = np.abs(sfft.ifft(x * cd[None, :], axis=1, workers=workers))
-    if cp is None:
-        return rd
-    rp = np.abs(sfft.ifft(x * cp[None, :], axis=1, workers=workers))
-    if b1c:
-        return (rd * np.sqrt(11) + rp * np.sqrt(29)) / np.sqrt(40)
-    return rd + rp
-
-
 def acquisition_b1c(long_signal, settings, diag=None):
     """acqResults = acquisition(longSignal, settings)   (B1C/acquisition.m:1)."""
     long_signal, settings, old = resample_condition(long_signal, settings)

@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
-FAST = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-tracking", "--no-fast-path"]
+FAST = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-tracking", "--no-strict-f32"]
 
 
 def run_bench(args, extra_env=None, timeout=900):
@@ -68,6 +68,11 @@ def test_joint_workload_at_full_size_is_bit_equal_to_the_single_signal_runs():
     one rank, and two ranks (LPT shards, one exchange per signal) sharing the one GPU of the box over gloo.  acqResults of
     each signal must be the bits of that signal's own single-device run (zero-filled shards summed: x + 0)."""
     b1c = run_bench(["--workload", "b1c"] + FAST)
+    # (the default B1C run also times cfg2 -- extra key `b2a` -- and labels its kernels from the plan)
+    assert b1c["b2a"]["ms_per_step"] > 0 and b1c["b2a"]["satellites_detected"] == b1c["b2a"]["satellites_injected"]
+    assert "k_rows_inv_f<1280>" in b1c["b2a"]["kernel"] and "k_rows_wave_f<4096>" in b1c["roofline"]["kernel"]
+    for k in ("frac_strict_f32", "frac_at_stored_bytes", "traffic_source"):
+        assert k in b1c["roofline"], k
     b2a = run_bench(["--workload", "b2a"] + FAST)
     want = {"b1c": b1c["config"]["results_sha256"]["b1c"], "b2a": b2a["config"]["results_sha256"]["b2a"]}
     one = run_bench(["--workload", "joint"] + FAST)
