@@ -328,7 +328,7 @@ struct AcqState {
     std::vector<double> h_prefix;         // prefix sums (DC means; integers below 2^53 for int8 data)
     std::vector<double> h_prefix_q;       // ... of the imaginary part
     bool cplx = false;              // longSignal = I + 1i*Q (postProcessing.m:92-96)
-    SampleView sview() const { return SampleView{skind >= kF64 ? (const void *)d_sig64 : (const void *)d_sig, skind}; }
+    SampleView sview() const { return SampleView{skind >= kF64 ? (const void *)d_sig64 : (const void *)d_sig, skind, n_samples}; }
     int8_t *d_prim = nullptr;       // [63][2][code_len]
     float2 *d_Cs = nullptr;         // [slots][ncomp][L]
     size_t cs_cap_slots = 0;
@@ -1903,3 +1903,5 @@ extern "C" int bds_acq_peaks(bds_ctx *ctx, int max_prn, double *peak, double *de
     }
     return BDS_OK;
 }
+
+BDS_DEBUG_TU_READER(bds_debug_failures_acq)

@@ -84,6 +84,7 @@ struct CodeTable {
         long idx = (long)ceil((ts * (double)(n + 1)) / tc);  // 1-based chip / half-chip index
         if (n == spc - 1) idx = boc ? 2L * code_len : code_len;
         if (boc && n == 0) idx = 1;
+        BDS_DASSERT(slot >= 0 && slot < 2 * BDS_MAX_PRN && idx >= 1 && idx <= (boc ? 2L : 1L) * code_len);
         const int8_t *c = prim + (long)slot * code_len;
         if (boc) {
             const long h = idx - 1;
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(256) void k_make_code(CodeTable tab, int slot, int 
             cv = tab.value(slot, n);
         } else {
             const long ci = (long)floor((tab.ts * (double)(n + 1)) / tab.tc);
+            BDS_DASSERT(ci >= 0 && slot >= 0 && slot < 2 * BDS_MAX_PRN);
             cv = (float)tab.prim[(long)slot * tab.code_len + (ci % tab.code_len)];
         }
         out[n] = (int8_t)cv;
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
             }
             t = a;
         }
+        BDS_DASSERT(n >= 0 && (jb.mode ? jb.code_k0 + n : n) < code_stride && jb.slot >= 0 && jb.slot < 2 * BDS_MAX_PRN);
         const int8_t cv = codes[cbase + n];
         const double2 xv = sig.load(a);
         const double x = (xv.x - jb.mean) * (double)cv;

@@ -457,6 +457,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
                     const unsigned long long mask = __builtin_amdgcn_ballot_w64(a >= thr);
                     if (a >= thr) {
                         const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        BDS_DASSERT(idx >= 0 && lag_at(k) >= 0 && (long)lag_at(k) < L && cell >= A.cell0 && cell < A.cell0 + A.G);
                         if (idx < A.extra_cap) {
                             Extra ex;
                             ex.v = a;

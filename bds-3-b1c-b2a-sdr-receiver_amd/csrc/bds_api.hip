@@ -332,3 +332,12 @@ extern "C" int bds_pre_run(const bds_settings *s, int max_prn, const double *car
     }
     return BDS_OK;
 }
+
+#ifdef BDS_DEBUG
+// debug build only (csrc/bds_debug.h): failed device-side bounds checks since the last call, all translation units
+extern "C" unsigned int bds_debug_failures_acq();
+extern "C" unsigned int bds_debug_failures_track();
+extern "C" __attribute__((visibility("default"))) unsigned int bds_debug_failures(void) {
+    return bds_debug_failures_acq() + bds_debug_failures_track();
+}
+#endif

@@ -5,6 +5,7 @@
 // (real, or interleaved complex for a fileType-2 record) and the search kernels read it through
 // the same SampleView as the raw int8 block.
 #pragma once
+#include "bds_debug.h"
 
 #include <hip/hip_runtime.h>
 
@@ -22,7 +23,9 @@ enum SampleKind : int { kS8 = 0, kS8C = 1, kF64 = 2, kF64C = 3 };
 struct SampleView {
     const void *p;
     int kind;
+    long n = 0;  // samples behind p (debug build: bound of every load; 0 = unknown)
     __device__ __forceinline__ double2 load(long m) const {
+        BDS_DASSERT(m >= 0 && (n == 0 || m < n));
         switch (kind) {
             case kS8: return make_double2((double)reinterpret_cast<const int8_t *>(p)[m], 0.0);
             case kS8C: {

@@ -27,6 +27,7 @@
 #include <functional>
 #include <type_traits>
 
+#include "bds_debug.h"
 #include "bds_internal.h"
 
 namespace bds {
@@ -88,12 +89,14 @@ static constexpr int kTabPad = 32;
 static constexpr long kTabStride = 122880;  // >= 12 * 10230 + 2 * kTabPad, multiple of 64
 __device__ __forceinline__ float tab_at(const int8_t *__restrict__ tab, int n_units, int i1) {
     int j = i1 + (kTabPad - 2);  // unit index i1 - 2, shifted by the left padding
+    BDS_DASSERT(j >= 0 && j <= n_units + 2 * kTabPad - 1);  // (the clamp below is a guard, never the intended look-up)
     j = max(0, min(j, n_units + 2 * kTabPad - 1));
     return (float)tab[j];
 }
 // data and pilot codes are read at the same index: slot 0 of a PRN holds them interleaved
 __device__ __forceinline__ char2 tab2_at(const int8_t *__restrict__ tab, int n_units, int i1) {
     int j = i1 + (kTabPad - 2);
+    BDS_DASSERT(j >= 0 && j <= n_units + 2 * kTabPad - 1);
     j = max(0, min(j, n_units + 2 * kTabPad - 1));
     return reinterpret_cast<const char2 *>(tab)[j];
 }
@@ -145,6 +148,7 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
     const long k1 = min(g.blk, k0 + p.chunk);
     for (int k = (int)k0 + (int)threadIdx.x; k < (int)k1; k += (int)blockDim.x) {  // blksize < 2^31
         float raw, raw_q = 0.f;
+        BDS_DASSERT(g.pos + k >= p.base && g.pos + k < p.win_end);  // inside the window of the record held in HBM
         if (p.cplx) {  // rawSignal = data(1:2:end) + 1i*data(2:2:end)  (tracking.m:242-246)
             const char2 v = reinterpret_cast<const char2 *>(dwin)[g.pos + k];
             raw = (float)v.x;
@@ -346,6 +350,7 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
     auto fetch = [&](long kw) {
         const long kb = kw + (long)lane * SEG;
         if (kb < g.blk) {
+            BDS_DASSERT(g.pos + kb >= p.base && g.pos + kb < p.win_end);  // first sample of the segment inside the window held in HBM
             const uintptr_t a = (uintptr_t)(dwin + (g.pos + kb) * coeff);
             const uint32_t *__restrict__ q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
 #pragma unroll
@@ -464,7 +469,10 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
             // B1C: ~21 half-chip steps per replica and pass -- one lane per (replica, step), the three replicas laid
             // end to end (63-66 items: one iteration as a rule), instead of three searches on a third of the lanes
             const int lo = lo1;
-            auto at1 = [&](int i1) -> char2 { return use1 ? s_t1[i1 - lo] : tab2_at(prim_d, NU, i1); };
+            auto at1 = [&](int i1) -> char2 {
+                BDS_DASSERT(!use1 || (i1 - lo >= 0 && i1 - lo < kCap1));  // inside the table slice staged in LDS
+                return use1 ? s_t1[i1 - lo] : tab2_at(prim_d, NU, i1);
+            };
             const int n0 = ub1[0] - ua1[0], n1 = ub1[1] - ua1[1], n2 = ub1[2] - ua1[2];
             for (int r = lane; r < n0 + n1 + n2; r += 64) {
                 const int ph = r < n0 ? 0 : r < n0 + n1 ? 1 : 2;
@@ -505,7 +513,10 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
         } else
         {  // code (and pilot code) at the look-up's own resolution: E, P, L steps of one rank together
             const int lo = lo1;
-            auto at1 = [&](int i1) -> char2 { return use1 ? s_t1[i1 - lo] : tab2_at(prim_d, NU, i1); };
+            auto at1 = [&](int i1) -> char2 {
+                BDS_DASSERT(!use1 || (i1 - lo >= 0 && i1 - lo < kCap1));  // inside the table slice staged in LDS
+                return use1 ? s_t1[i1 - lo] : tab2_at(prim_d, NU, i1);
+            };
             const int nmax = max(ub1[0] - ua1[0], max(ub1[1] - ua1[1], ub1[2] - ua1[2]));
             for (int r = lane; r < nmax; r += 64) {
                 int kk[3], uu[3];
@@ -556,7 +567,10 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
         }
         if (MODE == BDS_TRACK_WB && pilot) {  // pilotBOC61(ceil(tcode*6)+1)  (WB_tracking.m:298,311,324)
             const int lo = lo6;
-            auto at6 = [&](int i1) -> float { return use6 ? (float)s_t6[i1 - lo] : tab_at(prim_p, n6, i1); };
+            auto at6 = [&](int i1) -> float {
+                BDS_DASSERT(!use6 || (i1 - lo >= 0 && i1 - lo < kCap6));
+                return use6 ? (float)s_t6[i1 - lo] : tab_at(prim_p, n6, i1);
+            };
             const int nmax = max(ub6[0] - ua6[0], max(ub6[1] - ua6[1], ub6[2] - ua6[2]));
             for (int r = lane; r < nmax; r += 64) {
                 int kk[3], uu[3];
@@ -1415,6 +1429,7 @@ extern "C" int bds_track_correlate(bds_ctx *ctx, const bds_settings *s, const in
     TrkParams p{};
     int rc = fill_params(ctx, *s, p, 1, n_bytes);
     if (rc) return rc;
+    p.base = 0, p.win_end = p.n_bytes;  // the whole block is resident (the bounds the debug build checks the loads against)
     if ((rc = ensure_prim(ctx, t, s->signal))) return rc;
     long max_blk = 0;
     for (int c = 0; c < n_ch; ++c) {
@@ -1449,3 +1464,5 @@ extern "C" int bds_track_correlate(bds_ctx *ctx, const bds_settings *s, const in
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
     return BDS_OK;
 }
+
+BDS_DEBUG_TU_READER(bds_debug_failures_track)

@@ -165,6 +165,15 @@ def lib():
     return L
 
 
+def debug_failures() -> int:
+    """Failed device-side bounds checks since the last call; 0 on the product build (only the debug build, BDS_DEBUG=1
+    ./build.sh, exports the counter) or when the library was never loaded."""
+    if _lib is None or not hasattr(_lib, "bds_debug_failures"):
+        return 0
+    _lib.bds_debug_failures.restype = C.c_uint
+    return int(_lib.bds_debug_failures())
+
+
 def pack_settings(s) -> Settings:
     """MATLAB-style settings struct -> bds_settings.  Every field of SURVEY.md Appendix D that the selected
     receiver's initSettings.m defines is REQUIRED (a missing or misspelt field is an error naming it, never a silent

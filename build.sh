@@ -1,20 +1,35 @@
 #!/bin/bash
 # Build libbds_mi355x.so (HIP, gfx950 only) in-tree.  hipcc cross-compiles without a GPU.
+#   BDS_DEBUG=1 ./build.sh   debug build -> libbds_mi355x_debug.so: device-side bounds asserts on every code-table / IF-window /
+#                            candidate-list index (csrc/bds_debug.h), -O2 -g; load it with BDS_LIB_PATH (tools/README.md)
+#   BDS_SAN=1 ./build.sh     host code under AddressSanitizer + UndefinedBehaviorSanitizer -> libbds_mi355x_san.so
+#                            (run the CPU suite with it: tools/run_sanitized.sh)
 set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 PKG="$ROOT/bds-3-b1c-b2a-sdr-receiver_amd"
 SRC="$PKG/csrc"
 OUT="$PKG/libbds_mi355x.so"
+BLD="$PKG/build"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+OPT="-O3"
+EXTRA=()
+LINK=()
+if [ "${BDS_DEBUG:-0}" = 1 ]; then
+    OUT="$PKG/libbds_mi355x_debug.so"; BLD="$PKG/build/debug"; OPT="-O2 -g"; EXTRA+=(-DBDS_DEBUG=1 -Wno-pass-failed)
+elif [ "${BDS_SAN:-0}" = 1 ]; then
+    OUT="$PKG/libbds_mi355x_san.so"; BLD="$PKG/build/san"; OPT="-O1 -g"
+    EXTRA+=(-Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer -Xarch_host -fno-sanitize-recover=undefined)
+    LINK+=(-fsanitize=address,undefined -shared-libsan)
+fi
 # -ffp-contract=off everywhere except the search (bds_acq.hip): the tracking NCO index
 # arithmetic must round exactly like the reference's a + k*d (two roundings), while the
 # fp32 transform butterflies want FMA contraction.
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden
-       -Wall -Wno-unused-result -I"$ROOT/include" -I"$SRC")
-mkdir -p "$PKG/build"
+FLAGS=(--offload-arch=gfx950 $OPT -std=c++17 -fPIC -fvisibility=hidden
+       -Wall -Wno-unused-result -I"$ROOT/include" -I"$SRC" "${EXTRA[@]}")
+mkdir -p "$BLD"
 objs=()
 for f in bds_codes.cpp bds_api.hip bds_acq.hip bds_track.hip bds_sync.hip bds_multi.hip; do
-    o="$PKG/build/${f%.*}.o"
+    o="$BLD/${f%.*}.o"
     # rebuild when the source or any header is newer than the object
     if [ ! -f "$o" ] || [ -n "$(find "$SRC/$f" "$SRC"/*.h "$ROOT/include"/*.h -newer "$o" 2>/dev/null)" ]; then
         echo "hipcc $f"
@@ -31,5 +46,5 @@ for f in bds_codes.cpp bds_api.hip bds_acq.hip bds_track.hip bds_sync.hip bds_mu
     fi
     objs+=("$o")
 done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT" -ldl -Wl,-rpath,/opt/rocm/lib
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT" -ldl -Wl,-rpath,/opt/rocm/lib "${LINK[@]}"
 echo "built $OUT"

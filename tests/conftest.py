@@ -18,3 +18,16 @@ def ctx():
     import bds_amd
 
     return bds_amd.get_context(0)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """On the debug build of the library (BDS_DEBUG=1 ./build.sh, loaded through BDS_LIB_PATH: tools/run_debug.sh) every
+    kernel checks its code-table / IF-window / candidate-list indices on the device: none may have failed."""
+    try:
+        from bds_amd import native
+    except Exception:  # noqa: BLE001
+        return
+    n = native.debug_failures()
+    if n:
+        print(f"\nBDS_DEBUG: {n} device-side bounds checks FAILED during this session (see the BDS_DASSERT lines above)")
+        session.exitstatus = 1
