@@ -3,8 +3,11 @@
     hipcc ... -S bds_acq.hip -o acq.s ; python tools/isa_mix.py acq.s > profiles/r03_valu_bound.txt
 Per kernel: VALU instructions by issue class (SIMD cycles per wave-instruction measured with tools/probe/valu_rate.hip:
 2 for v_fma/add/sub/mul/mov/and/xor f32/b32, 4 for v_pk_*, v_cvt_*, v_max*, v_cmp*, v_cndmask, v_dot2*, v_alignbit, v_lshl_add,
-v_mul_lo, v_perm, 8 for v_sqrt/v_rsq/v_rcp), LDS instructions (issue cost per wave measured there too: ds_read_b64 8,
-ds_write_b64 24 cycles; a ds_read2/ds_write2_b64 counts as two) and the resulting SIMD-cycles per wave and item."""
+v_mul_lo, v_perm, 8 for v_sqrt/v_rsq/v_rcp), LDS instructions (a ds_read2/ds_write2_b64 counts as two) priced three ways:
+  * marginal issue cost beside vector work, per SIMD with two waves on it (tools/probe/coissue.hip, profiles/r04_coissue.txt:
+    "16fma,w" 44.6 vs "16fma" 34.6 cycles per group per SIMD -> ds_write_b64 10, ds_read_b64 6.2 SIMD-cycles);
+  * time of the CU's LDS unit (profiles/r03_lds_pattern.txt: 6.5 CU-cycles per ds_write_b64, 2.1 per ds_read_b64);
+  * the additive round-3 figure (8 / 24 SIMD-cycles: the LDS unit's throughput expressed per SIMD), kept for comparison."""
 import collections
 import json
 import re
@@ -43,23 +46,27 @@ def report(name, body, lo, hi, items_note):
     n_valu = sum(valu.values())
     cyc_valu = sum(k * v for k, v in valu.items())
     cyc_lds = 8 * ds_r + 24 * ds_w
+    cyc_lds_marg = 6.2 * ds_r + 10.0 * ds_w
+    cyc_lds_unit = 2.1 * ds_r + 6.5 * ds_w  # CU-cycles
     print(f"== {name}  (ISA lines {lo}..{hi}: {items_note})")
     print(f"   VALU instructions {n_valu}: {valu[2]} x 2 cycles, {valu[4]} x 4, {valu[8]} x 8  ->  {cyc_valu} SIMD cycles, {cyc_valu / n_valu:.2f} per instruction")
-    print(f"   LDS  {ds_r} b64 reads x 8 + {ds_w} b64 writes x 24 cycles  ->  {cyc_lds} SIMD cycles;   {vm} global/buffer memory instructions")
+    print(f"   LDS  {ds_r} b64 reads + {ds_w} b64 writes: marginal issue cost {cyc_lds_marg:.0f} SIMD cycles (6.2 / 10), LDS-unit time {cyc_lds_unit:.0f} CU cycles (2.1 / 6.5), "
+          f"round-3 additive figure {cyc_lds} (8 / 24);   {vm} global/buffer memory instructions")
     top = sorted(((n, op) for op, n in c.items() if op.startswith(("v_", "ds_"))), reverse=True)[:14]
     print("   " + ", ".join(f"{op} {n}" for n, op in top))
-    return dict(valu_insts=n_valu, valu_cycles=cyc_valu, cycles_per_inst=cyc_valu / n_valu, lds_cycles=cyc_lds, class_counts={str(k): v for k, v in valu.items()})
+    return dict(valu_insts=n_valu, valu_cycles=cyc_valu, cycles_per_inst=cyc_valu / n_valu, lds_cycles=cyc_lds, lds_marginal_cycles=cyc_lds_marg,
+                lds_unit_cu_cycles=cyc_lds_unit, lds_reads=ds_r, lds_writes=ds_w, vmem_insts=vm, class_counts={str(k): v for k, v in valu.items()})
 
 
 def main():
     lines = open(sys.argv[1]).read().split("\n")
     out = {}
     # column pass: one tile (both components) per workgroup; everything up to the wave maximum is the hot part
-    b = kernel_body(lines, "k_cols_wave_fILi768ELi2ELb0E7__half2Li6E")
+    b = kernel_body(lines, "k_cols_wave_fILi768ELi2ELb0E7__half2Li6ELb1ELb1EE")
     hi = next(i for i, l in enumerate(b) if "v_readlane_b32" in l)
-    out["cols"] = report("k_cols_wave_f<768, 2, false, __half2, 6>", b, 0, hi, "one 768 x 8 tile, 2 components = 48 point-components per lane (each through phase A and phase B)")
+    out["cols"] = report("k_cols_wave_f<768, 2, false, __half2, 6, true, true>", b, 0, hi, "one 768 x 8 tile, 2 components = 48 point-components per lane (each through phase A and phase B)")
     # row pass: the per-cell loop (2 components of one 4096-point row on 256 threads)
-    rows_kernel = ("k_rows_wave_fILi2EE", "k_rows_wave_f<2>") if any("k_rows_wave_fILi2EE" in l for l in lines) else ("k_rows_inv_fILi4096ELi2E7__half2E", "k_rows_inv_f<4096, 2, __half2>")
+    rows_kernel = ("k_rows_wave_fILi2ELb1ELb1EE", "k_rows_wave_f<2, true, true>")
     b = kernel_body(lines, rows_kernel[0])
     # the cell loop = the innermost loop that holds the barriers: from its header label to its back-edge branch
     hdr = [(i, l.split(":")[0]) for i, l in enumerate(b) if l.startswith(".LBB") and "Depth=2" in l and "Loop" in l]

@@ -27,7 +27,7 @@ def counters(prefix):
 rn, r = counters("k_rows_")
 cn, c = counters(sys.argv[5] if len(sys.argv) > 5 else "k_cols_wave_f")
 total = 1024.0 * (2 * r["FETCH_SIZE"] + r["WRITE_SIZE"] + 2 * c["FETCH_SIZE"] + c["WRITE_SIZE"])
-out = {"workload": workload, "cells_per_pair": cells, "bytes_per_pair": total,
+out = {"workload": workload, "cells_per_pair": cells, "round": (sys.argv[6] if len(sys.argv) > 6 else "round 4"), "bytes_per_pair": total,
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_run.sh), avg per dispatch of {rn} + {cn} "
                  f"(one dispatch pair = {cells} (PRN, bin) cells); FETCH_SIZE doubled per the gfx950 correction "
                  f"(MI355X_MICROARCH.md, HBM); see {keep}",

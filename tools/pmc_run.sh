@@ -2,7 +2,7 @@
 # Collect PMC counters for a short B1C bench run, one rocprofv3 pass per counter set
 # (--pmc only: never combined with trace domains, see the gpurun rules).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="${BENCH_ARGS:---workload b1c --steps 1 --warmup 0 --no-cpu-baseline --no-tracking --no-strict-f32 --prns 2}"
+ARGS="${BENCH_ARGS:---workload b1c --steps 1 --warmup 0 --no-cpu-baseline --no-tracking --no-strict-f32 --no-b2a --prns 2}"
 i=0
 while read -r set; do
   [ -z "$set" ] && continue
