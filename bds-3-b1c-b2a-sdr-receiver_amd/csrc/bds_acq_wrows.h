@@ -141,11 +141,38 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
                 // reads back to back: a burst from all four waves queues on the LDS store path at ~40 cycles per write against
                 // ~20 spread out, tools/phases.py.)
                 C y[16], a[4][4], o[4];
+#ifndef BDS_ROWS_DOT2_BUILTIN  // (-DBDS_ROWS_DOT2_BUILTIN: the compiler builtin instead; rows 1.82 vs 1.78 ms per 201 cells)
+                // The products with the three-operand v_dot2_f32_f16 (addend 0 inline) in inline assembly: the builtin compiles to
+                // the accumulating v_dot2c_f32_f16 behind a v_mov 0 per result (64 moves per cell).  The compiler does not know
+                // these are dot instructions, so the hazard it would pad -- 3 wait states between a dot's write and another
+                // vector instruction's read -- is closed by hand: four products per block, s_nop 2 at its end.
+#pragma unroll
+                for (int q = 0; q < 16; q += 4) {
+                    uint32_t xs[4], xc[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xs[i] = __builtin_amdgcn_alignbit(xn[q + i], xn[q + i], 16);  // (xi, xr)
+                        xc[i] = xn[q + i] ^ 0x80000000u;                               // (xr, -xi)
+                    }
+                    float re[4], im[4];
+                    asm volatile(
+                        "v_dot2_f32_f16 %0, %8, %16, 0\n v_dot2_f32_f16 %4, %12, %16, 0\n"
+                        "v_dot2_f32_f16 %1, %9, %17, 0\n v_dot2_f32_f16 %5, %13, %17, 0\n"
+                        "v_dot2_f32_f16 %2, %10, %18, 0\n v_dot2_f32_f16 %6, %14, %18, 0\n"
+                        "v_dot2_f32_f16 %3, %11, %19, 0\n v_dot2_f32_f16 %7, %15, %19, 0\n s_nop 2"
+                        : "=&v"(re[0]), "=&v"(re[1]), "=&v"(re[2]), "=&v"(re[3]), "=&v"(im[0]), "=&v"(im[1]), "=&v"(im[2]), "=&v"(im[3])
+                        : "v"(xc[0]), "v"(xc[1]), "v"(xc[2]), "v"(xc[3]), "v"(xs[0]), "v"(xs[1]), "v"(xs[2]), "v"(xs[3]),
+                          "v"(cv[comp][q]), "v"(cv[comp][q + 1]), "v"(cv[comp][q + 2]), "v"(cv[comp][q + 3]));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cx_set(y[q + i], re[i], im[i]);
+                }
+#else
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {  // ((xi, xr) is re-formed per component: one v_alignbit against 16 registers held across both)
                     const float2 t = cmul_h(xn[q], __builtin_amdgcn_alignbit(xn[q], xn[q], 16), cv[comp][q]);
                     cx_set(y[q], t.x, t.y);
                 }
+#endif
                 // the last component's products are the last readers of xn: the next cell's row is fetched into the same
                 // registers while the transform and the stores run
                 if (comp == NCOMP - 1 && g + 1 < g1) fetch_x(g + 1);
