@@ -1406,9 +1406,13 @@ int AcqRun::refine() {
     }
     {
         std::vector<std::set<Cell>> cs(P);
+        // (rounds 1-3 also refined the +-1 bin / +-1 lag neighbours of every candidate -- nine f64 sums per candidate.  The
+        //  completeness argument does not use them: the true maximum's sieve value is within kDelta / 2 of it, hence within
+        //  kDelta of the sieve maximum, hence on the list itself.  BDS_ACQ_NEIGH=1 brings them back.)
+        const int nb_r = tune.neigh;
         auto add = [&](int pi, int b, long lag) {
-            for (int db = -1; db <= 1; ++db)
-                for (int dl = -1; dl <= 1; ++dl) {
+            for (int db = -nb_r; db <= nb_r; ++db)
+                for (int dl = -nb_r; dl <= nb_r; ++dl) {
                     const int bb = b + db;
                     const long ll = lag + dl;
                     if (bb >= 0 && bb < D && ll >= 0 && ll < a.N) cs[pi].insert(Cell{bb, ll});
@@ -1500,6 +1504,7 @@ int AcqRun::metric_b1c() {
 //  wave-private kernel's running bounds have nothing to run on)
 int AcqRun::second_peak_b2a() {
     Plan2D &pl = a.plan;
+    const int nb_r = ctx->tune.neigh;
     int rc;
     so.cellmax = nullptr;
     so.lb = nullptr;
@@ -1570,12 +1575,12 @@ int AcqRun::second_peak_b2a() {
         for (int t = 0; t < pl.ntiles; ++t) {
             const Rec &r = r2[(size_t)pi * pl.ntiles + t];
             if (r.lag < 0 || r.v < thr) continue;
-            for (long dl = -1; dl <= 1; ++dl)
+            for (long dl = -nb_r; dl <= nb_r; ++dl)
                 if (inrange(r.lag + dl)) ls.insert(r.lag + dl);
         }
         for (const Extra &e : h_extra2)
             if (e.cell == pi && e.lag >= 0 && !(e.v < thr))
-                for (long dl = -1; dl <= 1; ++dl)
+                for (long dl = -nb_r; dl <= nb_r; ++dl)
                     if (inrange(e.lag + dl)) ls.insert(e.lag + dl);
         lags[pi].assign(ls.begin(), ls.end());
         for (long l : lags[pi])
