@@ -376,6 +376,8 @@ struct AcqState {
     double sum_sq_ext = 0;     // sum x^2 over it: X_rms^2 (Parseval)
     long sums_N = 0, sums_next = 0;  // sizes the two sums above were computed for
     float sX = 1.f, sC = 1.f, sB = 1.f;  // power-of-two storage scales
+    long sigpower_X = 0;       // X the cached B1C normaliser was computed for (0: none; reset by bds_acq_load)
+    double sigpower = 0;       // sqrt(var(sig(1:X)) * X), B1C/acquisition.m:150
 };
 
 void acq_state_free(AcqState *a) {
@@ -857,6 +859,7 @@ extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s_in, const int8_t
         for (long i = 0; i < n_eff; ++i) a.h_prefix_q[(size_t)i + 1] = a.h_prefix_q[(size_t)i] + a.h_im[(size_t)i];
     }
     a.n_samples = n_eff;
+    a.sigpower_X = 0;
     ext_sums(a);
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
     return BDS_OK;
@@ -1482,16 +1485,21 @@ int AcqRun::refine() {
 // sigPower = sqrt(var(sig(1:X)) * X), unbiased variance (B1C/acquisition.m:150)
 // (complex input: var = sum |x - mean|^2 / (X-1), as MATLAB's var of a complex vector)
 int AcqRun::metric_b1c() {
-    const double mean = (a.h_prefix[a.X] - a.h_prefix[0]) / (double)a.X;
-    const double mean_q = a.cplx ? (a.h_prefix_q[a.X] - a.h_prefix_q[0]) / (double)a.X : 0.0;
-    long double acc = 0;
-    for (long i = 0; i < a.X; ++i) {
-        const double d = a.h_re[(size_t)i] - mean;
-        const double dq = a.cplx ? a.h_im[(size_t)i] - mean_q : 0.0;
-        acc += (long double)(d * d + dq * dq);
+    // (a property of the loaded block and X: a million-term host sum, kept across calls -- it was ~1.5 ms of every run)
+    if (a.sigpower_X != a.X) {
+        const double mean = (a.h_prefix[a.X] - a.h_prefix[0]) / (double)a.X;
+        const double mean_q = a.cplx ? (a.h_prefix_q[a.X] - a.h_prefix_q[0]) / (double)a.X : 0.0;
+        long double acc = 0;
+        for (long i = 0; i < a.X; ++i) {
+            const double d = a.h_re[(size_t)i] - mean;
+            const double dq = a.cplx ? a.h_im[(size_t)i] - mean_q : 0.0;
+            acc += (long double)(d * d + dq * dq);
+        }
+        const double var = (double)(acc / (long double)(a.X - 1));
+        a.sigpower = std::sqrt(var * (double)a.X);
+        a.sigpower_X = a.X;
     }
-    const double var = (double)(acc / (long double)(a.X - 1));
-    const double sigPower = std::sqrt(var * (double)a.X);
+    const double sigPower = a.sigpower;
     for (int pi = 0; pi < P; ++pi) {
         res[pi].denom = sigPower;
         if (res[pi].codePhase + a.spc - 1 > a.n_samples) res[pi].codePhase -= a.spc;  // :239-241
