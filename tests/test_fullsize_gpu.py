@@ -164,3 +164,42 @@ def test_b1c_wideband_tracking_full_rate(ctx):
             np.testing.assert_allclose(getattr(g, f), getattr(r, f), rtol=0, atol=1e-4 * p, err_msg=f)
         np.testing.assert_allclose(g.carrFreq, r.carrFreq, rtol=0, atol=1e-3)
         np.testing.assert_allclose(g.codeFreq, r.codeFreq, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("env", [{"BDS_ACQ_PK": "0"}, {"BDS_ACQ_PK": "2"}, {"BDS_ACQ_ILV": "0"}, {"BDS_ACQ_PK": "0", "BDS_ACQ_ILV": "0"},
+                                 {"BDS_ACQ_NEIGH": "1"}, {"BDS_ACQ_WROWS": "0"}, {"BDS_ACQ_WCOLS": "0"}])
+def test_cfg3_kernel_variants_decide_the_same(env, monkeypatch):
+    """The switches of the round-4 search kernels at the cfg3 plan (768 x 4096): plain-fp32 instead of packed butterflies (both
+    passes / column pass only), component planes instead of interleaved components, the +-1 neighbours of rounds 1-3 refined
+    as well, the round-2 row / column kernels.  Every variant is a different sieve in front of the same f64 decision: acqResults
+    must be the default's bit for bit, the search grid within the sieve's tolerance of it."""
+    s, x, sats, _ = bench.build_workload("b1c")
+    prns = [sats[0].prn, 2, sats[1].prn, 33]
+    ref = bds_amd.native.Context(0)
+    ref.acq_load(s, x)
+    ref.acq_prepare(s)
+    want = ref.acq_run(s, prn_list=prns)
+    g0, _ = ref.acq_grid(len(prns), 201)
+    flags0 = ref.timing()["kernel_flags"]
+    ref.close()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = bds_amd.native.Context(0)  # the knobs are read once, at context creation
+    c.acq_load(s, x)
+    c.acq_prepare(s)
+    got = c.acq_run(s, prn_list=prns)
+    g1, _ = c.acq_grid(len(prns), 201)
+    tm = c.timing()
+    c.close()
+    for u, v in zip(want, got):
+        assert np.array_equal(u, v)
+    np.testing.assert_allclose(g1, g0, rtol=2e-3)
+    assert flags0 == 3  # default: interleaved components + packed butterflies
+    if "BDS_ACQ_PK" in env and env["BDS_ACQ_PK"] == "0":
+        assert not tm["kernel_flags"] & 2
+    if "BDS_ACQ_ILV" in env:
+        assert not tm["kernel_flags"] & 1
+    if "BDS_ACQ_WROWS" in env:
+        assert tm["rows_kernel"] == 1 and tm["kernel_flags"] == 0
+    if "BDS_ACQ_WCOLS" in env:
+        assert tm["cols_kernel"] == 1
