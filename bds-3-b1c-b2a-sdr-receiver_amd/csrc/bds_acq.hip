@@ -920,9 +920,11 @@ struct Cell {
     bool operator<(const Cell &o) const { return std::tie(b, lag) < std::tie(o.b, o.lag); }
 };
 
+// multi: every job carries up to kCorrFreqs frequencies (k_corr_f64_multi); out[j * kCorrFreqs + f]
 static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vector<CorrJob> &jobs,
-                    std::vector<double2> &out) {
-    out.resize(jobs.size());
+                    std::vector<double2> &out, bool multi = false) {
+    const int nper = multi ? kCorrFreqs : 1;
+    out.resize(jobs.size() * nper);
     if (jobs.empty()) return BDS_OK;
     int rc;
     // sampled codes the jobs refer to (built once per (slot, mode), cached in the context)
@@ -952,21 +954,26 @@ static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vecto
         size_t cap = std::max<size_t>(jobs.size(), 1024), dummy = 0;
         if ((rc = ensure(ctx, &a.d_jobs, &dummy, cap))) return rc;
         dummy = 0;
-        if ((rc = ensure(ctx, &a.d_jobout, &dummy, cap * kSlices))) return rc;
+        if ((rc = ensure(ctx, &a.d_jobout, &dummy, cap * kSlices * kCorrFreqs))) return rc;
         a.jobs_cap = cap;
     }
     BDS_HIP(ctx, hipMemcpyAsync(a.d_jobs, jobs.data(), sizeof(CorrJob) * jobs.size(), hipMemcpyHostToDevice, st(ctx)));
-    hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size(), kSlices), dim3(256), 0, st(ctx), a.sview(), a.N,
-                       (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
+    if (multi)
+        hipLaunchKernelGGL(k_corr_f64_multi, dim3((unsigned)jobs.size(), kSlices), dim3(256), 0, st(ctx), a.sview(), a.N,
+                           (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
+    else
+        hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size(), kSlices), dim3(256), 0, st(ctx), a.sview(), a.N,
+                           (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
     BDS_HIP(ctx, hipGetLastError());
-    std::vector<double2> part(jobs.size() * kSlices);
+    std::vector<double2> part(jobs.size() * kSlices * nper);
     BDS_HIP(ctx, hipMemcpyAsync(part.data(), a.d_jobout, sizeof(double2) * part.size(), hipMemcpyDeviceToHost, st(ctx)));
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
-    for (size_t j = 0; j < jobs.size(); ++j) {
-        double2 acc = make_double2(0.0, 0.0);
-        for (int k = 0; k < kSlices; ++k) acc.x += part[j * kSlices + k].x, acc.y += part[j * kSlices + k].y;
-        out[j] = acc;
-    }
+    for (size_t j = 0; j < jobs.size(); ++j)
+        for (int f = 0; f < (multi ? jobs[j].nf : 1); ++f) {
+            double2 acc = make_double2(0.0, 0.0);  // slices in order, as a single-frequency job adds them
+            for (int k = 0; k < kSlices; ++k) acc.x += part[(j * kSlices + k) * nper + f].x, acc.y += part[(j * kSlices + k) * nper + f].y;
+            out[j * nper + f] = acc;
+        }
     return BDS_OK;
 }
 
@@ -1635,67 +1642,75 @@ int AcqRun::fine_search() {
                             prns[pi], r.codePhase, r.codePhase + a.spc - 1);
             const double mean = (a.h_prefix[r.codePhase - 1 + a.spc] - a.h_prefix[r.codePhase - 1]) / (double)a.spc;  // :254
             const double mean_q = a.cplx ? (a.h_prefix_q[r.codePhase - 1 + a.spc] - a.h_prefix_q[r.codePhase - 1]) / (double)a.spc : 0.0;
-            for (int kf = 0; kf < nfine; ++kf) {
-                const double f = fb - s->acqStep + 25.0 * kf;  // :282-283
-                fine_frq[pi].push_back(f);
-                for (int comp = 0; comp < ncomp; ++comp) {
+            for (int kf = 0; kf < nfine; ++kf) fine_frq[pi].push_back(fb - s->acqStep + 25.0 * kf);  // :282-283
+            // jobs of one PRN: [component][chunk of up to kCorrFreqs frequencies]
+            for (int comp = 0; comp < ncomp; ++comp)
+                for (int k0 = 0; k0 < nfine; k0 += kCorrFreqs) {
                     CorrJob j{};
                     j.start = r.codePhase - 1;
                     j.len = a.spc;
-                    j.freq = f;
                     j.mean = mean;
                     j.mean_q = mean_q;
                     j.slot = (prns[pi] - 1) * 2 + comp;
                     j.circ = 0;
                     j.mode = 0;
+                    j.nf = std::min(kCorrFreqs, nfine - k0);
+                    for (int f = 0; f < j.nf; ++f) j.fr[f] = fine_frq[pi][k0 + f];
+                    j.freq = j.fr[0];
                     jobs.push_back(j);
                 }
-            }
         } else {
             nfine = (int)m_round(s->acqStep / 25) + 1;  // B2a/acquisition.m:265
             const long nn = (long)s->fineNoncoh * a.spc;
             if (r.codePhase - 1 + nn > a.n_samples)
                 return fail(ctx, BDS_ERR_ARG, "PRN %d: fine-search block %ld..%ld outside longSignal (B2a/acquisition.m:290)",
                             prns[pi], r.codePhase, r.codePhase + nn - 1);
-            for (int kf = 0; kf < nfine; ++kf) {
-                const double f = fb - s->acqStep / 2 + 25.0 * kf;  // :300-301
-                fine_frq[pi].push_back(f);
-                for (int seg = 0; seg < s->fineNoncoh; ++seg)
-                    for (int comp = 0; comp < 2; ++comp) {
+            for (int kf = 0; kf < nfine; ++kf) fine_frq[pi].push_back(fb - s->acqStep / 2 + 25.0 * kf);  // :300-301
+            // jobs of one PRN: [segment][component][chunk of up to kCorrFreqs frequencies]
+            for (int seg = 0; seg < s->fineNoncoh; ++seg)
+                for (int comp = 0; comp < 2; ++comp)
+                    for (int k0 = 0; k0 < nfine; k0 += kCorrFreqs) {
                         CorrJob j{};
                         j.start = r.codePhase - 1 + (long)seg * a.spc;
                         j.len = a.spc;
                         j.code_k0 = (long)seg * a.spc;
-                        j.freq = f;
                         j.slot = (prns[pi] - 1) * 2 + comp;
                         j.circ = 0;
                         j.mode = 1;
+                        j.nf = std::min(kCorrFreqs, nfine - k0);
+                        for (int f = 0; f < j.nf; ++f) j.fr[f] = fine_frq[pi][k0 + f];
+                        j.freq = j.fr[0];
                         jobs.push_back(j);
                     }
-            }
         }
         fine_of[pi] = 1;
     }
     std::vector<double2> jout;
-    if ((rc = run_jobs(ctx, a, *s, jobs, jout))) return rc;
-    size_t k = 0;
+    if ((rc = run_jobs(ctx, a, *s, jobs, jout, true))) return rc;
+    const int nchunk = (nfine + kCorrFreqs - 1) / kCorrFreqs;
+    size_t job0 = 0;  // first job of the PRN
     for (int pi = 0; pi < P; ++pi) {
         if (fine_of[pi] < 0) continue;
+        // sum of frequency kf of job group (seg, comp): jobs are laid out [seg][comp][chunk]
+        auto at = [&](int seg, int comp, int ncomp_, int kf) {
+            const size_t j = job0 + ((size_t)seg * ncomp_ + comp) * nchunk + kf / kCorrFreqs;
+            return jout[j * kCorrFreqs + kf % kCorrFreqs];
+        };
         double best = -1;
         int kbest = 0;
         for (int kf = 0; kf < nfine; ++kf) {
             double v;
             if (a.signal == BDS_SIGNAL_B1C) {
-                v = cabs2(jout[k]);
-                if (ncomp == 2) v = (v * 11 + cabs2(jout[k + 1]) * 29) / 40;  // :291-292
-                k += ncomp;
+                v = cabs2(at(0, 0, ncomp, kf));
+                if (ncomp == 2) v = (v * 11 + cabs2(at(0, 1, ncomp, kf)) * 29) / 40;  // :291-292
             } else {
                 double sd = 0, sp = 0;
-                for (int seg = 0; seg < s->fineNoncoh; ++seg, k += 2) sd += cabs2(jout[k]), sp += cabs2(jout[k + 1]);
+                for (int seg = 0; seg < s->fineNoncoh; ++seg) sd += cabs2(at(seg, 0, 2, kf)), sp += cabs2(at(seg, 1, 2, kf));
                 v = sd + sp;  // :321
             }
             if (v > best) best = v, kbest = kf;
         }
+        job0 += (size_t)(a.signal == BDS_SIGNAL_B1C ? ncomp : 2 * s->fineNoncoh) * nchunk;
         double cf = fine_frq[pi][kbest];
         if (cf == 0) cf = 1;  // :333-335
         carrFreq[prns[pi] - 1] = cf;

@@ -370,8 +370,10 @@ struct CorrJob {
     int slot;       // code slot (prn_idx*ncomp + comp)
     int circ;
     int mode;
-    int pad;
+    int nf;         // k_corr_f64_multi: frequencies of this job (1 .. kCorrFreqs), fr[0 .. nf)
+    double fr[6];   // ... the fine-search frequencies that share the job's samples and code [Hz]
 };
+constexpr int kCorrFreqs = 6;
 
 __global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
                                                   const int8_t *__restrict__ codes, long code_stride,
@@ -431,6 +433,81 @@ __global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
         __syncthreads();
     }
     if (threadIdx.x == 0) out[(long)blockIdx.x * gridDim.y + blockIdx.y] = make_double2(s_r[0], s_i[0]);
+}
+
+// The same sums for up to kCorrFreqs carrier frequencies that share a job's samples and code (the fine-Doppler search:
+// 17 frequencies 25 Hz apart per (PRN, segment, component) at B2a, 5 at B1C).  One frequency per job made every thread a chain
+// of dependent byte loads per frequency; here a sample and its code value are loaded once and every frequency's phasor is
+// advanced beside the others -- per frequency the operations and their order are those of k_corr_f64 (exact phasor every 16th
+// step and at the circular wrap, constant-angle rotation in between), so the sums are the same bits.
+// out[(job * slices + slice) * kCorrFreqs + f]
+__global__ __launch_bounds__(256) void k_corr_f64_multi(SampleView sig, long n_circ, const int8_t *__restrict__ codes,
+                                                        long code_stride, double inv_fs, const CorrJob *__restrict__ jobs,
+                                                        double2 *__restrict__ out) {
+    constexpr int FM = kCorrFreqs;
+    const CorrJob jb = jobs[blockIdx.x];
+    const int nf = jb.nf;
+    const long slice = ((jb.len + gridDim.y - 1) / gridDim.y + 255) & ~255L;
+    const long n_lo = (long)blockIdx.y * slice, n_hi = n_lo + slice < jb.len ? n_lo + slice : jb.len;
+    double sr[FM], si[FM], wr[FM], wi[FM], cr[FM], ci[FM];
+#pragma unroll
+    for (int f = 0; f < FM; ++f) {
+        sr[f] = si[f] = 0.0;
+        cr[f] = 1.0, ci[f] = 0.0;
+        const double dcyc = (f < nf ? jb.fr[f] : 0.0) * ((double)blockDim.x * inv_fs);
+        sincospi(2.0 * (dcyc - floor(dcyc)), &wi[f], &wr[f]);
+    }
+    int it = 0;
+    const long cbase = ((long)jb.slot * 2 + jb.mode) * code_stride + (jb.mode ? jb.code_k0 : 0);
+    for (long n = n_lo + threadIdx.x; n < n_hi; n += blockDim.x, ++it) {
+        long a = jb.start + n;
+        long t = n;
+        bool resync = (it & 15) == 0;
+        if (jb.circ) {
+            if (a >= n_circ) {
+                resync = resync || (a - (long)blockDim.x < n_circ);
+                a -= n_circ;
+            }
+            t = a;
+        }
+        BDS_DASSERT(n >= 0 && (jb.mode ? jb.code_k0 + n : n) < code_stride && jb.slot >= 0 && jb.slot < 2 * BDS_MAX_PRN);
+        const int8_t cv = codes[cbase + n];
+        const double2 xv = sig.load(a);
+        const double x = (xv.x - jb.mean) * (double)cv;
+        const double xq = (xv.y - jb.mean_q) * (double)cv;
+#pragma unroll
+        for (int f = 0; f < FM; ++f) {
+            if (f < nf) {
+                if (resync) {
+                    const double cyc = jb.fr[f] * ((double)t * inv_fs);
+                    sincospi(2.0 * (cyc - floor(cyc)), &ci[f], &cr[f]);
+                } else {
+                    const double nr = cr[f] * wr[f] - ci[f] * wi[f];
+                    ci[f] = cr[f] * wi[f] + ci[f] * wr[f];
+                    cr[f] = nr;
+                }
+                sr[f] += x * cr[f] - xq * ci[f];
+                si[f] += x * ci[f] + xq * cr[f];
+            }
+        }
+    }
+    __shared__ double s_r[256], s_i[256];
+#pragma unroll
+    for (int f = 0; f < FM; ++f) {
+        if (f >= nf) break;
+        __syncthreads();
+        s_r[threadIdx.x] = sr[f];
+        s_i[threadIdx.x] = si[f];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                s_r[threadIdx.x] += s_r[threadIdx.x + s];
+                s_i[threadIdx.x] += s_i[threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[((long)blockIdx.x * gridDim.y + blockIdx.y) * FM + f] = make_double2(s_r[0], s_i[0]);
+    }
 }
 
 }  // namespace bds
