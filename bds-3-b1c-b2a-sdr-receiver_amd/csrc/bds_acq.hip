@@ -29,6 +29,7 @@
 #include <set>
 #include <tuple>
 
+#include "bds_acq_scols.h"
 #include "bds_acq_wcols.h"
 #include "bds_acq_wrows.h"
 #include "bds_internal.h"
@@ -46,6 +47,8 @@ struct Plan2D {
     int logT = 0, Spad = 0, nt_cols = 0, nt_rows = 0, ntiles = 0;
     size_t lds_cols = 0, lds_rows = 0;
     bool fast = false;  // both lengths have compile-time specialised search kernels (bds_acq_fast.h)
+    bool small = false; // 80 x 4096: wave-private row pass + one-lane-per-column pass (bds_acq_scols.h); fp16 storage, two components
+    float2 *d_tw80 = nullptr;  // w80^k of that column pass
     float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_hi = nullptr, *d_lo = nullptr;
     float2 *d_ftab1 = nullptr, *d_ftab2 = nullptr;  // fp32 stage-twiddle tables of the inverse column / row transform
     float2 *d_wtab = nullptr;                       // per-lane twiddle table of the wave-private column pass (bds_acq_wcols.h)
@@ -113,7 +116,7 @@ static bool fast_rows(int b) { return b == 1280 || b == 2048 || b == 3072 || b =
 // Padded length L >= need (5-smooth) and its split L1 x L2, chosen by a cost model:
 // L * (stage costs of both passes + a memory term) -- a slightly longer transform made of
 // radix-16 stages beats the tightest 5-smooth length made of 3s and 5s.
-static bool choose_lengths(const Tuning &tune, long need, long &L, int &L1, int &L2) {
+static bool choose_lengths(const Tuning &tune, long need, long &L, int &L1, int &L2, bool allow_small) {
     const double kMem = 3.0;  // HBM/L2 traffic of the two passes, in units of one LDS stage
     double best = 1e30;
     const long lo = std::max<long>(need, 64), hi = lo + lo / 2 + 64;
@@ -134,6 +137,9 @@ static bool choose_lengths(const Tuning &tune, long need, long &L, int &L1, int 
             if (b > kMaxRowLen || b < a / 4) continue;
             double c = (double)cand * (plan_cost(a) + plan_cost((int)b) + kMem);
             if (fast_cols(a) && fast_rows((int)b)) c *= 0.6;  // specialised kernels exist
+            // 80 x 4096 (round 4): 4096-point rows on the wave-private row pass, 80-point columns one lane each -- measured
+            // against 256 x 1280 at cfg2: see DESIGN.md 1.6
+            if (allow_small && a == kSColsLen && b == 4096) c *= 0.4;
             if (c < best) best = c, L = cand, L1 = a, L2 = (int)b;
         }
     }
@@ -153,7 +159,7 @@ static int threads_for(const Plan1D &p, int T) {
 }
 
 static void plan_free(Plan2D &pl) {
-    for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo, &pl.d_ftab1, &pl.d_ftab2, &pl.d_wtab, &pl.d_wrtab})
+    for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo, &pl.d_ftab1, &pl.d_ftab2, &pl.d_wtab, &pl.d_wrtab, &pl.d_tw80})
         if (*p) (void)hipFree(*p), *p = nullptr;
     if (pl.d_clk) (void)hipFree(pl.d_clk), pl.d_clk = nullptr;
 }
@@ -242,10 +248,11 @@ static int upload_twiddles(bds_ctx *ctx, int n, long denom, long step, float2 **
     return BDS_OK;
 }
 
-static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
+static int plan_build(bds_ctx *ctx, Plan2D &pl, long need, bool allow_small) {
     plan_free(pl);
     const Tuning &tune = ctx->tune;
-    if (!choose_lengths(tune, need, pl.L, pl.L1, pl.L2))
+    pl.small = false;
+    if (!choose_lengths(tune, need, pl.L, pl.L1, pl.L2, allow_small))
         return fail(ctx, BDS_ERR_UNSUPPORTED, "no two-pass transform plan for length >= %ld", need);
     factor_radices(pl.L1, pl.p1);
     factor_radices(pl.L2, pl.p2);
@@ -269,6 +276,7 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
     pl.lds_cols = sizeof(float2) * (size_t)pl.Spad * (size_t)(1 << logT);
     pl.lds_rows = sizeof(float2) * (size_t)lds_span(pl.L2);
     pl.fast = want_fast;
+    pl.small = allow_small && pl.L1 == kSColsLen && pl.L2 == 4096 && !tune.generic;
     if (tune.verbose) {
         fprintf(stderr, "[bds] search kernels: %s\n", pl.fast ? "specialised" : "generic");
         fprintf(stderr, "[bds] plan: need %ld -> L %ld = %d (cols:", need, pl.L, pl.L1);
@@ -290,6 +298,16 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need) {
         if (pl.L2 == 4096 && (rc = upload_wrows_table(ctx, &pl.d_wrtab))) return rc;
         BDS_HIP(ctx, hipMalloc((void **)&pl.d_clk, 4 * sizeof(unsigned long long)));
         BDS_HIP(ctx, hipMemset(pl.d_clk, 0, 4 * sizeof(unsigned long long)));
+    }
+    if (pl.small) {
+        if ((rc = upload_wrows_table(ctx, &pl.d_wrtab))) return rc;
+        std::vector<float2> h(kSColsLen);
+        for (int k = 0; k < kSColsLen; ++k) {
+            const double ang = 2.0 * kPi * (double)k / (double)kSColsLen;
+            h[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+        BDS_HIP(ctx, hipMalloc((void **)&pl.d_tw80, sizeof(float2) * h.size()));
+        BDS_HIP(ctx, hipMemcpy(pl.d_tw80, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
     }
     pl.p1.tw = pl.d_tw1;
     pl.p2.tw = pl.d_tw2;
@@ -466,11 +484,12 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
     a.N = N;
     a.n_ext = N + X - 1;
     a.ncomp = ncomp;
-    if ((rc = plan_build(ctx, a.plan, a.n_ext))) return rc;
+    // (the 80 x 4096 plan: two components, fp16 storage, wave-private row pass available; BDS_ACQ_SMALL=0 keeps 256 x 1280)
+    const bool allow_small = ncomp == 2 && ctx->tune.fp16_storage != 0 && ctx->tune.small_plan != 0 && ctx->tune.wcols != 0;
+    if ((rc = plan_build(ctx, a.plan, a.n_ext, allow_small))) return rc;
     a.group_env = ctx->tune.group;
-    // default: fp32 search arithmetic on fp16-stored spectra (BDS_ACQ_FP16=0: fp32 storage;
-    // BDS_ACQ_HMATH=1: the packed-fp16 arithmetic kernels)
-    a.half = a.plan.fast && ctx->tune.fp16_storage != 0;
+    // default: fp32 search arithmetic on fp16-stored spectra (BDS_ACQ_FP16=0: fp32 storage)
+    a.half = (a.plan.fast || a.plan.small) && ctx->tune.fp16_storage != 0;
     // code spectrum: |fft(code)| <= X; stored value conj(C)/L * sC, kept below 2^15
     a.sC = a.half ? (float)std::exp2(std::floor(std::log2(32768.0 * (double)a.plan.L / (double)a.X))) : 1.f;
     // primary codes of every PRN, both components
@@ -615,7 +634,7 @@ static void launch_rows_f(bds_ctx *ctx, hipStream_t sr, const Plan2D &pl, const 
     const RowsFArgs A{(const float2 *)(kF32TabRows ? pl.d_ftab2 : pl.d_tw2), pl.twl, Xs, pl.L, pl.L1, G, bin0, Cs, Bw, out_scale, gc, nch, cl.bin, cl.cs, nvb, ctx->tune.clockprobe ? pl.d_clk : nullptr, ilv ? 1 : 0};
     const int grid = ctx->tune.rows_grid > 0 ? std::min(nvb, (ctx->tune.rows_grid + 7) / 8 * 8) : nvb;
     if constexpr (S == 4096 && std::is_same<ST, __half2>::value) {
-        if (ctx->tune.wrows != 0) {  // wave-private row pass (bds_acq_wrows.h): per-lane twiddle constants, 4 barriers per cell
+        if (ctx->tune.wrows != 0 || pl.small) {  // wave-private row pass (bds_acq_wrows.h): per-lane twiddle constants, 4 barriers per cell
             RowsFArgs B = A;
             B.tw = pl.d_wrtab;
             const bool pk = ctx->tune.pk != 0;  // packed-fp32 butterflies (bds_fft_pk.h)
@@ -708,6 +727,17 @@ static void launch_fast_f(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const
                           const CellList &cl = {}) {
     // both components of an element side by side in the inter-pass buffer: the wave-private pair of the 768 x 4096 plan (cfg3),
     // unmasked search (one lag range from 0), fp16 storage, two components
+    if constexpr (NC == 2 && std::is_same<ST, __half2>::value) {
+        if (pl.small) {  // 80 x 4096: wave-private row pass (components interleaved) + one lane per column and component
+            launch_rows_f<4096, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl, true);
+            if (so.mid) (void)hipEventRecord(so.mid, st_);
+            const SColsArgs A{(const float2 *)pl.d_tw80, pl.L2, G, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, cl.rng, so.cellmax, so.lb, so.lb_div,
+                              so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep};
+            want_lds(ctx, k_cols_small_f<NC>, kSColsLdsBytes);
+            hipLaunchKernelGGL((k_cols_small_f<NC>), dim3((unsigned)(G * (pl.L2 / (kSColsNT / 2)))), dim3(kSColsNT), kSColsLdsBytes, st_, A);
+            return;
+        }
+    }
     const bool ilv = NC == 2 && std::is_same<ST, __half2>::value && pl.L1 == 768 && pl.L2 == 4096 && ctx->tune.wrows != 0 &&
                      so.cellmax && ctx->tune.ilv != 0 && !cl.rng && lo1 == 0 && lo2 > hi2;
     switch (pl.L2) {
@@ -1129,7 +1159,7 @@ int AcqRun::setup() {
         w0 *= inv;
         w1 *= inv;
     }
-    fsearch = pl.fast && !a.no_fast_search;  // fp32-arithmetic specialised kernels (default)
+    fsearch = (pl.fast || (pl.small && a.half)) && !a.no_fast_search;  // fp32-arithmetic specialised kernels (default)
     // sieve tolerance: every lag within kDelta of a PRN's maximum is re-evaluated in f64.  fp32 storage errs by ~1e-7 of the
     // PRN maximum.  fp16 storage: three roundings lie between the exact value and the sieve's (signal spectrum, code spectrum,
     // inter-pass buffer; 2^-11 relative each).  On noise-like spectra they average out -- 2.5e-4 of the PRN maximum at worst
@@ -1148,7 +1178,7 @@ int AcqRun::setup() {
     // bounds instead of per-tile records
     // (the 256-point plans keep the tile kernel unless forced with BDS_ACQ_WCOLS=1: a workgroup's share of such a tile is
     //  8 points per lane and the per-workgroup constants and barriers dominate -- measured at cfg2 2.18 vs 1.39 ms per launch)
-    wcols = fsearch && tune.wcols != 0 && (pl.L1 != 256 || tune.wcols > 0);
+    wcols = fsearch && (pl.small || (tune.wcols != 0 && (pl.L1 != 256 || tune.wcols > 0)));
     so = SieveOut{nullptr, a.d_extra, a.d_extra_count, kExtraCap, 0, (float)(1.0 - kDelta)};
     if (wcols) {
         if ((rc = ensure(ctx, &a.d_cellmax, &a.cellmax_cap, (size_t)std::max(P, 1) * D))) return rc;
@@ -1521,12 +1551,22 @@ int AcqRun::second_peak_b2a() {
     Plan2D &pl = a.plan;
     const int nb_r = ctx->tune.neigh;
     int rc;
+    const bool small = pl.small && fsearch;  // the 80 x 4096 plan has no tile kernel: its column pass reports as in the search
     so.cellmax = nullptr;
     so.lb = nullptr;
     const long s2c = (long)std::ceil(s->samplingFreq / s->codeFreqBasis) * 2;  // samples2CodeChip :137
     std::vector<std::array<long, 4>> rng(P);
-    if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * pl.ntiles))) return rc;
-    so.recs = a.d_recs;
+    if (small) {  // cell = PRN index: one packed maximum and one running bound per PRN
+        BDS_HIP(ctx, hipMemsetAsync(a.d_cellmax, 0, sizeof(unsigned long long) * (size_t)std::max(P, 1), stream()));
+        BDS_HIP(ctx, hipMemsetAsync(a.d_lb, 0, sizeof(float) * (size_t)std::max(P, 1), stream()));
+        so.cellmax = a.d_cellmax;
+        so.lb = a.d_lb;
+        so.lb_div = 1;
+        so.recs = nullptr;
+    } else {
+        if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * pl.ntiles))) return rc;
+        so.recs = a.d_recs;
+    }
     // specialised kernels: all PRNs' (PRN, winning bin) cells in one launch pair through a cell list
     // (63 tiny launch pairs were ~1 ms of the 2.7 ms refinement at cfg2)
     const size_t cap_cells = a.bw_cap / (size_t)pl.L * 8 / elem / (size_t)ncomp;  // cells the work buffer holds
@@ -1548,7 +1588,7 @@ int AcqRun::second_peak_b2a() {
         h_cs[pi] = (long)a.cs_slot[prns[pi]] * ncomp * pl.L;
         h_rng[pi] = make_int4((int)rng[pi][0], (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3]);
         if (!batched)
-            launch_cells(prns[pi], res[pi].fbin - 1, 1, a.d_recs + (size_t)pi * pl.ntiles, (int)rng[pi][0],
+            launch_cells(prns[pi], res[pi].fbin - 1, 1, small ? nullptr : a.d_recs + (size_t)pi * pl.ntiles, (int)rng[pi][0],
                          (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3], pi, nullptr);
     }
     if (batched && P > 0) {
@@ -1561,12 +1601,16 @@ int AcqRun::second_peak_b2a() {
         BDS_HIP(ctx, hipMemcpyAsync(d_cs, h_cs.data(), sizeof(long) * P, hipMemcpyHostToDevice, stream()));
         BDS_HIP(ctx, hipMemcpyAsync(d_bin, h_bin.data(), sizeof(int) * P, hipMemcpyHostToDevice, stream()));
         const CellList cl{d_bin, d_cs, d_rng};
-        launch_list(P, a.d_recs, cl, 0, nullptr);
+        launch_list(P, small ? nullptr : a.d_recs, cl, 0, nullptr);
     }
     BDS_HIP(ctx, hipGetLastError());
-    std::vector<Rec> r2((size_t)P * pl.ntiles);
+    std::vector<Rec> r2(small ? 0 : (size_t)P * pl.ntiles);
+    std::vector<unsigned long long> h_cm(small ? (size_t)P : 0);
     int n_extra2 = 0;
-    BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, stream()));
+    if (small)
+        BDS_HIP(ctx, hipMemcpyAsync(h_cm.data(), a.d_cellmax, sizeof(unsigned long long) * (size_t)P, hipMemcpyDeviceToHost, stream()));
+    else
+        BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, stream()));
     BDS_HIP(ctx, hipMemcpyAsync(&n_extra2, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, stream()));
     BDS_HIP(ctx, hipStreamSynchronize(stream()));
     if (n_extra2 > kExtraCap && a.half) return redo(kRedoFp32, "overflow list of the second-peak pass ran over at the fp16-storage tolerance");
@@ -1581,13 +1625,17 @@ int AcqRun::second_peak_b2a() {
     std::vector<std::vector<long>> lags(P);
     for (int pi = 0; pi < P; ++pi) {
         float M = -1.f;
-        for (int t = 0; t < pl.ntiles; ++t) M = std::max(M, r2[(size_t)pi * pl.ntiles + t].v);
+        if (small) {
+            int lag_unused;
+            unpack_cell(h_cm[(size_t)pi], &M, &lag_unused);  // (the maximum itself is on the list, like every lag above the threshold)
+        }
+        for (int t = 0; t < pl.ntiles && !small; ++t) M = std::max(M, r2[(size_t)pi * pl.ntiles + t].v);
         const float thr = (float)((1.0 - kDelta) * (double)M);
         std::set<long> ls;
         auto inrange = [&](long l) {
             return (l >= rng[pi][0] && l <= rng[pi][1]) || (l >= rng[pi][2] && l <= rng[pi][3]);
         };
-        for (int t = 0; t < pl.ntiles; ++t) {
+        for (int t = 0; t < pl.ntiles && !small; ++t) {
             const Rec &r = r2[(size_t)pi * pl.ntiles + t];
             if (r.lag < 0 || r.v < thr) continue;
             for (long dl = -nb_r; dl <= nb_r; ++dl)
@@ -1784,10 +1832,10 @@ int AcqRun::finish() {
     t.plan_l1 = pl.L1;
     t.plan_l2 = pl.L2;
     {
-        const bool wrows_on = fsearch && a.half && pl.L2 == 4096 && tune.wrows != 0;
+        const bool wrows_on = fsearch && a.half && pl.L2 == 4096 && (tune.wrows != 0 || pl.small);
         t.rows_kernel = !fsearch ? 0 : wrows_on ? 2 : 1;
-        t.cols_kernel = !fsearch ? 0 : wcols ? 2 : 1;
-        const bool ilv_on = wrows_on && wcols && ncomp == 2 && pl.L1 == 768 && tune.ilv != 0;
+        t.cols_kernel = !fsearch ? 0 : pl.small ? 3 : wcols ? 2 : 1;
+        const bool ilv_on = wrows_on && wcols && ncomp == 2 && ((pl.L1 == 768 && tune.ilv != 0) || pl.small);
         t.kernel_flags = (ilv_on ? 1 : 0) | (wrows_on && tune.pk != 0 ? 2 : 0);
     }
     return BDS_OK;

@@ -350,7 +350,7 @@ def strict_f32_leg(local_rank, s, x, n_cells_samples, ncomp, n_circ):
 
 
 ROWS_KERNEL = {0: "k_rows_inv (run-time plan)", 1: "k_rows_inv_f", 2: "k_rows_wave_f"}
-COLS_KERNEL = {0: "k_cols_inv_max (run-time plan)", 1: "k_cols_inv_max_f (tile)", 2: "k_cols_wave_f"}
+COLS_KERNEL = {0: "k_cols_inv_max (run-time plan)", 1: "k_cols_inv_max_f (tile)", 2: "k_cols_wave_f", 3: "k_cols_small_f"}
 
 
 def kernel_label(tm):
