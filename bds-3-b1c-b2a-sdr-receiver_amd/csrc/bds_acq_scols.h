@@ -24,6 +24,9 @@
 
 namespace bds {
 
+#ifndef BDS_SCOLS_OCC
+#define BDS_SCOLS_OCC 2
+#endif
 constexpr int kSColsLen = 80;      // column length
 constexpr int kSColsOut = 49;      // output rows formed: n1 = 0 .. 48
 constexpr int kSColsNT = 256;      // threads: 128 columns x 2 components
@@ -66,7 +69,7 @@ __device__ __forceinline__ void pk_radix5_012(const v2f (&t)[5], v2f &x0, v2f &x
 }
 
 template <int NCOMP>
-__global__ __launch_bounds__(kSColsNT, 2) void k_cols_small_f(SColsArgs A) {
+__global__ __launch_bounds__(kSColsNT, BDS_SCOLS_OCC) void k_cols_small_f(SColsArgs A) {
     static_assert(NCOMP == 2, "two components side by side in the inter-pass buffer");
     extern __shared__ __attribute__((aligned(16))) float sm_all[];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -203,3 +203,23 @@ def test_cfg3_kernel_variants_decide_the_same(env, monkeypatch):
         assert tm["rows_kernel"] == 1 and tm["kernel_flags"] == 0
     if "BDS_ACQ_WCOLS" in env:
         assert tm["cols_kernel"] == 1
+
+
+def test_cfg2_plans_decide_the_same(monkeypatch):
+    """cfg2 (B2a, 63 PRNs x 26 bins) on the 80 x 4096 plan of round 4 (wave-private row pass + one lane per column,
+    bds_acq_scols.h) and on the 256 x 1280 plan of rounds 1-3 (BDS_ACQ_SMALL=0): different sieves, the same f64 decision --
+    acqResults bit for bit, the second peak included (peakMetric = peak / second peak)."""
+    s, x, sats, _ = bench.build_workload("b2a")
+    out = {}
+    for small in ("1", "0"):
+        monkeypatch.setenv("BDS_ACQ_SMALL", small)
+        c = bds_amd.native.Context(0)
+        c.acq_load(s, x)
+        c.acq_prepare(s)
+        out[small] = c.acq_run(s)
+        tm = c.timing()
+        c.close()
+        assert (tm["plan_l1"], tm["plan_l2"], tm["cols_kernel"]) == ((80, 4096, 3) if small == "1" else (256, 1280, 1))
+    for u, v in zip(out["1"], out["0"]):
+        assert np.array_equal(u, v)
+    assert sorted(int(p) for p in np.nonzero(out["1"][0])[0] + 1) == sorted(sat.prn for sat in sats)
