@@ -187,7 +187,7 @@ static int upload_stage_tables_f32(bds_ctx *ctx, const Plan1D &p, float2 **dptr)
 
 // per-lane twiddle table of the wave-private column pass (layout: wcols_table_entries<S>() in bds_acq_wcols.h), inverse
 // direction, rounded from f64: [p - 1][thread] = w_S^(b p) with b = 16 (thread / 64) + (thread % 64) / 4, then
-// [j - 1][lane] = w_64^(u (bl - u)) with u = lane / 8, bl = (j + u) % 8 (stage 3 applies the stage-2 twiddle to its inputs)
+// [j - 1][lane] = w_64^(u j) with u = lane / 8 (stage 3 applies the stage-2 twiddle to its inputs, input j being bl = j)
 static int upload_wcols_table(bds_ctx *ctx, int S, float2 **dptr) {
     const int R1 = S / 64;
     std::vector<float2> h;
@@ -199,8 +199,8 @@ static int upload_wcols_table(bds_ctx *ctx, int S, float2 **dptr) {
         }
     for (int j = 1; j < 8; ++j)
         for (int lane = 0; lane < 64; ++lane) {
-            const int u = lane >> 3, bl = (j + u) & 7;
-            const double a = 2.0 * kPi * (double)(((u * (bl - u)) % 64 + 64) % 64) / 64.0;
+            const int u = lane >> 3;
+            const double a = 2.0 * kPi * (double)((u * j) % 64) / 64.0;
             h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
         }
     BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * h.size()));

@@ -16,9 +16,8 @@
 //       of the wave that owns column pair cp at [m = c R1 + p][b]                      -- barrier --
 //   phase B (wave w owns columns 2w, 2w+1 and its LDS region; no workgroup barrier inside): lane (ml = lane & 7,
 //       bl = lane >> 3), slots s: m = ml + 8 s.  Radix-8 over bh, twiddle w64^(bl u) from per-lane constants, written
-//       back IN PLACE at [m][8 u + bl]; then lane (ml, u) reads row u starting at column u (a rotation of the
-//       butterfly's inputs = a unit factor on its outputs, invisible in |X|; it makes the read conflict-free),
-//       radix-8 over bl, magnitudes in registers.
+//       back IN PLACE at [m][8 u + bl]; then lane (ml, u) reads row u, radix-8 over bl, magnitudes in registers.
+//       (Columns are swapped inside aligned quads by (ml >> 1) -- struct WCols -- which keeps every access class conflict-free.)
 //   Two LDS round trips per point instead of three-plus-tables, three barriers per tile and two components
 //   instead of twelve-plus, every stage twiddle a per-lane constant (one coalesced load each from a per-lane table),
 //   the rows of both components in flight before anything else happens.
@@ -33,6 +32,7 @@
 
 #include "bds_acq_f32.h"
 #include "bds_fft_pk.h"
+#include "bds_lds.h"
 
 // Timing experiments (tools/exp/exp_wparts.sh; results are INVALID with any of these defined):
 //   BDS_EXP_WC_NOTAIL  nothing after the wave maximum (no bounds, no list, no atomics)
@@ -84,8 +84,16 @@ struct WCols {
     static constexpr int R1 = S / 64;     // radix of the first stage
     static constexpr int M = 2 * R1;      // (column of the pair, p) combinations a wave owns
     static constexpr int SL = M / 8;      // radix-8 butterflies per lane and stage
-    static constexpr int MS = 68;         // elements between consecutive m: 2 MS = 8 (mod 64 banks)
-    static constexpr int RS = M * MS + 8; // elements between the waves' regions: 2 RS = 16 (mod 64)
+    // LDS layout of a wave's region: element (m, column) at [m MS + (column ^ ((m & 7) >> 1))]; regions RS apart.
+    // The hardware serves a ds_read_b64 in halves of 32 lanes over 64 banks (32 eight-byte slots) and a ds_write_b64 in groups
+    // of 16 contiguous lanes over 32 banks (16 slots).  The phase-B readers (8 ml x 4 bl or u per half) need MS = 4 (mod 32),
+    // the in-place writers (8 ml x 2 bl per group) MS = 2 (mod 4): the plain layout of rounds 3-4 read clean and wrote 2-way
+    // (SQ_LDS_BANK_CONFLICT was 46 % of this kernel's LDS cycles).  Swapping columns inside every aligned quad by (ml >> 1)
+    // separates the writers ml and ml + 4, keeps the stage-2 reads a permutation of what they were, and makes the stage-3
+    // reads clean WITHOUT the rotated start they used to need; phase A's writers (4 column pairs x 4 b per group) want the
+    // regions 4 (mod 16) slots apart.  tools/proto_cols_wave.py checks every access class under this bank model.
+    static constexpr int MS = 68;
+    static constexpr int RS = M * MS + 4;
     static constexpr int NW = 4, NT = 256, T = 8;
     static constexpr size_t kLdsBytes = sizeof(float2) * NW * RS;
     // waves per SIMD the register budget is set for (measured unconstrained need: 80 / 123 / 174 / 215 VGPRs; the
@@ -234,16 +242,19 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     }
     PH_MARK(19);  // phase-A constants formed
     C *const ldsc = reinterpret_cast<C *>(ldsf);
-    C *const wrA = ldsc + cp * RS + b;  // + m MS
+    C *wrA[4];  // + m MS, by the swizzle (m & 7) >> 1 of row m
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wrA[k] = ldsc + cp * RS + (b ^ k);
     // phase B: stage 2 as lane (ml, bl), stage 3 as lane (ml, u) with u = bl
     const int ml = lane & 7, bl = lane >> 3;
     // stage-2 twiddle w_64^(bl u), applied by stage 3 to its INPUTS (bds_fft_fma.h: folded into the first butterfly layer): input
-    // j of lane (ml, u) is bl = (j + u) & 7; the common unit factor w_64^(u u) is left out (invisible in |X|)
+    // j of lane (ml, u) is bl = j
     C twB[8];
-    C *const rw2 = ldsc + wave * RS + ml * MS + bl;  // + s 8 MS + 8 bh (read), + 8 u (write back)
-    const C *rd3[8];                                 // row u from column u on: + s 8 MS
+    C *const rw2 = ldsc + wave * RS + ml * MS + (bl ^ (ml >> 1));  // + s 8 MS + 8 bh (read), + 8 u (write back)
+    const unsigned rw2a = lds_offset(rw2);
+    unsigned rd3a[8];                                              // row u: + s 8 MS
 #pragma unroll
-    for (int j = 0; j < 8; ++j) rd3[j] = ldsc + wave * RS + ml * MS + 8 * bl + ((j + bl) & 7);
+    for (int j = 0; j < 8; ++j) rd3a[j] = lds_offset(ldsc + wave * RS + ml * MS + 8 * bl + (j ^ (ml >> 1)));
     // lag of output (s, v) of this lane: row e = p + R1 u + 8 R1 v of column 2 wave + c (m = ml + 8 s = c R1 + p), i.e.
     // lbase[s] + v vstep                                                                            (L < 2^31)
     int lbase[SL];
@@ -340,7 +351,7 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
 #pragma unroll
-                for (int p = 0; p < R1; ++p) wrA[(c * R1 + p) * MS] = z[c][p];
+                for (int p = 0; p < R1; ++p) wrA[((c * R1 + p) & 7) >> 1][(c * R1 + p) * MS] = z[c][p];
             }
             PH_WAIT_LGKM();
             PH_MARK(3 + 6 * comp);  // phase A writes issued and landed
@@ -348,25 +359,26 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
         BDS_WSYNC();
         PH_MARK(4 + 6 * comp);  // barrier
         // ---- phase B, one slot (= 8 of the wave's rows m) at a time so that only 16-32 points are live:
-        //   st2(s): radix 8 over bh, back in place;  st3(s): twiddle, radix 8 over bl (rotated start), magnitudes.
+        //   st2(s): radix 8 over bh, back in place;  st3(s): twiddle, radix 8 over bl, magnitudes.
         // Row m is read and written by the 8 lanes of one ml only, all in this wave, and LDS traffic of a wave is in
         // order: st2(s) may write as soon as its own reads are in, st3(s) may read as soon as st2(s) has written.
         // The units are software-pipelined by hand (st2(s + 1) sits between the write and the read-back of slot s)
         // and fenced, so that the scheduler neither serialises the LDS latency nor hoists every read to the top.
-        auto st2 = [&](int s) {
+        // (reads: bds_lds.h -- single ds_read_b64 instructions, a batch and its wait per statement)
+        auto st2 = [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
             C y[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) y[q] = rw2[s * 8 * MS + 8 * q];
+            lds_read8<s * 8 * MS * (int)sizeof(C), 8 * (int)sizeof(C)>(y, rw2a);
             wave_sync();
             cx_bfly8<false>(y, (const C *)nullptr);
 #pragma unroll
             for (int u = 0; u < 8; ++u) rw2[s * 8 * MS + 8 * u] = y[u];
             wave_sync();
         };
-        auto st3 = [&](int s) {
+        auto st3 = [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
             C y[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] = rd3[j][s * 8 * MS];
+            lds_read8p<s * 8 * MS * (int)sizeof(C)>(y, rd3a);
             wave_sync();
             cx_bfly8<true>(y, twB);
 #pragma unroll
@@ -384,12 +396,12 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        st2(0);
-#pragma unroll
-        for (int s = 0; s < SL; ++s) {
-            if (s + 1 < SL) st2(s + 1);
-            st3(s);
-        }
+        st2(std::integral_constant<int, 0>{});
+        static_for<SL>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s + 1 < SL) st2(std::integral_constant<int, s + 1>{});
+            st3(sc);
+        });
         PH_MARK(5 + 6 * comp);  // phase B
     }
     // ---- maximum of the wave's two columns, candidates ------------------------------------------

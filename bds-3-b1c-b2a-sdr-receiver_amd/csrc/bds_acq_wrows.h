@@ -16,7 +16,7 @@
 //   phase 1b: lane (ql, u = lane >> 2) reads row u starting at column u (bank-conflict free; a rotation of the butterfly's
 //       inputs = the factor w16^(-u v) on its outputs, folded into the per-lane inter-pass twiddle), twiddle w256^(bl u) from
 //       per-lane constants ON THE INPUTS (bds_fft_fma.h: folded into the first butterfly layer), radix 16 over bl, Y to the
-//       exchange buffer at [19 e'' + q']                                                            -- barrier --
+//       exchange buffer at [20 e'' + ((e'' >> 3) & 3) + q']                                                            -- barrier --
 //   phase 2 : thread e'' reads its 16 q', twiddle w4096^(q' e'') from per-lane constants, radix 16, inter-pass twiddle, store.
 //   Against k_rows_inv_f: every stage twiddle is a per-lane constant (30 of them were rebuilt from four table reads with
 //   eleven complex products per butterfly and twiddled stage: 176 of its 1693 vector instructions per cell), no LDS twiddle
@@ -26,6 +26,7 @@
 
 #include "bds_acq_f32.h"
 #include "bds_fft_pk.h"
+#include "bds_lds.h"
 
 namespace bds {
 
@@ -35,8 +36,14 @@ namespace bds {
 // input 0 needs none; it goes into the inter-pass twiddle); inverse direction
 constexpr int kWRowsTableEntries = 15 * 256 + 15 * 64 + 16 + 16;
 constexpr int kWRowsRegion = 1024;  // elements of a wave's region (4 q' x 256)
-constexpr int kWRowsXS = 19;        // elements between consecutive e'' of the exchange buffer (38 dwords: conflict-free both ways; 17 costs 7 %)
-constexpr size_t kWRowsLdsBytes = sizeof(float2) * (4 * kWRowsRegion + 256 * kWRowsXS);
+// Exchange buffer: Y_q'[e''] at [20 e'' + ((e'' >> 3) & 3) + q'].  The hardware serves a ds_write_b64 in groups of 16 contiguous
+// lanes over 32 banks (16 eight-byte slots) and a ds_read_b64 in halves of 32 lanes over 64 banks (32 slots): the writers of a
+// group -- 4 q' x 4 consecutive u -- need the stride = 4 (mod 16 slots), the readers -- 32 consecutive e'' -- an odd one, so no
+// plain stride serves both (19, rounds 3-4, read clean and wrote 2-way: SQ_LDS_BANK_CONFLICT was 22 % of the kernel's LDS
+// cycles).  Stride 20 with every octet of e'' shifted by one slot more (mod 4) is clean both ways, and both sides still
+// address it as one per-lane base + a compile-time offset.
+constexpr int kWRowsXS = 20;
+constexpr size_t kWRowsLdsBytes = sizeof(float2) * (4 * kWRowsRegion + 256 * kWRowsXS + 4);
 
 // PK: the butterflies and twiddle products on packed fp32 pairs (bds_fft_pk.h: half the vector issue slots for the same pipe time)
 template <int NCOMP, bool ILV, bool PK>
@@ -73,8 +80,8 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
     C *const ldsc = reinterpret_cast<C *>(ldsf);
     C *const wr1 = ldsc + wave * kWRowsRegion + lane;                     // + 64 u
     const C *const rd1 = ldsc + wave * kWRowsRegion + 64 * bl + ql;       // + 4 ((j + u) & 15)
-    C *const wrx = ldsc + 4 * kWRowsRegion + XS * bl + qp;                // + 16 XS v
-    const C *const rd2 = ldsc + 4 * kWRowsRegion + XS * tid;              // + q'
+    C *const wrx = ldsc + 4 * kWRowsRegion + XS * bl + (bl >> 3) + qp;    // e'' = u + 16 v: + 16 XS v + 2 (v & 1)
+    const unsigned rd2a = lds_offset(ldsc + 4 * kWRowsRegion + XS * tid + ((tid >> 3) & 3));  // + q'
 
     for (int vb = (int)blockIdx.x; vb < A.nvb; vb += (int)gridDim.x) {
         const int xcd = vb & 7, m = vb >> 3;
@@ -178,18 +185,18 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
                 if (comp == NCOMP - 1 && g + 1 < g1) fetch_x(g + 1);
 #pragma unroll
                 for (int n2 = 0; n2 < 4; ++n2) cx_bfly16_l1<false>(y, (const C *)nullptr, n2, a[n2]);
-#define BDS_WR_L2(K1, DST, STEP)                    \
-    cx_bfly16_l2<K1>(a, o);                         \
-    __builtin_amdgcn_sched_barrier(0);              \
-    (DST)[(STEP) * (K1)] = o[0];                    \
-    (DST)[(STEP) * ((K1) + 4)] = o[1];              \
-    (DST)[(STEP) * ((K1) + 8)] = o[2];              \
-    (DST)[(STEP) * ((K1) + 12)] = o[3];             \
+#define BDS_WR_L2(K1, DST, STEP, ODD)                       \
+    cx_bfly16_l2<K1>(a, o);                                 \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    (DST)[(STEP) * (K1) + (ODD) * ((K1) & 1)] = o[0];       \
+    (DST)[(STEP) * ((K1) + 4) + (ODD) * ((K1) & 1)] = o[1]; \
+    (DST)[(STEP) * ((K1) + 8) + (ODD) * ((K1) & 1)] = o[2]; \
+    (DST)[(STEP) * ((K1) + 12) + (ODD) * ((K1) & 1)] = o[3]; \
     __builtin_amdgcn_sched_barrier(0)
-                BDS_WR_L2(0, wr1, 64);
-                BDS_WR_L2(1, wr1, 64);
-                BDS_WR_L2(2, wr1, 64);
-                BDS_WR_L2(3, wr1, 64);
+                BDS_WR_L2(0, wr1, 64, 0);
+                BDS_WR_L2(1, wr1, 64, 0);
+                BDS_WR_L2(2, wr1, 64, 0);
+                BDS_WR_L2(3, wr1, 64, 0);
                 wave_sync();
                 // ---- phase 1b: radix 16 over bl (rotated start), to the exchange buffer
 #pragma unroll
@@ -205,20 +212,16 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
                 PH_MARK(8 * comp + 2);  // phase 1b layer 1 (waits for its inputs group by group)
                 if (comp > 0 || g > g0) BDS_SYNC();  // every thread is through with the exchange buffer (previous transform)
                 PH_MARK(8 * comp + 3);  // barrier
-                BDS_WR_L2(0, wrx, 16 * XS);
-                BDS_WR_L2(1, wrx, 16 * XS);
-                BDS_WR_L2(2, wrx, 16 * XS);
-                BDS_WR_L2(3, wrx, 16 * XS);
+                BDS_WR_L2(0, wrx, 16 * XS, 2);
+                BDS_WR_L2(1, wrx, 16 * XS, 2);
+                BDS_WR_L2(2, wrx, 16 * XS, 2);
+                BDS_WR_L2(3, wrx, 16 * XS, 2);
 #undef BDS_WR_L2
                 PH_MARK(8 * comp + 4);  // phase 1b layer 2 + exchange writes
                 BDS_SYNC();
                 PH_MARK(8 * comp + 5);  // barrier
                 // ---- phase 2: twiddle (wi folded in), radix 16 over q', uniform factor, store
-#pragma unroll
-                for (int n2 = 0; n2 < 4; ++n2) {
-#pragma unroll
-                    for (int mm = 0; mm < 4; ++mm) y[n2 + 4 * mm] = rd2[n2 + 4 * mm];
-                }
+                lds_read16(y, rd2a);  // bds_lds.h: sixteen ds_read_b64 (the compiler's ds_read2_b64 pairs take twice the LDS cycles)
                 __builtin_amdgcn_sched_barrier(0);
                 PH_MARK(8 * comp + 6);  // exchange reads issued
 #pragma unroll
