@@ -13,7 +13,7 @@ import json
 import re
 import sys
 
-CYC4 = ("v_pk_", "v_cvt_", "v_max", "v_min", "v_cmp", "v_cndmask", "v_dot2", "v_alignbit", "v_lshl_add", "v_mul_lo", "v_perm", "v_mad_u", "v_lshlrev_b64", "v_mbcnt")
+CYC4 = ("v_pk_", "v_fma_mix", "v_cvt_", "v_max", "v_min", "v_cmp", "v_cndmask", "v_dot2", "v_alignbit", "v_lshl_add", "v_mul_lo", "v_perm", "v_mad_u", "v_lshlrev_b64", "v_mbcnt")
 CYC8 = ("v_sqrt", "v_rsq", "v_rcp", "v_sin", "v_cos", "v_exp", "v_log")
 
 

@@ -55,7 +55,7 @@ for key, prefix in (("rows", "k_rows_wave_f"), ("cols", "k_cols_wave_f")):
                  "SQ_WAIT_ANY_over_SQ_WAVE_CYCLES": c["SQ_WAIT_ANY"] / wc if wc and c.get("SQ_WAIT_ANY") else None,
                  "SQ_WAIT_INST_ANY_over_SQ_WAVE_CYCLES": c["SQ_WAIT_INST_ANY"] / wc if wc and c.get("SQ_WAIT_INST_ANY") else None,
                  "SQ_LDS_DATA_FIFO_FULL_over_IDX_ACTIVE": c["SQ_LDS_DATA_FIFO_FULL"] / ia if ia and c.get("SQ_LDS_DATA_FIFO_FULL") else None,
-                 "SQ_LDS_BANK_CONFLICT_over_IDX_ACTIVE": c["SQ_LDS_BANK_CONFLICT"] / ia if ia and c.get("SQ_LDS_BANK_CONFLICT") else None}
+                 "SQ_LDS_BANK_CONFLICT_over_IDX_ACTIVE": c["SQ_LDS_BANK_CONFLICT"] / ia if ia and c.get("SQ_LDS_BANK_CONFLICT") is not None else None}
     tot["valu"] += valu_cyc
     tot["marg"] += marg
     tot["unit"] += unit
