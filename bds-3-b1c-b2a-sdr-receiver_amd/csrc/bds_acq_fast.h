@@ -61,6 +61,17 @@ __global__ __launch_bounds__(1024) void k_rows_fwd_st(Plan1D p, const float2 *__
     }
 }
 
+// exp(-j 2 pi x), 0 <= x < 1 given in f64: fp32 sine / cosine of the fp32 part of x, corrected to first order for its rounding
+__device__ __forceinline__ void phasor32_neg(double x, float *c, float *s) {
+    const float hi = (float)x;
+    const float lo = (float)(x - (double)hi);
+    float s0, c0;
+    sincospif(2.0f * hi, &s0, &c0);
+    const float d = 6.28318530717958647692f * lo;
+    *c = c0 - d * s0;
+    *s = -(s0 + d * c0);
+}
+
 template <class L, class = void>
 struct has_carrier : std::false_type {};
 template <class L>
@@ -69,8 +80,8 @@ struct has_carrier<L, std::enable_if_t<L::kHasCarrier>> : std::true_type {};
 // ---- forward passes on the compile-time stages (fp32 arithmetic) -------------------------------
 // Same two passes as k_cols_fwd / k_rows_fwd_st above with the transform lengths as template
 // parameters.  Column pass: T columns per workgroup (4: measured 4.3 ms per 201 bins against 4.7 ms with
-// 8 and 5.8 ms on the run-time engine); the loader (carrier wipe-off of the int8 block by an f64
-// phasor rotation, or the sampled code) feeds the tile straight into LDS.
+// 8 and 5.8 ms on the run-time engine); the loader (carrier wipe-off of the int8 block by a phasor
+// rotation, or the sampled code) feeds the tile straight into LDS.
 template <int S, int T, class Loader>
 __global__ __launch_bounds__((cols_threads<S, T>()), 2) void k_cols_fwd_t(const float2 *__restrict__ tw, TwiddleL twl,
                                                                         int L2, Loader ld,
@@ -85,21 +96,24 @@ __global__ __launch_bounds__((cols_threads<S, T>()), 2) void k_cols_fwd_t(const 
     const int batch = blockIdx.y;
     const int c0 = tile * T;
     if constexpr (has_carrier<Loader>::value) {
-        // a thread keeps its column and walks the rows in steps of NT / T: the carrier advances by a
-        // constant angle, so it is rotated in f64 and re-evaluated exactly every 8th step and where the
-        // periodic extension wraps (the phase index restarts there)
+        // a thread keeps its column and walks the rows in steps of NT / T: the carrier advances by a constant angle, so it is
+        // a phasor rotated in fp32 from a start taken at the f64-reduced phase (SignalLoader::phasor32), taken again where the
+        // periodic extension wraps (the phase index restarts there) and every 16th step (S * T / NT = 12 steps here: never).
+        // Rounds 1-4 rotated in f64 and called the f64 sincospi five times per thread -- start, step, 8th step, and twice
+        // for the inter-pass twiddle below: 750 of the kernel's 1650 vector instructions per wave, and the vector pipe was
+        // 100 % busy (profiles/r04_b1c_pmc.txt).  fp32 rotation over <= 15 steps: ~1e-6, the rounding of the transform itself.
         static_assert(NT % T == 0, "column of a thread must stay fixed");
         const int j = tid % T, col = c0 + j;
         const long dn = (long)(NT / T) * L2;
-        double wr, wi, c = 1.0, sn = 0.0;
-        ld.step(batch, dn, &wr, &wi);
+        float wr, wi, c = 1.f, sn = 0.f;
+        ld.step32(batch, dn, &wr, &wi);
         int it = 0;
         for (int r = tid / T; r < S; r += NT / T, ++it) {
             const long n = (long)r * L2 + col;
-            if ((it & 7) == 0 || (n >= ld.n_circ && n - dn < ld.n_circ)) {
-                ld.exact(batch, n, &c, &sn);
+            if ((it & 15) == 0 || (n >= ld.n_circ && n - dn < ld.n_circ)) {
+                ld.exact32(batch, n, &c, &sn);
             } else {
-                const double nr = c * wr - sn * wi;
+                const float nr = c * wr - sn * wi;
                 sn = c * wi + sn * wr;
                 c = nr;
             }
@@ -116,20 +130,22 @@ __global__ __launch_bounds__((cols_threads<S, T>()), 2) void k_cols_fwd_t(const 
     TPlan<S>::template run<T, NT, -1>(lds, tw_lds, tid, LdsIO{}, LdsIO{});
     float2 *o = out + (long)batch * out_stride;
     // inter-pass twiddle W_L^(k1 col) = exp(-j 2 pi k1 col / L): a thread keeps its column and walks k1
-    // in steps of NT / T, so the twiddle is an f64 rotation from an exact start (a table look-up per
-    // element is two scattered loads per lane and made this kernel TA-bound)
+    // in steps of NT / T, so the twiddle is a rotation from a start whose phase is an exact integer ratio (a table look-up
+    // per element is two scattered loads per lane and made this kernel TA-bound); fp32 phasors as for the carrier above
     static_assert(NT % T == 0, "column of a thread must stay fixed");
     (void)twl;
     {
         const int j = tid % T, col = c0 + j, k0 = tid / T;
         constexpr int dk = NT / T;
         const long L = (long)S * L2;
-        double wr, wi, c, sn;
-        sincospi(-2.0 * (double)(((long)dk * col) % L) / (double)L, &wi, &wr);
-        sincospi(-2.0 * (double)(((long)k0 * col) % L) / (double)L, &sn, &c);
-        for (int k1 = k0; k1 < S; k1 += dk) {
-            if (col < L2) o[(long)k1 * L2 + col] = cmul(lds[j * SP + k1 + (k1 >> 4)], make_float2((float)c, (float)sn));
-            const double nr = c * wr - sn * wi;
+        float wr, wi, c, sn;
+        phasor32_neg((double)(((long)dk * col) % L) / (double)L, &wr, &wi);
+        phasor32_neg((double)(((long)k0 * col) % L) / (double)L, &c, &sn);
+        int it = 0;
+        for (int k1 = k0; k1 < S; k1 += dk, ++it) {
+            if (it && (it & 15) == 0) phasor32_neg((double)(((long)k1 * col) % L) / (double)L, &c, &sn);
+            if (col < L2) o[(long)k1 * L2 + col] = cmul(lds[j * SP + k1 + (k1 >> 4)], make_float2(c, sn));
+            const float nr = c * wr - sn * wi;
             sn = c * wi + sn * wr;
             c = nr;
         }

@@ -61,6 +61,26 @@ struct SignalLoader {
         const double cyc = freq(batch) * ((double)dn * inv_fs);
         sincospi(2.0 * (cyc - floor(cyc)), s, c);
     }
+    // fp32 phasors from the f64-reduced phase (round 4, forward column pass): the turn count is reduced in f64 as above, the
+    // sine / cosine taken in fp32 with the first-order correction for the rounding of the fraction -- ~1e-7, a third of the
+    // instructions of an f64 sincospi, which made that kernel vector-bound (five per thread for twelve elements)
+    static __device__ __forceinline__ void phasor32(double cyc, float *c, float *s) {
+        const double fr = cyc - floor(cyc);
+        const float hi = (float)fr;
+        const float lo = (float)(fr - (double)hi);
+        float s0, c0;
+        sincospif(2.0f * hi, &s0, &c0);
+        const float d = 6.28318530717958647692f * lo;
+        *c = c0 - d * s0;
+        *s = s0 + d * c0;
+    }
+    __device__ __forceinline__ void exact32(int batch, long n, float *c, float *s) const {
+        const long m = n < n_circ ? n : n - n_circ;
+        phasor32(freq(batch) * ((double)m * inv_fs), c, s);
+    }
+    __device__ __forceinline__ void step32(int batch, long dn, float *c, float *s) const {
+        phasor32(freq(batch) * ((double)dn * inv_fs), c, s);
+    }
     __device__ __forceinline__ float2 mix(long n, double c, double s) const {
         if (n >= n_ext) return make_float2(0.f, 0.f);
         const double2 xv = sig.load(n < n_circ ? n : n - n_circ);
