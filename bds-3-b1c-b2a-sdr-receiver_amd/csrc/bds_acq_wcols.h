@@ -227,9 +227,12 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     // goes out behind phase A's arithmetic, where its latency is covered by phase B of component 0.
     Raw pre0[R1], pre1[(NCOMP > 1 && !ILV) ? R1 : 1];
     C twA[R1];  // w_S^(b p), inverse direction
+    C twB1;  // w_64^u, the first of the phase-B constants (the others are its powers, formed behind phase A)
     {
         const float2 t = A.wtab[tid];
         cx_set(twA[1], t.x, t.y);
+        const float2 u = A.wtab[(R1 - 1) * W::NT + lane];
+        cx_set(twB1, u.x, u.y);
     }
     fetch(pre0, 0);
     PH_MARK(17);  // rows of component 0 requested
@@ -325,11 +328,12 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
                 // the deferred requests (see above): answered while phase B of this component runs
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NCOMP > 1 && !ILV) fetch(pre1, 1);
+                // w_64^(u j) as powers of w_64^u: six complex products instead of six more load instructions, each of which
+                // costs this wave ~200 cycles of issue time here (round 4, late: the phase clocks showed component 0's phase A
+                // at 2.7 k cycles against 1.1 k for component 1's)
+                twB[1] = twB1;
 #pragma unroll
-                for (int j = 1; j < 8; ++j) {
-                    const float2 t = A.wtab[(R1 - 1) * W::NT + (j - 1) * 64 + lane];
-                    cx_set(twB[j], t.x, t.y);
-                }
+                for (int j = 2; j < 8; ++j) twB[j] = (j & 1) ? cx_mul(twB[j - 1], twB1) : cx_mul(twB[j / 2], twB[j / 2]);
                 // the cell's maximum so far and the PRN's running bound (L2 / fabric latency), used after the transforms;
                 // stale values are lower values, which only costs a redundant visit of the rare path below
                 lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
