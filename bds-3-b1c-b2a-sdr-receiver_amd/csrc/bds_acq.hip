@@ -547,27 +547,37 @@ static void launch_cols_fwd_t(bds_ctx *ctx, hipStream_t s_, const Plan2D &pl, Lo
 }
 template <int S, class ST>
 static void launch_rows_fwd_t(bds_ctx *ctx, hipStream_t s_, const Plan2D &pl, int nb, const float2 *Bw, ST *dst, long dst_stride,
-                              int conj_flag, float scale) {
+                              int conj_flag, float scale, int perm) {
     const size_t lds = sizeof(float2) * (tspan<S>() + lds_span(twiddle_entries<S>()));
     want_lds(ctx, k_rows_fwd_t<S, ST>, lds);
     hipLaunchKernelGGL((k_rows_fwd_t<S, ST>), dim3(pl.L1, nb), dim3(rows_threads<S>()), lds, s_, (const float2 *)pl.d_tw2, Bw,
-                       pl.L, dst, dst_stride, conj_flag, scale);
+                       pl.L, dst, dst_stride, conj_flag, scale, perm);
 }
 template <class ST>
 static void launch_rows_fwd_any(bds_ctx *ctx, hipStream_t s_, const Plan2D &pl, int nb, const float2 *Bw, ST *dst, long dst_stride,
-                                int conj_flag, float scale) {
+                                int conj_flag, float scale, int perm) {
     switch (pl.L2) {
-        case 1280: launch_rows_fwd_t<1280, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
-        case 2048: launch_rows_fwd_t<2048, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
-        case 3072: launch_rows_fwd_t<3072, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
-        default: launch_rows_fwd_t<4096, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale); break;
+        case 1280: launch_rows_fwd_t<1280, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale, 0); break;
+        case 2048: launch_rows_fwd_t<2048, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale, 0); break;
+        case 3072: launch_rows_fwd_t<3072, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale, 0); break;
+        default: launch_rows_fwd_t<4096, ST>(ctx, s_, pl, nb, Bw, dst, dst_stride, conj_flag, scale, perm); break;
     }
+}
+
+// The spectra of this configuration are stored in the element order of the wave-private 4096-point row pass (wrows_perm(),
+// bds_acq_fast.h): exactly when launch_rows_f will run k_rows_wave_f on them -- fp16 storage, 4096-point rows, a specialised
+// plan (or the 80 x 4096 one) and the specialised search not switched off.  Every fallback (fp32 storage, run-time-plan
+// kernels) clears a.half and re-runs bds_acq_prepare, which rebuilds the spectra in natural order.
+static bool spectra_permuted(const bds_ctx *ctx, const AcqState &a) {
+    const Plan2D &pl = a.plan;
+    return a.half && pl.L2 == 4096 && (pl.fast || pl.small) && (ctx->tune.wrows != 0 || pl.small) && !a.no_fast_search;
 }
 
 template <class Loader>
 static int forward(bds_ctx *ctx, AcqState &a, Loader ld, int nb, float2 *dst, long dst_stride, int conj_flag,
                    float scale) {
     Plan2D &pl = a.plan;
+    const int perm = spectra_permuted(ctx, a) ? 1 : 0;
     if (pl.fast && !ctx->tune.generic_fwd) {
         switch (pl.L1) {
             case 256: launch_cols_fwd_t<256>(ctx, st(ctx), pl, ld, nb, a.d_Bw); break;
@@ -576,9 +586,9 @@ static int forward(bds_ctx *ctx, AcqState &a, Loader ld, int nb, float2 *dst, lo
             default: launch_cols_fwd_t<1024>(ctx, st(ctx), pl, ld, nb, a.d_Bw); break;
         }
         if (a.half)
-            launch_rows_fwd_any<__half2>(ctx, st(ctx), pl, nb, (const float2 *)a.d_Bw, (__half2 *)dst, dst_stride, conj_flag, scale);
+            launch_rows_fwd_any<__half2>(ctx, st(ctx), pl, nb, (const float2 *)a.d_Bw, (__half2 *)dst, dst_stride, conj_flag, scale, perm);
         else
-            launch_rows_fwd_any<float2>(ctx, st(ctx), pl, nb, (const float2 *)a.d_Bw, dst, dst_stride, conj_flag, scale);
+            launch_rows_fwd_any<float2>(ctx, st(ctx), pl, nb, (const float2 *)a.d_Bw, dst, dst_stride, conj_flag, scale, 0);
         BDS_HIP(ctx, hipGetLastError());
         return BDS_OK;
     }
@@ -587,7 +597,7 @@ static int forward(bds_ctx *ctx, AcqState &a, Loader ld, int nb, float2 *dst, lo
                        pl.logT, pl.Spad, ld, a.d_Bw, pl.L);
     if (a.half)  // dst counts in stored elements (fp16 complex)
         hipLaunchKernelGGL(k_rows_fwd_st<__half2>, g2, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2,
-                           (const float2 *)a.d_Bw, pl.L, (__half2 *)dst, dst_stride, conj_flag, scale);
+                           (const float2 *)a.d_Bw, pl.L, (__half2 *)dst, dst_stride, conj_flag, scale, perm);
     else
         hipLaunchKernelGGL(k_rows_fwd, g2, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2, (const float2 *)a.d_Bw,
                            pl.L, dst, dst_stride, conj_flag, scale);

@@ -24,6 +24,17 @@ __device__ __forceinline__ float2 ld_c(const __half2 *p, long i) { return __half
 __device__ __forceinline__ void st_c(float2 *p, long i, float2 v) { p[i] = v; }
 __device__ __forceinline__ void st_c(__half2 *p, long i, float2 v) { p[i] = __float22half2_rn(v); }
 
+// Element order of a 4096-point spectrum row as the wave-private row pass reads it (bds_acq_wrows.h, round 4): thread t of
+// its workgroup -- wave w = t / 64, lane (ql = t & 3, bl = (t & 63) >> 2), q' = 4 w + ql -- multiplies the sixteen elements
+// e = 16 bl + q' + 256 bh, bh = 0 .. 15.  Stored at [16 t + bh] they are 64 contiguous bytes per thread and 4 KB per wave:
+// four 16-byte loads per lane and row instead of sixteen 4-byte ones in 16-byte pieces.  The forward row pass writes the rows
+// of the signal and code spectra in this order whenever the search will run that kernel (spectra_permuted() in bds_acq.hip).
+__host__ __device__ __forceinline__ constexpr int wrows_perm(int e) {
+    const int bh = e >> 8, r = e & 255, bl = r >> 4, qp = r & 15;
+    const int t = 64 * (qp >> 2) + 4 * bl + (qp & 3);
+    return 16 * t + bh;
+}
+
 template <int S>
 __host__ __device__ constexpr int rows_threads() { return S / 16 < 64 ? 64 : ((S / 16 + 63) / 64) * 64; }
 #ifndef BDS_COLS768X8_NT
@@ -43,7 +54,7 @@ __host__ __device__ constexpr int cols_threads() {
 template <class ST>
 __global__ __launch_bounds__(1024) void k_rows_fwd_st(Plan1D p, const float2 *__restrict__ in, long in_stride,
                                                       ST *__restrict__ out, long out_stride, int conj_flag,
-                                                      float scale) {
+                                                      float scale, int perm) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int row = blockIdx.x, batch = blockIdx.y;
@@ -57,7 +68,7 @@ __global__ __launch_bounds__(1024) void k_rows_fwd_st(Plan1D p, const float2 *__
         float2 v = lds[lds_phys(e)];
         v.x *= scale;
         v.y *= conj_flag ? -scale : scale;
-        st_c(dst, e, v);
+        st_c(dst, perm ? wrows_perm(e) : e, v);  // (perm: 4096-point rows only)
     }
 }
 
@@ -158,7 +169,7 @@ template <int S, class ST>
 __global__ __launch_bounds__(rows_threads<S>(), 3) void k_rows_fwd_t(const float2 *__restrict__ tw,
                                                                    const float2 *__restrict__ in, long in_stride,
                                                                    ST *__restrict__ out, long out_stride,
-                                                                   int conj_flag, float scale) {
+                                                                   int conj_flag, float scale, int perm) {
     constexpr int NT = rows_threads<S>();
     extern __shared__ __attribute__((aligned(16))) float2 lds[];  // tspan<S>() data + twiddle table
     float2 *tw_lds = lds + tspan<S>();
@@ -169,8 +180,36 @@ __global__ __launch_bounds__(rows_threads<S>(), 3) void k_rows_fwd_t(const float
     ST *dst = out + (long)batch * out_stride + (long)row * S;
     const float sy = conj_flag ? -scale : scale;
     auto src = [&](int, int, int, int e) { return src_row[e]; };
-    auto dstf = [&](int, int, int, int e, float2 v) { st_c(dst, e, make_float2(v.x * scale, v.y * sy)); };
+    // perm (4096-point rows, fp16 storage): the last stage leaves thread t the outputs t + 256 q, which wrows_perm() puts at
+    // sixteen consecutive stored elements -- collected in registers, then written below
+    constexpr bool kCanPerm = S == 4096 && std::is_same<ST, __half2>::value;
+    [[maybe_unused]] uint32_t hv[16];
+    auto dstf = [&](int, int q, int, int e, float2 v) {
+        const float2 w = make_float2(v.x * scale, v.y * sy);
+        if constexpr (kCanPerm) {
+            if (perm) {
+                const __half2 h = __float22half2_rn(w);
+                hv[q] = *reinterpret_cast<const uint32_t *>(&h);
+                return;
+            }
+        }
+        st_c(dst, e, w);
+    };
     TPlan<S>::template run<1, NT, -1>(lds, tw_lds, tid, src, dstf);
+    if constexpr (kCanPerm) {
+        if (perm) {
+            // through LDS, so that the row leaves in full lines (a thread's 64 bytes straight to memory are four 16-byte
+            // pieces per store instruction at a 64-byte stride: forward pass 3.7 -> 4.05 ms)
+            __syncthreads();  // every thread has read its inputs of the last stage
+            uint4 *l4 = reinterpret_cast<uint4 *>(lds);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) l4[wrows_perm(tid) / 4 + k] = make_uint4(hv[4 * k], hv[4 * k + 1], hv[4 * k + 2], hv[4 * k + 3]);
+            __syncthreads();
+            uint4 *g4 = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g4[tid + NT * k] = l4[tid + NT * k];
+        }
+    }
 }
 
 // 16-byte-per-lane global access: four consecutive complex elements

@@ -19,7 +19,8 @@
 //       back IN PLACE at [m][8 u + bl]; then lane (ml, u) reads row u, radix-8 over bl, magnitudes in registers.
 //       (Columns are swapped inside aligned quads by (ml >> 1) -- struct WCols -- which keeps every access class conflict-free.)
 //   Two LDS round trips per point instead of three-plus-tables, three barriers per tile and two components
-//   instead of twelve-plus, every stage twiddle a per-lane constant (one coalesced load each from a per-lane table),
+//   instead of twelve-plus, every stage twiddle a per-lane constant (round 4: TWO coalesced loads from a per-lane table,
+//   w_S^b and w_64^u -- the other sixteen are their powers: a load instruction costs a wave ~200 cycles of issue time here),
 //   the rows of both components in flight before anything else happens.
 //   Every LDS access class is bank-conflict free (tools/proto_cols_wave.py models the layouts lane by lane).
 //

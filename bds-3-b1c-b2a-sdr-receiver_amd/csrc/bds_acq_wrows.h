@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
     }
     const int ql = lane & 3, bl = lane >> 2;  // phase 1a: (ql, bl); phase 1b: (ql, u = bl)
     const int qp = 4 * wave + ql;             // this lane's q' in phase 1
-    const int xoff = 16 * bl + qp;            // its inputs: xoff + 256 bh
+    // its inputs: elements 16 bl + qp + 256 bh of the spectrum rows
     C *const ldsc = reinterpret_cast<C *>(ldsf);
     C *const wr1 = ldsc + wave * kWRowsRegion + lane;                     // + 64 u
     const C *const rd1 = ldsc + wave * kWRowsRegion + 64 * bl + ql;       // + 4 ((j + u) & 15)
@@ -92,12 +92,20 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         if (A.cell_cs) Cs += A.cell_cs[g0];
         if (tid < 16) s_b[tid] = A.twl.get<+1>((uint32_t)((long)k1 * 256 * tid));
         // spectrum row of the next cell, raw as stored: elements xoff + 256 bh
+        // (stored in the order this kernel multiplies them, wrows_perm() of bds_acq_fast.h: element xoff + 256 bh of the row
+        //  sits at [16 tid + bh] -- four 16-byte loads per lane, 4 KB contiguous per wave)
         uint32_t xn[16];
+        auto fetch16 = [&](const ST *row, uint32_t(&d)[16]) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(row + 16 * tid);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint4 v = p[k];
+                d[4 * k] = v.x, d[4 * k + 1] = v.y, d[4 * k + 2] = v.z, d[4 * k + 3] = v.w;
+            }
+        };
         auto fetch_x = [&](int g) {
             const int bin = A.cell_bin ? A.cell_bin[g] : A.bin0 + g;
-            const ST *xr = (const ST *)A.Xs + (long)bin * L + (long)k1 * S + xoff;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) xn[q] = *reinterpret_cast<const uint32_t *>(xr + q * 256);
+            fetch16((const ST *)A.Xs + (long)bin * L + (long)k1 * S, xn);
         };
         // The inter-pass twiddle W_L^(k1 e) of output e = tid + 256 p' factors into a per-thread part
         //   wi = W_L^(k1 tid) x storage scale x w16^(u v) (u = tid & 15, v = tid >> 4: undoes the rotated read of phase 1b)
@@ -133,9 +141,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         uint32_t cv[NCOMP][16];
 #pragma unroll
         for (int comp = 0; comp < NCOMP; ++comp) {
-            const ST *cr = Cs + (long)comp * L + (long)k1 * S + xoff;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) cv[comp][q] = *reinterpret_cast<const uint32_t *>(cr + q * 256);
+            fetch16(Cs + (long)comp * L + (long)k1 * S, cv[comp]);
         }
         PH_MARK(16);  // workgroup prologue: twiddles, code rows issued
         for (int g = g0; g < g1; ++g) {
