@@ -409,6 +409,13 @@ void acq_state_free(AcqState *a) {
     delete a;
 }
 
+// After the tuning knobs changed: the plan, the storage mode and the element order of the cached spectra all depend on them
+// (spectra_permuted() must agree between the forward transforms and the search), so the next bds_acq_prepare re-derives
+// everything.  The loaded IF block stays.
+void acq_state_invalidate(AcqState *a) {
+    if (a) a->plan.L = 0;
+}
+
 static int check_settings(bds_ctx *ctx, const bds_settings &s) {
     if (s.signal != BDS_SIGNAL_B1C && s.signal != BDS_SIGNAL_B2A)
         return fail(ctx, BDS_ERR_ARG, "settings.signal must be BDS_SIGNAL_B1C or BDS_SIGNAL_B2A");

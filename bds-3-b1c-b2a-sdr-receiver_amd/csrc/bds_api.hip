@@ -118,6 +118,7 @@ extern "C" bds_ctx *bds_create(int device_id) {
 extern "C" int bds_reload_tuning(bds_ctx *ctx) {
     if (!ctx) return BDS_ERR_ARG;
     ctx->tune = bds::tuning_from_env();
+    bds::acq_state_invalidate(ctx->acq);  // plan, storage mode and spectrum layout follow the knobs
     return BDS_OK;
 }
 

@@ -63,6 +63,7 @@ Tuning tuning_from_env();
 struct AcqState;    // bds_acq.hip
 struct TrackState;  // bds_track.hip
 void acq_state_free(AcqState *);
+void acq_state_invalidate(AcqState *);  // forget the configuration (plan, storage mode, cached spectra): re-derived by the next prepare
 void track_state_free(TrackState *);
 
 }  // namespace bds

@@ -154,7 +154,8 @@ typedef struct bds_ctx bds_ctx;
 BDS_API bds_ctx *bds_create(int device_id);
 BDS_API void bds_destroy(bds_ctx *ctx);
 /* Tuning / test hook: the BDS_* environment knobs (tools/README.md) are read once, at bds_create, into the
- * context; this re-reads them into an existing context.  Never needed by a host application. */
+ * context; this re-reads them into an existing context and makes the next bds_acq_prepare re-derive the acquisition
+ * configuration (plan, storage mode, cached code spectra).  Never needed by a host application. */
 BDS_API int bds_reload_tuning(bds_ctx *ctx);
 BDS_API const char *bds_last_error(const bds_ctx *ctx); /* ctx may be NULL: creation errors */
 BDS_API int bds_device_name(const bds_ctx *ctx, char *buf, int buflen);
