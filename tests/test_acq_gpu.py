@@ -304,3 +304,32 @@ def test_fine_search_carrier_of_exactly_zero_becomes_one(ctx):
     assert ref.carrFreq[6] == 1.0 and got.carrFreq[6] == 1.0
     np.testing.assert_array_equal(got.codePhase, ref.codePhase)
     np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6)
+
+
+def test_tuning_reload_rebuilds_the_spectrum_layout(ctx, monkeypatch):
+    """The wave-private row pass reads spectrum rows in its own element order (wrows_perm, written so by the forward row pass),
+    k_rows_inv_f in natural order.  Switching between them on ONE context with UNCHANGED settings must rebuild the cached code
+    spectra: bds_reload_tuning invalidates the acquisition configuration."""
+    from helpers import spc_of
+    from bds_amd import synth
+    monkeypatch.setenv("BDS_ACQ_FORCE_L1L2", "512x4096")
+    ctx.reload_tuning()
+    try:
+        s = bds_amd.init_settings_b1c(samplingFreq=10.3e6, IF=2.5e6, acqSatelliteList=[7, 19, 33], acqSearchBand=200, acqStep=100)
+        spc = spc_of(s)
+        sats = [synth.Sat(19, 130.0, 0.41 * spc, 0.7, 47.0), synth.Sat(33, -90.0, 0.83 * spc, 2.2, 45.0)]
+        x = synth.make_if(s, sats, 3 * spc, seed=78)
+        ref = oacq.acquisition_b1c(x.astype(np.float64), s)
+        for wrows, kernel in (("1", 2), ("0", 1), ("1", 2)):
+            monkeypatch.setenv("BDS_ACQ_WROWS", wrows)
+            ctx.reload_tuning()
+            got = bds_amd.acquisition(x, s, verbose=False)
+            tm = ctx.timing()
+            assert tm["rows_kernel"] == kernel and tm["half_storage"] == 1, (wrows, tm)
+            np.testing.assert_array_equal(got.codePhase, ref.codePhase, err_msg=wrows)
+            np.testing.assert_array_equal(got.carrFreq, ref.carrFreq, err_msg=wrows)
+            np.testing.assert_allclose(got.peakMetric, ref.peakMetric, rtol=1e-6, atol=0, err_msg=wrows)
+    finally:
+        monkeypatch.delenv("BDS_ACQ_FORCE_L1L2", raising=False)
+        monkeypatch.delenv("BDS_ACQ_WROWS", raising=False)
+        ctx.reload_tuning()
