@@ -116,7 +116,9 @@ static bool fast_rows(int b) { return b == 1280 || b == 2048 || b == 3072 || b =
 // Padded length L >= need (5-smooth) and its split L1 x L2, chosen by a cost model:
 // L * (stage costs of both passes + a memory term) -- a slightly longer transform made of
 // radix-16 stages beats the tightest 5-smooth length made of 3s and 5s.
-static bool choose_lengths(const Tuning &tune, long need, long &L, int &L1, int &L2, bool allow_small) {
+// small_ok: the 80 x 4096 plan may be chosen (small_plan_ok(): two components, fp16 storage, the specialised kernels on, and
+// every searched lag inside the output rows k_cols_small_f forms)
+static bool choose_lengths(const Tuning &tune, long need, long &L, int &L1, int &L2, bool small_ok) {
     const double kMem = 3.0;  // HBM/L2 traffic of the two passes, in units of one LDS stage
     double best = 1e30;
     const long lo = std::max<long>(need, 64), hi = lo + lo / 2 + 64;
@@ -139,7 +141,7 @@ static bool choose_lengths(const Tuning &tune, long need, long &L, int &L1, int 
             if (fast_cols(a) && fast_rows((int)b)) c *= 0.6;  // specialised kernels exist
             // 80 x 4096 (round 4): 4096-point rows on the wave-private row pass, 80-point columns one lane each -- measured
             // against 256 x 1280 at cfg2: see DESIGN.md 1.6
-            if (allow_small && a == kSColsLen && b == 4096) c *= 0.4;
+            if (small_ok && a == kSColsLen && b == 4096) c *= 0.4;
             if (c < best) best = c, L = cand, L1 = a, L2 = (int)b;
         }
     }
@@ -248,11 +250,20 @@ static int upload_twiddles(bds_ctx *ctx, int n, long denom, long step, float2 **
     return BDS_OK;
 }
 
-static int plan_build(bds_ctx *ctx, Plan2D &pl, long need, bool allow_small) {
+// The register column pass of the 80 x 4096 plan forms output rows 0 .. kSColsOut - 1 only (bds_acq_scols.h): the plan is
+// eligible -- and gets its cost bonus in choose_lengths -- only when the largest searched lag N - 1 lies in those rows and
+// the kernels that need it will really run (the same predicate sets pl.small).  cfg2: N = 198 750 -> row 48.  B2a at
+// 102 MS/s (N = 204 000 -> row 49) or B1C with pilot at 25 MS/s, cohT 1 (N = 275 000 -> row 67) stay on 256 x 1280.
+static bool small_plan_ok(const Tuning &tune, long n_lags, bool allow_small) {
+    return allow_small && !tune.generic && n_lags >= 1 && (n_lags - 1) / 4096 < kSColsOut;
+}
+
+static int plan_build(bds_ctx *ctx, Plan2D &pl, long need, long n_lags, bool allow_small) {
     plan_free(pl);
     const Tuning &tune = ctx->tune;
     pl.small = false;
-    if (!choose_lengths(tune, need, pl.L, pl.L1, pl.L2, allow_small))
+    const bool small_ok = small_plan_ok(tune, n_lags, allow_small);
+    if (!choose_lengths(tune, need, pl.L, pl.L1, pl.L2, small_ok))
         return fail(ctx, BDS_ERR_UNSUPPORTED, "no two-pass transform plan for length >= %ld", need);
     factor_radices(pl.L1, pl.p1);
     factor_radices(pl.L2, pl.p2);
@@ -276,7 +287,7 @@ static int plan_build(bds_ctx *ctx, Plan2D &pl, long need, bool allow_small) {
     pl.lds_cols = sizeof(float2) * (size_t)pl.Spad * (size_t)(1 << logT);
     pl.lds_rows = sizeof(float2) * (size_t)lds_span(pl.L2);
     pl.fast = want_fast;
-    pl.small = allow_small && pl.L1 == kSColsLen && pl.L2 == 4096 && !tune.generic;
+    pl.small = small_ok && pl.L1 == kSColsLen && pl.L2 == 4096;
     if (tune.verbose) {
         fprintf(stderr, "[bds] search kernels: %s\n", pl.fast ? "specialised" : "generic");
         fprintf(stderr, "[bds] plan: need %ld -> L %ld = %d (cols:", need, pl.L, pl.L1);
@@ -375,6 +386,7 @@ struct AcqState {
     size_t lb_cap = 0;
     std::map<int, std::vector<std::pair<int, long>>> last_cands;  // PRN -> (bin, lag) cells the last run refined in f64
     bool no_fast_search = false;     // this configuration fell back to the run-time-plan search kernels
+    bool no_small = false;           // this configuration's 80 x 4096 plan fell back to fp32 storage: re-planned without it
     CorrJob *d_jobs = nullptr;
     double2 *d_jobout = nullptr;
     size_t jobs_cap = 0;
@@ -471,10 +483,10 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
         ncomp = 2;
     }
     if (X < 1 || X > spc || N <= X) return fail(ctx, BDS_ERR_ARG, "degenerate acquisition sizes (spc=%ld X=%ld N=%ld)", spc, X, N);
-    const bool same = a.signal == s.signal && a.fs == s.samplingFreq && a.cfb == s.codeFreqBasis &&
-                      a.cohT == s.acqCohT && a.pilotACQ == s.pilotACQflag && a.code_len == s.codeLength &&
-                      a.plan.L > 0;
-    if (same) return BDS_OK;
+    const bool same_key = a.signal == s.signal && a.fs == s.samplingFreq && a.cfb == s.codeFreqBasis &&
+                          a.cohT == s.acqCohT && a.pilotACQ == s.pilotACQflag && a.code_len == s.codeLength;
+    if (same_key && a.plan.L > 0) return BDS_OK;
+    if (!same_key) a.no_small = false;  // (set by the fp32-storage fallback of an 80 x 4096 plan, which re-plans with plan.L = 0)
     a.no_fast_search = false;
     a.code_have.clear();  // sampled-code cache: same key
     a.cs_slot.clear();  // the spectra cache is keyed by everything above: drop it (slot size depends on L)
@@ -492,8 +504,8 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
     a.n_ext = N + X - 1;
     a.ncomp = ncomp;
     // (the 80 x 4096 plan: two components, fp16 storage, wave-private row pass available; BDS_ACQ_SMALL=0 keeps 256 x 1280)
-    const bool allow_small = ncomp == 2 && ctx->tune.fp16_storage != 0 && ctx->tune.small_plan != 0 && ctx->tune.wcols != 0;
-    if ((rc = plan_build(ctx, a.plan, a.n_ext, allow_small))) return rc;
+    const bool allow_small = ncomp == 2 && ctx->tune.fp16_storage != 0 && ctx->tune.small_plan != 0 && ctx->tune.wcols != 0 && !a.no_small;
+    if ((rc = plan_build(ctx, a.plan, a.n_ext, N, allow_small))) return rc;
     a.group_env = ctx->tune.group;
     // default: fp32 search arithmetic on fp16-stored spectra (BDS_ACQ_FP16=0: fp32 storage)
     a.half = (a.plan.fast || a.plan.small) && ctx->tune.fp16_storage != 0;
@@ -1911,6 +1923,14 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         AcqState &a = *ctx->acq;
         const bool plain_kernels = rc == kRedoPlain;
         if (ctx->tune.verbose) fprintf(stderr, "[bds] search re-run (%s): %s\n", plain_kernels ? "run-time-plan kernels" : "fp32 storage", why.c_str());
+        if (a.plan.small) {
+            // the 80 x 4096 plan has no fp32-storage kernels of its own: re-plan (256 x 1280 for cfg2) so that the re-run takes
+            // the specialised fp32 pair instead of the run-time-plan kernels on 80 x 4096
+            a.no_small = true;
+            a.plan.L = 0;
+            bds_settings eff;
+            if (int rc2 = acq_configure(ctx, *effective(s_in, &eff))) return rc2;
+        }
         a.half = false;
         a.no_fast_search = a.no_fast_search || plain_kernels;
         a.sC = 1.f;

@@ -61,6 +61,7 @@ struct TrkParams {
     int cplx;        // fileType 2: the record is interleaved I/Q int8 pairs (tracking.m:132-136,242-246)
     int chunk;       // samples per correlate workgroup
     int runs;        // 1: run-based correlator (correlate_runs), chunk = kTrkThreads * 8 or * 16
+    int prec;        // numerics of the run-based correlator's carrier wipe-off and prefix sums (Tuning::trk_prec)
     int code_len;    // 10230
     int n_epochs;
     double fs, inv_fs;
@@ -275,11 +276,13 @@ __device__ __forceinline__ int first_sample_of(double st, double inc, double inv
 }
 
 // LDS of one wave of correlate_runs<., SEG>: prefix sums, segment bases, rotation table, code-table slices
-__host__ __device__ constexpr size_t runs_wave_lds(int seg) {
-    return (size_t)(64 * seg + 64) * 8 + 64 * 16 + (size_t)seg * 8 + (size_t)kCap1 * 2 + kCap6;
+// (prec: TrkParams::prec -- 0 fp32 carrier + fp32 local prefix sums, 1 f64 prefix sums, 2 f64 carrier too, 3 the
+// reference's own trigarg per sample; f64 prefix entries are 16 bytes, the f64 rotation table as well)
+__host__ __device__ constexpr size_t runs_wave_lds(int seg, int prec) {
+    return (size_t)(64 * seg + 64) * (prec >= 1 ? 16 : 8) + 64 * 16 + (size_t)seg * (prec >= 2 ? 16 : 8) + (size_t)kCap1 * 2 + kCap6;
 }
-static inline size_t runs_lds_bytes(int seg) {
-    return std::max<size_t>(runs_wave_lds(seg) * (kTrkThreads / 64), sizeof(double) * (kTrkThreads / 64) * kNSums);
+static inline size_t runs_lds_bytes(int seg, int prec) {
+    return std::max<size_t>(runs_wave_lds(seg, prec) * (kTrkThreads / 64), sizeof(double) * (kTrkThreads / 64) * kNSums);
 }
 __device__ __forceinline__ void wave_sync() {  // LDS written by this wave is read by other lanes of this wave
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -312,7 +315,7 @@ __device__ __forceinline__ double lane_f64(double v, int l) {  // broadcast of l
 // The waves of a workgroup work independently (wave w on samples k0 + w 64 SEG .. of each chunk, its own LDS
 // slice, no workgroup barrier before the final reduction): the kernel is bound by latency -- HBM reads,
 // dependent f64 evaluations -- and independent waves hide it where barrier-separated phases cannot.
-template <int MODE, int SEG, bool CPLX>
+template <int MODE, int SEG, bool CPLX, int PREC>
 __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, const int8_t *__restrict__ prim_d,
                                                const int8_t *__restrict__ prim_p, const TrkParams &p,
                                                const EpochGeom &g, long k0_first, long k_stride, bool pilot, double *sums) {
@@ -322,12 +325,18 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
     constexpr int NWD = SEG / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char trk_lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    unsigned char *wl = trk_lds + runs_wave_lds(SEG) * wave;
-    float2 *s_loc = reinterpret_cast<float2 *>(wl);                                 // [WCH + 64]: position i at i + i / SEG
-    double2 *s_base = reinterpret_cast<double2 *>(wl + (size_t)(WCH + 64) * 8);     // [64] segment bases
-    float2 *s_w = reinterpret_cast<float2 *>(wl + (size_t)(WCH + 64) * 8 + 64 * 16);  // [SEG]
-    char2 *s_t1 = reinterpret_cast<char2 *>(wl + (size_t)(WCH + 64) * 8 + 64 * 16 + (size_t)SEG * 8);  // [kCap1]
-    int8_t *s_t6 = reinterpret_cast<int8_t *>(s_t1 + kCap1);                                            // [kCap6]
+    // PT: type of a segment's local prefix sums; CT: type of the carrier replica and the wiped samples
+    using PT = std::conditional_t<(PREC >= 1), double, float>;
+    using PT2 = std::conditional_t<(PREC >= 1), double2, float2>;
+    using CT = std::conditional_t<(PREC >= 2), double, float>;
+    using CT2 = std::conditional_t<(PREC >= 2), double2, float2>;
+    constexpr size_t kLoc = (size_t)(WCH + 64) * sizeof(PT2);
+    unsigned char *wl = trk_lds + runs_wave_lds(SEG, PREC) * wave;
+    PT2 *s_loc = reinterpret_cast<PT2 *>(wl);                                       // [WCH + 64]: position i at i + i / SEG
+    double2 *s_base = reinterpret_cast<double2 *>(wl + kLoc);                       // [64] segment bases
+    CT2 *s_w = reinterpret_cast<CT2 *>(wl + kLoc + 64 * 16);                        // [SEG]
+    char2 *s_t1 = reinterpret_cast<char2 *>(wl + kLoc + 64 * 16 + (size_t)SEG * sizeof(CT2));  // [kCap1]
+    int8_t *s_t6 = reinterpret_cast<int8_t *>(s_t1 + kCap1);                                    // [kCap6]
     const int NU = UNITS * p.code_len, n6 = 12 * p.code_len;
     const double inc = g.step * scale, inv_inc = 1.0 / inc;
     const double st3[3] = {(g.rem - p.spacing) * scale, g.rem * scale, (g.rem + p.spacing) * scale};  // E, P, L
@@ -339,12 +348,16 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
     double acc[kNSums];
 #pragma unroll
     for (int i = 0; i < kNSums; ++i) acc[i] = 0.0;
-    if (lane < SEG) {  // rotation of sample j of a segment against its first sample
+    if (PREC < 3 && lane < SEG) {  // rotation of sample j of a segment against its first sample
         const double cyc = g.carrFreq * ((double)lane * p.inv_fs);
         double sn, cs;
         sincospi(2.0 * (cyc - floor(cyc)), &sn, &cs);
-        s_w[lane] = make_float2((float)cs, (float)sn);
+        s_w[lane].x = (CT)cs, s_w[lane].y = (CT)sn;
     }
+    // PREC 3: the carrier argument of every sample exactly as the reference forms it,
+    //   trigarg = (carrFreq*2*pi) .* ((0:blksize) ./ fs) + remCarrPhase   (tracking.m:303-304; left to right, one rounding
+    // per operation: the translation unit is built with -ffp-contract=off), then sin / cos of that f64 value
+    const double w_ref = (g.carrFreq * 2.0) * 3.14159265358979323846;
     // the segment's bytes (I/Q pairs: 2 SEG bytes), whole aligned dwords around it
     uint32_t raw[nwd + 1];
     auto fetch = [&](long kw) {
@@ -398,7 +411,7 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
         // ---- phase 1: wipe the carrier off this lane's SEG samples, exclusive prefix sums of the segment to LDS
         const int kb = k0 + lane * SEG;
         const int n_here = max(0, min(SEG, k1 - kb));
-        float run_i = 0.f, run_q = 0.f;
+        PT run_i = 0, run_q = 0;
         if (n_here > 0) {
             uint32_t wr[nwd];
             {
@@ -406,44 +419,52 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
 #pragma unroll
                 for (int i = 0; i < nwd; ++i) wr[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], sh);
             }
-            const float bcf = (float)bc, bsf = (float)bs;
+            const CT bcf = (CT)bc, bsf = (CT)bs;
             const int lbase = lane * SEG + lane;
-            // sample j of the segment, carrier-wiped: (ib, qb).  The carrier is base x table entry in fp32 with
-            // explicit FMAs (the exact two-rounding rule of the build only matters for the code index)
-            auto wiped = [&](int j, float &ib, float &qb) {
-                float rw, rw_q = 0.f;
+            // sample j of the segment, carrier-wiped: (ib, qb).  PREC < 3: the carrier is base x table entry with
+            // explicit FMAs (the exact two-rounding rule of the build only matters for the code index), in fp32
+            // (PREC 0, 1) or f64 (PREC 2); PREC 3: sin / cos of the reference's own trigarg(k)
+            auto wiped = [&](int j, CT &ib, CT &qb) {
+                CT rw, rw_q = 0;
                 if (CPLX) {  // rawSignal = data(1:2:end) + 1i*data(2:2:end)  (tracking.m:242-246)
                     const uint32_t w = wr[j >> 1];
-                    rw = (float)(int8_t)(w >> ((j & 1) * 16));
-                    rw_q = (float)(int8_t)(w >> ((j & 1) * 16 + 8));
+                    rw = (CT)(int)(int8_t)(w >> ((j & 1) * 16));
+                    rw_q = (CT)(int)(int8_t)(w >> ((j & 1) * 16 + 8));
                 } else {
-                    rw = (float)(int8_t)(wr[j >> 2] >> ((j & 3) * 8));
+                    rw = (CT)(int)(int8_t)(wr[j >> 2] >> ((j & 3) * 8));
                 }
-                const float2 w = s_w[j];
-                const float c2 = fmaf(bcf, w.x, -(bsf * w.y)), s2 = fmaf(bsf, w.x, bcf * w.y);
+                CT c2, s2;
+                if constexpr (PREC == 3) {
+                    const double tt = (double)(kb + j) / p.fs;
+                    const double trig = (w_ref * tt) + g.remCarr;
+                    sincos(trig, &s2, &c2);
+                } else {
+                    const CT2 w = s_w[j];
+                    c2 = fma(bcf, w.x, -(bsf * w.y)), s2 = fma(bsf, w.x, bcf * w.y);
+                }
                 if (MODE == BDS_TRACK_B2A) {  // exp(+j th): q = real, i = imag (tracking.m:309-314)
-                    qb = CPLX ? fmaf(rw, c2, -(rw_q * s2)) : rw * c2;
-                    ib = CPLX ? fmaf(rw, s2, rw_q * c2) : rw * s2;
+                    qb = CPLX ? fma(rw, c2, -(rw_q * s2)) : rw * c2;
+                    ib = CPLX ? fma(rw, s2, rw_q * c2) : rw * s2;
                 } else {  // exp(-j th): i = real, q = imag (NB_tracking.m:320-325)
-                    ib = CPLX ? fmaf(rw, c2, rw_q * s2) : rw * c2;
-                    qb = CPLX ? fmaf(rw_q, c2, -(rw * s2)) : -(rw * s2);
+                    ib = CPLX ? fma(rw, c2, rw_q * s2) : rw * c2;
+                    qb = CPLX ? fma(rw_q, c2, -(rw * s2)) : -(rw * s2);
                 }
             };
             if (n_here == SEG) {  // every segment but the last one of the block
 #pragma unroll
                 for (int j = 0; j < SEG; ++j) {
-                    float ib, qb;
+                    CT ib, qb;
                     wiped(j, ib, qb);
-                    s_loc[lbase + j] = make_float2(run_i, run_q);
-                    run_i += ib, run_q += qb;
+                    s_loc[lbase + j].x = run_i, s_loc[lbase + j].y = run_q;
+                    run_i += (PT)ib, run_q += (PT)qb;
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < SEG; ++j) {
-                    float ib, qb;
+                    CT ib, qb;
                     wiped(j, ib, qb);
-                    s_loc[lbase + j] = make_float2(run_i, run_q);
-                    run_i += j < n_here ? ib : 0.f, run_q += j < n_here ? qb : 0.f;
+                    s_loc[lbase + j].x = run_i, s_loc[lbase + j].y = run_q;
+                    run_i += j < n_here ? (PT)ib : (PT)0, run_q += j < n_here ? (PT)qb : (PT)0;
                 }
             }
         }
@@ -462,7 +483,7 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
         auto prefix = [&](int kk) -> double2 {  // sum of the wiped samples k0 .. kk-1, kk in (k0, k1)
             const int pos = kk - k0, seg = pos / SEG;
             const double2 b = s_base[seg];
-            const float2 l = s_loc[pos + seg];
+            const PT2 l = s_loc[pos + seg];
             return make_double2(b.x + (double)l.x, b.y + (double)l.y);
         };
         if (MODE != BDS_TRACK_B2A) {
@@ -642,7 +663,7 @@ __device__ __forceinline__ void apply_update(const TrkParams &p, ChanState &s, c
 // wait for another and an epoch is one launch instead of two (the update as its own kernel costs ~5 us, mostly the
 // floor of a small dependent launch).  State and partial sums ping-pong between two buffers; workgroup 0 of the channel
 // writes the results of the previous epoch and the state the current one starts from.
-template <int MODE, int SEG, bool CPLX>
+template <int MODE, int SEG, bool CPLX, int PREC>
 __global__ __launch_bounds__(kTrkThreads, BDS_TRK_MINW) void k_trk_correlate(const int8_t *__restrict__ data,
                                                               const int8_t *__restrict__ prim, TrkParams p,
                                                               const ChanState *__restrict__ st_in, ChanState *__restrict__ st_out,
@@ -673,13 +694,13 @@ __global__ __launch_bounds__(kTrkThreads, BDS_TRK_MINW) void k_trk_correlate(con
     const int8_t *pd = prim + ((long)(s.prn - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
     const int8_t *pp = prim + ((long)(s.prn - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
     if constexpr (SEG > 0)  // run-based correlator, SEG samples per lane and pass
-        correlate_runs<MODE, SEG, CPLX>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+        correlate_runs<MODE, SEG, CPLX, PREC>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
     else  // per-sample correlator (reads p.cplx itself)
         correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
 }
 
 // Open-loop variant: geometry supplied by the caller (bds_track_correlate).
-template <int MODE, int SEG, bool CPLX>
+template <int MODE, int SEG, bool CPLX, int PREC>
 __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t *__restrict__ data,
                                                                    const int8_t *__restrict__ prim, TrkParams p,
                                                                    const int *__restrict__ prn,
@@ -703,25 +724,37 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t
     const int8_t *pd = prim + ((long)(prn[ch] - 1) * 2 + 0) * kTabStride;  // (data, pilot) pairs
     const int8_t *pp = prim + ((long)(prn[ch] - 1) * 2 + 1) * kTabStride;  // pilot BOC(6,1)
     if constexpr (SEG > 0)  // run-based correlator, SEG samples per lane and pass
-        correlate_runs<MODE, SEG, CPLX>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
+        correlate_runs<MODE, SEG, CPLX, PREC>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
     else  // per-sample correlator (reads p.cplx itself)
         correlate_slice<MODE>(data, pd, pp, p, g, k0, (long)nblocks * p.chunk, p.pilot != 0, out);
 }
 
-// launch k<MODE, SEG, CPLX> for the run-time (mode, runs, cplx) of p
+// launch k<MODE, SEG, CPLX, PREC> for the run-time (mode, runs, cplx, prec) of p; the f64 prefix sums of PREC >= 1 need
+// more dynamic LDS than the default limit of a kernel: raised once per kernel and context
 #define BDS_TRK_LAUNCH(KERN, grid, lds, stream, ...)                                                        \
     do {                                                                                                    \
-        auto go = [&](auto mode_c) {                                                                        \
-            constexpr int M = decltype(mode_c)::value;                                                      \
-            if (p.runs == 16 && !p.cplx) hipLaunchKernelGGL((KERN<M, 16, false>), grid, dim3(kTrkThreads), lds, stream, __VA_ARGS__); \
-            else if (p.runs == 16) hipLaunchKernelGGL((KERN<M, 16, true>), grid, dim3(kTrkThreads), lds, stream, __VA_ARGS__);       \
-            else if (p.runs == 8 && !p.cplx) hipLaunchKernelGGL((KERN<M, 8, false>), grid, dim3(kTrkThreads), lds, stream, __VA_ARGS__); \
-            else if (p.runs == 8) hipLaunchKernelGGL((KERN<M, 8, true>), grid, dim3(kTrkThreads), lds, stream, __VA_ARGS__);         \
-            else hipLaunchKernelGGL((KERN<M, 0, false>), grid, dim3(kTrkThreads), lds, stream, __VA_ARGS__);                          \
+        auto fire = [&](auto kern) {                                                                        \
+            if ((lds) > 48 * 1024 && ctx->lds_attr_done.insert((const void *)kern).second)                  \
+                (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)); \
+            hipLaunchKernelGGL(kern, grid, dim3(kTrkThreads), lds, stream, __VA_ARGS__);                    \
         };                                                                                                  \
-        if (p.mode == BDS_TRACK_B2A) go(std::integral_constant<int, BDS_TRACK_B2A>{});                      \
-        else if (p.mode == BDS_TRACK_NB) go(std::integral_constant<int, BDS_TRACK_NB>{});                   \
-        else go(std::integral_constant<int, BDS_TRACK_WB>{});                                               \
+        auto go = [&](auto mode_c, auto prec_c) {                                                           \
+            constexpr int M = decltype(mode_c)::value, PR = decltype(prec_c)::value;                        \
+            if (p.runs == 16 && !p.cplx) fire(KERN<M, 16, false, PR>);                                      \
+            else if (p.runs == 16) fire(KERN<M, 16, true, PR>);                                             \
+            else if (p.runs == 8 && !p.cplx) fire(KERN<M, 8, false, PR>);                                   \
+            else if (p.runs == 8) fire(KERN<M, 8, true, PR>);                                               \
+            else fire(KERN<M, 0, false, 0>);                                                                \
+        };                                                                                                  \
+        auto gp = [&](auto mode_c) {                                                                        \
+            if (p.prec == 0) go(mode_c, std::integral_constant<int, 0>{});                                  \
+            else if (p.prec == 1) go(mode_c, std::integral_constant<int, 1>{});                             \
+            else if (p.prec == 2) go(mode_c, std::integral_constant<int, 2>{});                             \
+            else go(mode_c, std::integral_constant<int, 3>{});                                              \
+        };                                                                                                  \
+        if (p.mode == BDS_TRACK_B2A) gp(std::integral_constant<int, BDS_TRACK_B2A>{});                      \
+        else if (p.mode == BDS_TRACK_NB) gp(std::integral_constant<int, BDS_TRACK_NB>{});                   \
+        else gp(std::integral_constant<int, BDS_TRACK_WB>{});                                               \
     } while (0)
 
 __global__ void k_trk_reduce_open(const double *__restrict__ part, int nblocks, double *__restrict__ sums) {
@@ -1024,6 +1057,8 @@ static int fill_params(bds_ctx *ctx, const bds_settings &s, TrkParams &p, int n_
         if (ctx->tune.trk_chunk == 2048) p.runs = 8;
         if (ctx->tune.trk_chunk == 4096) p.runs = 16;
         p.chunk = kTrkThreads * p.runs;
+        p.prec = std::max(0, std::min(3, ctx->tune.trk_prec));
+        if (ctx->tune.trk_seg == 8 || ctx->tune.trk_seg == 16) p.runs = ctx->tune.trk_seg, p.chunk = kTrkThreads * p.runs;
     }
     p.n_bytes = (long long)(n_bytes / (p.cplx ? 2 : 1));  // whole samples an fread can deliver
     return BDS_OK;
@@ -1286,12 +1321,12 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &loa
             ChanState *st_in = d_st + (size_t)cur * n_ch, *st_out = d_st + (size_t)(cur ^ 1) * n_ch;
             const double *part_prev = k > 0 ? d_part + (size_t)(cur ^ 1) * part_n : nullptr;
             double *part_cur = d_part + (size_t)cur * part_n;
-            BDS_TRK_LAUNCH(k_trk_correlate, gc, (p.runs ? runs_lds_bytes(p.runs) : 0), st(ctx), data, (const int8_t *)t.d_prim, p,
+            BDS_TRK_LAUNCH(k_trk_correlate, gc, (p.runs ? runs_lds_bytes(p.runs, p.prec) : 0), st(ctx), data, (const int8_t *)t.d_prim, p,
                            (const ChanState *)st_in, st_out, part_prev, part_cur, nblocks, k, (const TrkOut *)d_out);
             st_final = st_out;
             if (k == n_epochs - 1) launch_update(st_final, part_cur, k);  // the last epoch's update has no next launch to ride on
         } else {
-            BDS_TRK_LAUNCH(k_trk_correlate, gc, (p.runs ? runs_lds_bytes(p.runs) : 0), st(ctx), data, (const int8_t *)t.d_prim, p,
+            BDS_TRK_LAUNCH(k_trk_correlate, gc, (p.runs ? runs_lds_bytes(p.runs, p.prec) : 0), st(ctx), data, (const int8_t *)t.d_prim, p,
                            (const ChanState *)d_st, d_st, (const double *)nullptr, d_part, nblocks, k, (const TrkOut *)d_out);
             launch_update(d_st, d_part, k);
         }
@@ -1456,7 +1491,7 @@ extern "C" int bds_track_correlate(bds_ctx *ctx, const bds_settings *s, const in
     BDS_HIP(ctx, hipMemcpyAsync(d_prn, prn, sizeof(int) * n_ch, hipMemcpyHostToDevice, st(ctx)));
     BDS_HIP(ctx, hipMemcpyAsync(d_s6, state6, sizeof(double) * 6 * n_ch, hipMemcpyHostToDevice, st(ctx)));
     dim3 gc(nblocks, n_ch);
-    BDS_TRK_LAUNCH(k_trk_correlate_open, gc, (p.runs ? runs_lds_bytes(p.runs) : 0), st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p,
+    BDS_TRK_LAUNCH(k_trk_correlate_open, gc, (p.runs ? runs_lds_bytes(p.runs, p.prec) : 0), st(ctx), (const int8_t *)d_data, (const int8_t *)t.d_prim, p,
                    (const int *)d_prn, (const double *)d_s6, d_part, nblocks);
     hipLaunchKernelGGL(k_trk_reduce_open, dim3(n_ch), dim3(64), 0, st(ctx), (const double *)d_part, nblocks, d_sums);
     BDS_HIP(ctx, hipGetLastError());

@@ -9,5 +9,7 @@ contract=off
 [ "$f" = bds_track.hip ] && contract="off -fno-slp-vectorize"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$SRC" -ffp-contract=$contract \
     --cuda-device-only -Rpass-analysis=kernel-resource-usage -c "$SRC/$f" -o /dev/null "$@" 2>&1 |
-  awk '/Function Name:/{name=$NF} /VGPRs:/{v=$NF} /AGPRs:/{a=$NF} /SGPRs:/{s=$NF} /ScratchSize/{sc=$(NF)} /Occupancy/{o=$NF} /LDS Size/{print name, "VGPR", v, "AGPR", a, "SGPR", s, "scratch", sc, "occ", o, "LDS", $(NF-1)}' |
-  while read -r name rest; do echo "$(echo "$name" | c++filt | cut -c1-90) | $rest"; done | grep -E "$pat"
+  sed -n 's/.*remark: *\(.*\) \[-Rpass-analysis=kernel-resource-usage\]$/\1/p' |
+  awk -F': ' '/^Function Name/{name=$2} /^TotalSGPRs/{s=$2} /^VGPRs:/{v=$2} /^AGPRs/{a=$2} /^ScratchSize/{sc=$2} /^Occupancy/{o=$2} /^VGPRs Spill/{vs=$2}
+              /^LDS Size/{print name, "| VGPR", v, "AGPR", a, "SGPR", s, "scratch", sc, "vspill", vs, "occ", o, "LDS", $2}' |
+  while read -r name rest; do echo "$(echo "$name" | c++filt | sed 's/(.*//' | cut -c1-100) $rest"; done | grep -E "$pat"
