@@ -65,7 +65,7 @@ Tuning tuning_from_env() {
     t.trk_nblocks = std::max(0, geti("BDS_TRK_NBLOCKS", 0));
     t.trk_chunk = std::max(0, geti("BDS_TRK_CHUNK", 0));
     t.trk_persample = has("BDS_TRK_PERSAMPLE");
-    t.trk_prec = geti("BDS_TRK_PREC", 0);
+    t.trk_prec = geti("BDS_TRK_PREC", 4);
     t.trk_seg = geti("BDS_TRK_SEG", 0);
     t.trk_nofuse_update = has("BDS_TRK_NOFUSE_UPDATE");
     return t;

@@ -29,6 +29,7 @@
 
 #include "bds_debug.h"
 #include "bds_internal.h"
+#include "bds_strict_math.h"
 
 namespace bds {
 
@@ -438,6 +439,12 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
                     const double tt = (double)(kb + j) / p.fs;
                     const double trig = (w_ref * tt) + g.remCarr;
                     sincos(trig, &s2, &c2);
+                } else if constexpr (PREC == 4) {
+                    const double tt = div_by_fs((double)(kb + j), p.fs, p.inv_fs);
+                    BDS_DASSERT(tt == (double)(kb + j) / p.fs);
+                    BDS_DASSERT(tt == (double)(kb + j) / p.fs);
+                    const double trig = (w_ref * tt) + g.remCarr;
+                    sincos_strict(trig, s2, c2);
                 } else {
                     const CT2 w = s_w[j];
                     c2 = fma(bcf, w.x, -(bsf * w.y)), s2 = fma(bsf, w.x, bcf * w.y);
@@ -750,7 +757,8 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t
             if (p.prec == 0) go(mode_c, std::integral_constant<int, 0>{});                                  \
             else if (p.prec == 1) go(mode_c, std::integral_constant<int, 1>{});                             \
             else if (p.prec == 2) go(mode_c, std::integral_constant<int, 2>{});                             \
-            else go(mode_c, std::integral_constant<int, 3>{});                                              \
+            else if (p.prec == 3) go(mode_c, std::integral_constant<int, 3>{});                             \
+            else go(mode_c, std::integral_constant<int, 4>{});                                              \
         };                                                                                                  \
         if (p.mode == BDS_TRACK_B2A) gp(std::integral_constant<int, BDS_TRACK_B2A>{});                      \
         else if (p.mode == BDS_TRACK_NB) gp(std::integral_constant<int, BDS_TRACK_NB>{});                   \
@@ -1057,7 +1065,7 @@ static int fill_params(bds_ctx *ctx, const bds_settings &s, TrkParams &p, int n_
         if (ctx->tune.trk_chunk == 2048) p.runs = 8;
         if (ctx->tune.trk_chunk == 4096) p.runs = 16;
         p.chunk = kTrkThreads * p.runs;
-        p.prec = std::max(0, std::min(3, ctx->tune.trk_prec));
+        p.prec = std::max(0, std::min(4, ctx->tune.trk_prec));
         if (ctx->tune.trk_seg == 8 || ctx->tune.trk_seg == 16) p.runs = ctx->tune.trk_seg, p.chunk = kTrkThreads * p.runs;
     }
     p.n_bytes = (long long)(n_bytes / (p.cplx ? 2 : 1));  // whole samples an fread can deliver

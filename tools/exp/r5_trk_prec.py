@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Round-5 experiment: closed-loop tracking against the f64 oracle fixtures over the full horizon, per
 numerics mode of the run-based correlator (BDS_TRK_PREC: 0 fp32 carrier + fp32 prefix sums, 1 f64 prefix sums, 2 f64 carrier
-too, 3 the reference's own trigarg per sample) and per segment length: first epoch at which SURVEY section 8d's closed-loop
+too, 3 the reference's own trigarg per sample with the library's division and sincos, 4 the same values from the hand-written
+division and sin / cos of csrc/bds_strict_math.h -- the default) and per segment length: first epoch at which SURVEY section 8d's closed-loop
 tolerances break (I/Q 1e-4 |P|, carrFreq 1e-3 Hz, codeFreq 1e-6 Hz), worst errors over the horizon, and us per epoch on
 12 channels at 99.375 MS/s.
-    python tools/exp/r5_trk_prec.py [--quick]     -> one JSON line per (fixture, prec, seg) and per (mode, prec, seg) timing"""
+    python tools/exp/r5_trk_prec.py [--quick] [prec ...]     -> one JSON line per (fixture, prec, seg) and per (mode, prec, seg) timing"""
 import json
 import os
 import sys
@@ -18,6 +19,7 @@ sys.path.insert(0, ROOT)
 import bds_amd  # noqa: E402
 
 quick = "--quick" in sys.argv
+PRECS = tuple(int(a) for a in sys.argv[1:] if a.isdigit()) or (0, 1, 2, 3, 4)  # numerics modes to run
 ctx = bds_amd.get_context(0)
 
 
@@ -49,7 +51,7 @@ def set_mode(prec, seg):
 fixtures = {n: load(n) for n in ("trk_wb_long", "trk_b2a_long")}
 for name, (z, s, chans, x, n_epochs) in fixtures.items():
     mode = str(z["mode"])
-    for prec in (0, 1, 2, 3):
+    for prec in PRECS:
         for seg in ((0,) if quick else (0, 8 if mode != "B2A" else 16)):
             set_mode(prec, seg)
             got, _ = bds_amd.tracking(x, chans, s, mode=mode)
@@ -88,7 +90,7 @@ for mode in ("WB", "NB", "B2A"):
     x = np.tile(x, n // base + 1)[:n]
     ch = [SimpleNamespace(PRN=p, acquiredFreq=s.IF + 100.0 * i, codePhase=float(1000 * i + 1), codeFreq=s.codeFreqBasis, status="T")
           for i, p in enumerate(range(1, 13))]
-    for prec in (0, 1, 2, 3):
+    for prec in PRECS:
         for seg in (0, 8 if mode != "B2A" else 16):
             set_mode(prec, seg)
             bds_amd.tracking(x, ch, s, mode=mode)
