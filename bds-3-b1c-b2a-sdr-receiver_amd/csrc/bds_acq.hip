@@ -430,7 +430,7 @@ void acq_state_invalidate(AcqState *a) {
 
 static int check_settings(bds_ctx *ctx, const bds_settings &s) {
     if (s.signal != BDS_SIGNAL_B1C && s.signal != BDS_SIGNAL_B2A)
-        return fail(ctx, BDS_ERR_ARG, "settings.signal must be BDS_SIGNAL_B1C or BDS_SIGNAL_B2A");
+        return fail(ctx, BDS_ERR_ARG, "settings.signal must be 1 (B1C) or 2 (B2a)");
     if (s.dataType != 0)
         return fail(ctx, BDS_ERR_UNSUPPORTED, "settings.dataType: only 'schar' (int8 samples) is supported");
     if (!(s.samplingFreq > 0) || !(s.codeFreqBasis > 0) || s.codeLength != 10230)
@@ -512,8 +512,9 @@ static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
     // code spectrum: |fft(code)| <= X; stored value conj(C)/L * sC, kept below 2^15
     a.sC = a.half ? (float)std::exp2(std::floor(std::log2(32768.0 * (double)a.plan.L / (double)a.X))) : 1.f;
     // primary codes of every PRN, both components
-    if (!a.d_prim) BDS_HIP(ctx, hipMalloc((void **)&a.d_prim, (size_t)BDS_MAX_PRN * 2 * 10230));
-    std::vector<int8_t> prim((size_t)BDS_MAX_PRN * 2 * 10230);
+    const size_t prim_bytes = (size_t)BDS_MAX_PRN * 2 * 10230;
+    if (!a.d_prim) BDS_HIP(ctx, hipMalloc((void **)&a.d_prim, prim_bytes));
+    std::vector<int8_t> prim(prim_bytes);
     for (int prn = 1; prn <= BDS_MAX_PRN; ++prn)
         for (int c = 0; c < 2; ++c) gen_primary(s.signal, c == 1, prn, &prim[((size_t)(prn - 1) * 2 + c) * 10230]);
     BDS_HIP(ctx, hipMemcpy(a.d_prim, prim.data(), prim.size(), hipMemcpyHostToDevice));

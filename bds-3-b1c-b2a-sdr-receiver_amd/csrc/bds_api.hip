@@ -26,6 +26,14 @@ int fail(bds_ctx *ctx, int code, const char *fmt, ...) {
     return code;
 }
 
+// Environment knobs.  The RELEASE library reads four documented ones (include/bds_mi355x.h lists them):
+//   BDS_ACQ_FP16=0      fp32 storage of the spectra and the inter-pass buffer as well (default: fp16 storage, f64 decisions)
+//   BDS_TRK_PREC=0..4   numerics of the tracking correlator (default 4 = strict; 0 = fp32 carrier, 2.4x faster wide-band)
+//   BDS_VERBOSE         progress / fallback messages on stderr
+//   BDS_ACQ_CLOCKPROBE  sampled workgroups time themselves with the shader clock (bds_timing::shader_clock_GHz)
+// Everything else -- kernel selection, launch shapes, plan overrides, the sieve tolerance, the switches that turn the
+// completeness self-check off or force a fallback -- exists only in the TEST-HOOKS build (BDS_TEST_HOOKS=1 ./build.sh ->
+// libbds_mi355x_hooks.so, what tests/ load): a stray variable in a MATLAB session cannot change what the release library decides.
 Tuning tuning_from_env() {
     Tuning t;
     auto geti = [](const char *name, int dflt) {
@@ -33,6 +41,11 @@ Tuning tuning_from_env() {
         return e ? std::atoi(e) : dflt;
     };
     auto has = [](const char *name) { return std::getenv(name) != nullptr; };
+    t.fp16_storage = geti("BDS_ACQ_FP16", -1);
+    t.trk_prec = geti("BDS_TRK_PREC", 4);
+    t.verbose = has("BDS_VERBOSE");
+    t.clockprobe = geti("BDS_ACQ_CLOCKPROBE", 0);
+#ifdef BDS_TEST_HOOKS
     if (const char *e = std::getenv("BDS_ACQ_FORCE_L1L2")) {
         int a = 0, b = 0;
         if (sscanf(e, "%dx%d", &a, &b) == 2) t.force_l1 = a, t.force_l2 = b;
@@ -41,7 +54,6 @@ Tuning tuning_from_env() {
     t.generic = has("BDS_ACQ_GENERIC");
     t.generic_fwd = has("BDS_ACQ_GENERIC_FWD");
     t.group = std::max(0, std::min(1024, geti("BDS_ACQ_GROUP", 0)));
-    t.fp16_storage = geti("BDS_ACQ_FP16", -1);
     t.gchunk = std::max(1, geti("BDS_ACQ_GCHUNK", 34));
     t.multi_any = has("BDS_ACQ_MULTI_ANY");
     t.nomulti = has("BDS_ACQ_NOMULTI");
@@ -58,16 +70,14 @@ Tuning tuning_from_env() {
     t.pk = geti("BDS_ACQ_PK", 1);
     t.small_plan = geti("BDS_ACQ_SMALL", 1);
     t.neigh = std::max(0, std::min(4, geti("BDS_ACQ_NEIGH", 0)));
-    t.clockprobe = geti("BDS_ACQ_CLOCKPROBE", 0);
     t.wcols_qchunk = std::max(1, geti("BDS_ACQ_WCOLS_QCHUNK", 4));
-    t.verbose = has("BDS_VERBOSE");
     t.multi_force_rccl = has("BDS_MULTI_FORCE_RCCL");
     t.trk_nblocks = std::max(0, geti("BDS_TRK_NBLOCKS", 0));
     t.trk_chunk = std::max(0, geti("BDS_TRK_CHUNK", 0));
     t.trk_persample = has("BDS_TRK_PERSAMPLE");
-    t.trk_prec = geti("BDS_TRK_PREC", 4);
     t.trk_seg = geti("BDS_TRK_SEG", 0);
     t.trk_nofuse_update = has("BDS_TRK_NOFUSE_UPDATE");
+#endif
     return t;
 }
 
@@ -151,6 +161,17 @@ extern "C" int bds_abi_check(int sz_settings, int sz_channel, int sz_track_out, 
             sz_track_out == (int)sizeof(bds_track_out) && sz_timing == (int)sizeof(bds_timing))
                ? BDS_OK
                : BDS_ERR_ARG;
+}
+
+extern "C" int bds_build_flags(void) {
+    int f = 0;
+#ifdef BDS_TEST_HOOKS
+    f |= 1;
+#endif
+#ifdef BDS_DEBUG
+    f |= 2;
+#endif
+    return f;
 }
 
 extern "C" int bds_get_timing(bds_ctx *ctx, bds_timing *t) {

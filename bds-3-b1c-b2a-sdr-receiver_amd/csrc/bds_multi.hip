@@ -40,9 +40,13 @@ struct Rccl {
     std::string err;
     bool load() {
         if (lib) return true;
-        // BDS_RCCL_LIB names the library to load instead of the default search (deployments with RCCL elsewhere; the
+        // test-hooks build: BDS_RCCL_LIB names the library to load instead of the default search (the
         // test that a missing library is a clean BDS_ERR_UNSUPPORTED, tests/test_multi_gpu.py)
+#ifdef BDS_TEST_HOOKS
         const char *forced = std::getenv("BDS_RCCL_LIB");
+#else
+        const char *forced = nullptr;  // the release library loads RCCL by its soname / from /opt/rocm/lib only
+#endif
         std::string last = "?";
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             if (forced) name = forced;
@@ -154,7 +158,11 @@ extern "C" bds_multi *bds_multi_create(int n_devices, const int *device_ids) {
     // one device, so the exchange of such a handle is the same sum taken on the host.
     // (only the exact value "1" arms it, and it says so on stderr: a deployment that merely inherits the variable gets the
     //  duplicate-device check and RCCL as usual)
+#ifdef BDS_TEST_HOOKS
     const char *alias_env = std::getenv("BDS_MULTI_TEST_ALIAS");
+#else
+    const char *alias_env = nullptr;  // (test-hooks build only)
+#endif
     const bool alias = alias_env && std::strcmp(alias_env, "1") == 0;
     if (alias) fprintf(stderr, "[bds] BDS_MULTI_TEST_ALIAS=1: test hook active -- repeated device ids accepted, exchange summed on the host instead of RCCL\n");
     if (n_devices <= 0) n_devices = n;  // all visible devices

@@ -17,7 +17,8 @@ TRACK_MODE = {"B2A": 0, "NB": 1, "WB": 2}
 CODE_KIND = {"data": 0, "pilot": 1, "data_boc11": 2, "pilot_boc11": 3, "pilot_boc61": 4, "pilot_secondary": 5}
 CODE_LEN = {0: 10230, 1: 10230, 2: 20460, 3: 20460, 4: 122760, 5: 1800}
 
-# BDS_LIB_PATH: load another build of the library (tools/exp/exp_parts.sh timing variants); default = the in-tree build
+# BDS_LIB_PATH: load another build of the library -- libbds_mi355x_hooks.so (the test-hooks build: tests/conftest.py,
+# tools/exp/), the debug build, timing variants; default = the in-tree RELEASE build
 _LIB_PATH = os.environ.get("BDS_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbds_mi355x.so")
 
 
@@ -81,7 +82,7 @@ class AcqJob(C.Structure):
 
 
 EXPORTS = [
-    "bds_create", "bds_destroy", "bds_reload_tuning", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_gen_code", "bds_acquire",
+    "bds_create", "bds_destroy", "bds_reload_tuning", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_build_flags", "bds_gen_code", "bds_acquire",
     "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_acq_candidates", "bds_get_timing",
     "bds_track", "bds_track_mem", "bds_track_loaded_bytes", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
     "bds_calc_weighing_factor", "bds_pre_run", "bds_pre_run_device", "bds_acquire_track",
@@ -90,6 +91,12 @@ EXPORTS = [
 ]
 
 _lib = None
+HOOKS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbds_mi355x_hooks.so")
+
+
+def has_test_hooks():
+    """True when the loaded library is the test-hooks build (reads the tuning / test environment switches)."""
+    return bool(lib().bds_build_flags() & 1)
 
 
 def lib():
@@ -113,6 +120,7 @@ def lib():
     L.bds_create.restype, L.bds_create.argtypes = vp, [i32]
     L.bds_destroy.restype, L.bds_destroy.argtypes = None, [vp]
     L.bds_reload_tuning.restype, L.bds_reload_tuning.argtypes = i32, [vp]
+    L.bds_build_flags.restype, L.bds_build_flags.argtypes = i32, []
     L.bds_track_loaded_bytes.restype, L.bds_track_loaded_bytes.argtypes = C.c_longlong, [vp]
     L.bds_multi_create.restype, L.bds_multi_create.argtypes = vp, [i32, _IP]
     L.bds_multi_destroy.restype, L.bds_multi_destroy.argtypes = None, [vp]

@@ -202,6 +202,17 @@ def tracking_leg(name, local_rank, base):
         ch.append(SimpleNamespace(PRN=sat.prn, acquiredFreq=float(cf), codePhase=float(shift + int(np.ceil(sat.delay)) + 1),
                                   codeFreq=float(code_freq), status="T"))
     ctx = bds_amd.get_context(local_rank)
+    # the fp32 carrier / fp32 prefix sums of rounds 2-4 (BDS_TRK_PREC=0: SURVEY 8d only up to its first ceil() flip,
+    # tests/test_track_long_gpu.py), timed beside the default for comparison
+    os.environ["BDS_TRK_PREC"] = "0"
+    try:
+        ctx.reload_tuning()
+        bds_amd.tracking(x, ch, s, mode=mode)
+        bds_amd.tracking(x, ch, s, mode=mode)
+        fast_ms = ctx.timing()["total_ms"]
+    finally:
+        del os.environ["BDS_TRK_PREC"]
+        ctx.reload_tuning()
     bds_amd.tracking(x, ch, s, mode=mode)  # warm-up (H2D, code tables)
     res, _ = bds_amd.tracking(x, ch, s, mode=mode)
     dev_ms = ctx.timing()["total_ms"]
@@ -215,6 +226,9 @@ def tracking_leg(name, local_rank, base):
             "int8_read_GBps": samples / (dev_ms * 1e-3) / 1e9,  # one byte per sample per channel (algorithmic)
             "correlator_GMACs": samples * macs / (dev_ms * 1e-3) / 1e9, "macs_per_sample": macs,
             "channels_locked": locked,
+            "numerics": "strict (default, BDS_TRK_PREC=4): the reference's trigarg(k) per sample, f64 sin/cos, f64 prefix sums -- SURVEY 8d over the whole 3 600 / 49 000-epoch horizon",
+            "fp32_carrier_ms_per_epoch": fast_ms / epochs,
+            "fp32_carrier_note": "BDS_TRK_PREC=0: fp32 carrier recurrence + fp32 prefix sums; 8d tolerances hold until its first ceil() flip (epoch 142 / 1 588), a bounded floor after it",
             "note": "device time of the epoch loop (one launch per epoch: correlate + the previous epoch's loop update; record window in HBM); locked synthetic record "
                     "(12 satellites at 47 dB-Hz, one block of whole code periods repeated)"}
 
@@ -392,6 +406,40 @@ def b2a_leg(local_rank, steps=5):
             "satellites_injected": sorted(sat.prn for sat in sats)}
 
 
+def cold_leg(local_rank, s, x):
+    """Extra key `cold` (SURVEY.md 8d "also report cold"; the reference times the whole call, postProcessing.m:104-112): a
+    FRESH context, wall time of each step with a device-wide synchronisation after it -- the IF block to HBM (bds_acq_load:
+    H2D + block statistics), the per-PRN code generation and code-spectrum transforms (bds_acq_prepare), the first
+    bds_acq_run (plan constants, buffers, first launches) and a second, warm one for comparison."""
+    import torch
+
+    import bds_amd
+
+    def tick():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    t0 = tick()
+    c = bds_amd.native.Context(local_rank)
+    try:
+        t1 = tick()
+        c.acq_load(s, x)
+        t2 = tick()
+        c.acq_prepare(s)
+        t3 = tick()
+        c.acq_run(s)
+        t4 = tick()
+        c.acq_run(s)
+        t5 = tick()
+    finally:
+        c.close()
+    return {"create_ms": (t1 - t0) * 1e3, "load_ms": (t2 - t1) * 1e3, "prepare_ms": (t3 - t2) * 1e3, "first_run_ms": (t4 - t3) * 1e3,
+            "cold_total_ms": (t4 - t1) * 1e3, "warm_run_ms": (t5 - t4) * 1e3, "block_MB": x.nbytes / 1e6,
+            "note": "fresh context; load = H2D of the int8 block + its statistics, prepare = 63 x code generation + code-spectrum "
+                    "transforms (cached across calls afterwards), first_run = first bds_acq_run (buffers, plan constants); "
+                    "cold_total = load + prepare + first_run; wall clock with a device synchronisation after each step"}
+
+
 def clock_leg(local_rank, s, x):
     """Engine clock the search kernels actually run at (extra call, never `value`): with BDS_ACQ_CLOCKPROBE=1 sampled workgroups of
     the row and column pass time their own life with the shader clock against the constant reference clock
@@ -427,6 +475,7 @@ def main():
                     help="skip the extra (never the headline) call with fp32 storage end to end")
     ap.add_argument("--no-tracking-full", action="store_true", help="skip the cfg4 leg (12 channels x 3 600 epochs from a 3.6 GB file)")
     ap.add_argument("--no-b2a", action="store_true", help="skip the extra cfg2 leg (B2a full acquisition, key `b2a`)")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-start leg (key `cold`)")
     ap.add_argument("--prns", type=int, default=63, help="tuning only: search PRNs 1..N instead of all 63")
     args = ap.parse_args()
 
@@ -640,6 +689,11 @@ def main():
                 valu["shader_clock_source"] = "measured in this run (one extra call, BDS_ACQ_CLOCKPROBE=1: sampled workgroups, s_memtime against s_memrealtime)"
                 valu["bound_ms_at_shader_clock"] = valu["bound_ms"] * valu["clock_GHz"] / ck["shader_clock_GHz"]
                 valu["frac_of_issue_bound_at_shader_clock"] = valu["bound_ms_at_shader_clock"] / ck["pair_ms"] if ck["pair_ms"] else None
+        if world == 1 and len(sigs) == 1 and args.prns == 63 and not args.no_cold:
+            out["cold"] = {names[0]: cold_leg(local_rank, s, x)}
+            if names == ["b1c"] and not args.no_b2a:
+                s2, x2, _, _ = build_workload("b2a")
+                out["cold"]["b2a"] = cold_leg(local_rank, s2, x2)
         out["b2a"] = b2a_leg(local_rank) if world == 1 and names == ["b1c"] and not args.no_b2a and args.prns == 63 else None
         if len(sigs) > 1:
             out["config"]["satellites_detected_per_signal"] = {g["name"]: sorted(int(p) for p in np.nonzero(r[0])[0] + 1)

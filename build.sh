@@ -27,24 +27,45 @@ fi
 FLAGS=(--offload-arch=gfx950 $OPT -std=c++17 -fPIC -fvisibility=hidden
        -Wall -Wno-unused-result -I"$ROOT/include" -I"$SRC" "${EXTRA[@]}")
 mkdir -p "$BLD"
-objs=()
-for f in bds_codes.cpp bds_api.hip bds_acq.hip bds_track.hip bds_sync.hip bds_multi.hip; do
-    o="$BLD/${f%.*}.o"
+# Two libraries from one set of objects: the RELEASE library reads four documented environment knobs (csrc/bds_api.hip,
+# include/bds_mi355x.h); libbds_mi355x_hooks.so (-DBDS_TEST_HOOKS: only bds_api.hip and bds_multi.hip differ) also reads the
+# tuning / test switches and is what tests/ and tools/exp/ load (tests/conftest.py).  BDS_TEST_HOOKS=0 skips it.
+HOOKS="${BDS_TEST_HOOKS:-1}"
+[ "${BDS_DEBUG:-0}" = 1 ] || [ "${BDS_SAN:-0}" = 1 ] && HOOKS=0 && EXTRA+=(-DBDS_TEST_HOOKS=1)   # debug / sanitizer builds carry the hooks themselves
+compile() {  # source, object, extra flags...
+    local f="$1" o="$2"; shift 2
     # rebuild when the source or any header is newer than the object
     if [ ! -f "$o" ] || [ -n "$(find "$SRC/$f" "$SRC"/*.h "$ROOT/include"/*.h -newer "$o" 2>/dev/null)" ]; then
-        echo "hipcc $f"
+        echo "hipcc $f $*"
         if [[ "$f" == *.cpp ]]; then
-            "$HIPCC" "${FLAGS[@]}" -ffp-contract=off -x c++ -c "$SRC/$f" -o "$o"
+            "$HIPCC" "${FLAGS[@]}" -ffp-contract=off -x c++ -c "$SRC/$f" -o "$o" "$@"
         else
-            contract=off
+            local contract=off
             # the search: FMA contraction on; SLP packing off (v_pk_* f32 runs at the scalar rate on
             # gfx950 and costs register shuffles: measured -4.6 % on the cell pair)
             [ "$f" = bds_acq.hip ] && contract="fast -fno-slp-vectorize"
             [ "$f" = bds_track.hip ] && contract="off -fno-slp-vectorize"
-            "$HIPCC" "${FLAGS[@]}" -ffp-contract=$contract -c "$SRC/$f" -o "$o" ${BDS_HIPCC_EXTRA:-}
+            "$HIPCC" "${FLAGS[@]}" -ffp-contract=$contract -c "$SRC/$f" -o "$o" ${BDS_HIPCC_EXTRA:-} "$@"
         fi
     fi
+}
+objs=(); hobjs=(); pids=()
+for f in bds_acq.hip bds_track.hip bds_codes.cpp bds_api.hip bds_sync.hip bds_multi.hip; do
+    o="$BLD/${f%.*}.o"
+    compile "$f" "$o" & pids+=($!)
     objs+=("$o")
+    if [ "$HOOKS" = 1 ] && { [ "$f" = bds_api.hip ] || [ "$f" = bds_multi.hip ]; }; then
+        ho="$BLD/${f%.*}_hooks.o"
+        compile "$f" "$ho" -DBDS_TEST_HOOKS=1 & pids+=($!)
+        hobjs+=("$ho")
+    else
+        hobjs+=("$o")
+    fi
 done
+for p in "${pids[@]}"; do wait "$p"; done   # (set -e: a failed compile ends the build here)
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT" -ldl -Wl,-rpath,/opt/rocm/lib "${LINK[@]}"
 echo "built $OUT"
+if [ "$HOOKS" = 1 ]; then
+    "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${hobjs[@]}" -o "${OUT%.so}_hooks.so" -ldl -Wl,-rpath,/opt/rocm/lib "${LINK[@]}"
+    echo "built ${OUT%.so}_hooks.so"
+fi

@@ -153,14 +153,26 @@ typedef struct bds_ctx bds_ctx;
 /* One context per GPU (one process per GPU under torch.distributed / RCCL). */
 BDS_API bds_ctx *bds_create(int device_id);
 BDS_API void bds_destroy(bds_ctx *ctx);
-/* Tuning / test hook: the BDS_* environment knobs (tools/README.md) are read once, at bds_create, into the
- * context; this re-reads them into an existing context and makes the next bds_acq_prepare re-derive the acquisition
- * configuration (plan, storage mode, cached code spectra).  Never needed by a host application. */
+/* Environment knobs, read once at bds_create into the context.  The release library reads exactly these:
+ *   BDS_ACQ_FP16=0       fp32 storage of the spectra and the inter-pass buffer as well (default: fp16 storage; every reported
+ *                        value is decided in f64 either way)
+ *   BDS_TRK_PREC=0..4    numerics of the tracking correlator: 4 (default) the reference's own carrier argument per sample in
+ *                        f64 -- SURVEY.md 8d tolerances over the whole horizon; 0 fp32 carrier recurrence, ~2.4x faster in
+ *                        wide-band mode, 8d tolerances until the first ceil() flip (a few hundred epochs)
+ *   BDS_VERBOSE          progress / fallback messages on stderr
+ *   BDS_ACQ_CLOCKPROBE=1 sampled workgroups time themselves with the shader clock (bds_timing.shader_clock_GHz)
+ * (plus BDS_MEX_DEVICES in the MEX gateway and BDS_LIB_PATH in the ctypes host).  Kernel-selection, launch-shape and sieve
+ * switches, the RCCL path override and the aliased-device hook exist only in libbds_mi355x_hooks.so (-DBDS_TEST_HOOKS,
+ * built beside the release library by build.sh; tools/README.md lists them), which is what tests/ load.
+ * bds_reload_tuning re-reads the knobs into an existing context and makes the next bds_acq_prepare re-derive the
+ * acquisition configuration (plan, storage mode, cached code spectra).  Never needed by a host application. */
 BDS_API int bds_reload_tuning(bds_ctx *ctx);
 BDS_API const char *bds_last_error(const bds_ctx *ctx); /* ctx may be NULL: creation errors */
 BDS_API int bds_device_name(const bds_ctx *ctx, char *buf, int buflen);
 /* Binding self-check: returns 0 when the caller's struct sizes equal the library's. */
 BDS_API int bds_abi_check(int sizeof_settings, int sizeof_channel, int sizeof_track_out, int sizeof_timing);
+/* Which build this is: bit 0 = test hooks compiled in (libbds_mi355x_hooks.so), bit 1 = debug build (device-side bounds checks). */
+BDS_API int bds_build_flags(void);
 
 /* ---- ranging codes (host side, no GPU needed) -------------------------------- */
 /* Replaces generateB2aDataCode.m / generateB2aPilotCode.m / generateDataBOC11.m /

@@ -19,6 +19,7 @@ def run_bench(args, extra_env=None, timeout=900):
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
+    env.pop("BDS_LIB_PATH", None)  # bench.py runs on the RELEASE library (the suite itself on the test-hooks build)
     env.update(extra_env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env,
                        cwd=ROOT, timeout=timeout)
@@ -43,6 +44,9 @@ def test_bench_line_single():
     d = run_bench(["--workload", "b2a"] + FAST)
     check_line(d, 1)
     assert d["config"]["jobs_rank0"] == {"b2a": 63}
+    cold = d["cold"]["b2a"]  # SURVEY 8d "also report cold": fresh context, load + prepare + first run
+    assert cold["cold_total_ms"] > cold["warm_run_ms"] > 0 and cold["load_ms"] > 0 and cold["prepare_ms"] > 0
+    assert abs(cold["cold_total_ms"] - (cold["load_ms"] + cold["prepare_ms"] + cold["first_run_ms"])) < 1e-6
 
 
 def test_bench_two_ranks_self_spawn():

@@ -1,3 +1,4 @@
+export BDS_LIB_PATH="${BDS_LIB_PATH:-$(cd "$(dirname "${BASH_SOURCE[0]}")" && git rev-parse --show-toplevel 2>/dev/null || echo "$PWD")/bds-3-b1c-b2a-sdr-receiver_amd/libbds_mi355x_hooks.so}"  # the tuning switches exist in the test-hooks build only
 for g in 1 2 3 4 6 8 12 16; do echo -n "GROUP=$g: "; BDS_ACQ_GROUP=$g timeout 300 python bench.py --workload b1c --steps 1 --warmup 1 --no-cpu-baseline --prns 8 2>&1 | grep -E "^\{" | python -c "
 import sys,json
 for l in sys.stdin:

@@ -1,3 +1,4 @@
+export BDS_LIB_PATH="${BDS_LIB_PATH:-$(cd "$(dirname "${BASH_SOURCE[0]}")" && git rev-parse --show-toplevel 2>/dev/null || echo "$PWD")/bds-3-b1c-b2a-sdr-receiver_amd/libbds_mi355x_hooks.so}"  # the tuning switches exist in the test-hooks build only
 for ov in 0 1; do echo -n "OVERLAP=$ov: "; if [ $ov = 1 ]; then export BDS_ACQ_OVERLAP=1; else unset BDS_ACQ_OVERLAP; fi; timeout 300 python bench.py --workload b1c --steps 3 --warmup 1 --no-cpu-baseline --no-tracking 2>&1 | grep -E "^\{" | python -c "
 import sys,json
 for l in sys.stdin:

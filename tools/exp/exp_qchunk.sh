@@ -1,4 +1,5 @@
 #!/bin/bash
+export BDS_LIB_PATH="${BDS_LIB_PATH:-$(cd "$(dirname "${BASH_SOURCE[0]}")" && git rev-parse --show-toplevel 2>/dev/null || echo "$PWD")/bds-3-b1c-b2a-sdr-receiver_amd/libbds_mi355x_hooks.so}"  # the tuning switches exist in the test-hooks build only
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for q in 1 2 4 8 16; do
   BDS_ACQ_WCOLS_QCHUNK=$q timeout 300 python bench.py --prns 8 --no-cpu-baseline --no-tracking --no-strict-f32 --steps 3 --warmup 1 2>/dev/null | python -c "

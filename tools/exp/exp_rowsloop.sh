@@ -1,4 +1,5 @@
 # row-pass cell loop: prefetch on/off x occupancy bound x cells per workgroup (full B1C search)
+export BDS_LIB_PATH="${BDS_LIB_PATH:-$(cd "$(dirname "${BASH_SOURCE[0]}")" && git rev-parse --show-toplevel 2>/dev/null || echo "$PWD")/bds-3-b1c-b2a-sdr-receiver_amd/libbds_mi355x_hooks.so}"  # the tuning switches exist in the test-hooks build only
 for v in "-DBDS_ROWS_PREFETCH=1 -DBDS_ROWS_OCC=3" "-DBDS_ROWS_PREFETCH=0 -DBDS_ROWS_OCC=4" "-DBDS_ROWS_PREFETCH=0 -DBDS_ROWS_OCC=3"; do
   touch bds-3-b1c-b2a-sdr-receiver_amd/csrc/bds_acq.hip
   BDS_HIPCC_EXTRA="$v" ./build.sh 2>&1 | grep -q built || { echo "build failed: $v"; continue; }

@@ -1,3 +1,4 @@
+export BDS_LIB_PATH="${BDS_LIB_PATH:-$(cd "$(dirname "${BASH_SOURCE[0]}")" && git rev-parse --show-toplevel 2>/dev/null || echo "$PWD")/bds-3-b1c-b2a-sdr-receiver_amd/libbds_mi355x_hooks.so}"  # the tuning switches exist in the test-hooks build only
 for lt in 3 2; do for g in 2 4 8; do echo "== LOGT=$lt GROUP=$g"; BDS_ACQ_LOGT=$lt BDS_ACQ_GROUP=$g timeout 300 python bench.py --workload b1c --steps 1 --warmup 1 --no-cpu-baseline --prns 8 2>&1 | grep -E "^\{" | python -c "
 import sys,json
 for l in sys.stdin:

@@ -1,5 +1,6 @@
 #!/bin/bash
 # tracking epoch time vs channel count: flat = latency-bound, linear = throughput-bound
+export BDS_LIB_PATH="${BDS_LIB_PATH:-$(cd "$(dirname "${BASH_SOURCE[0]}")" && git rev-parse --show-toplevel 2>/dev/null || echo "$PWD")/bds-3-b1c-b2a-sdr-receiver_amd/libbds_mi355x_hooks.so}"  # the tuning switches exist in the test-hooks build only
 cd "$GRAFT_REPO_ROOT"
 for M in ${MODES:-WB B2A}; do
 for env in "BDS_TRK_PERSAMPLE=1" "BDS_X=0"; do

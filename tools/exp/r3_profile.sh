@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-3 measurement pass (GPU box): PMC counters (default and fp32 storage), kernel-trace stats, tracking profile, sieve error
 # at the cfg3 plan, the default bench lines.  Everything lands under gpurun_out/; the summaries are copied to profiles/ by hand.
+export BDS_LIB_PATH="${BDS_LIB_PATH:-$(cd "$(dirname "${BASH_SOURCE[0]}")" && git rev-parse --show-toplevel 2>/dev/null || echo "$PWD")/bds-3-b1c-b2a-sdr-receiver_amd/libbds_mi355x_hooks.so}"  # the tuning switches exist in the test-hooks build only
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 bash tools/pmc_run.sh > gpurun_out/pmc_run.log 2>&1; tail -2 gpurun_out/pmc_run.log
 cp gpurun_out/pmc_summary.txt gpurun_out/pmc_summary_default.txt

@@ -1,5 +1,6 @@
 #!/bin/bash
 # power / clock samples (rocm-smi) while the cfg3 search runs: is the chip at its power cap?
+export BDS_LIB_PATH="${BDS_LIB_PATH:-$(cd "$(dirname "${BASH_SOURCE[0]}")" && git rev-parse --show-toplevel 2>/dev/null || echo "$PWD")/bds-3-b1c-b2a-sdr-receiver_amd/libbds_mi355x_hooks.so}"  # the tuning switches exist in the test-hooks build only
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 rocm-smi --showpower --showclocks --showmaxpower --showperflevel 2>&1 | grep -v "^$" | head -30

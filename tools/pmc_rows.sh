@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC counters of the two row-pass kernels side by side (wave-private vs k_rows_inv_f), two passes each
+export BDS_LIB_PATH="${BDS_LIB_PATH:-$(cd "$(dirname "${BASH_SOURCE[0]}")" && git rev-parse --show-toplevel 2>/dev/null || echo "$PWD")/bds-3-b1c-b2a-sdr-receiver_amd/libbds_mi355x_hooks.so}"  # the tuning switches exist in the test-hooks build only
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ARGS="--workload b1c --steps 1 --warmup 0 --no-cpu-baseline --no-tracking --no-strict-f32 --prns 2"
 for mode in 1 0; do

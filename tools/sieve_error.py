@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
+os.environ.setdefault("BDS_LIB_PATH", os.path.join(ROOT, "bds-3-b1c-b2a-sdr-receiver_amd", "libbds_mi355x_hooks.so"))  # tuning switches: test-hooks build only
 import bds_amd  # noqa: E402
 from helpers import medium_b2a, small_b1c  # noqa: E402
 from oracle import acquisition as oacq  # noqa: E402
