@@ -31,6 +31,7 @@
 
 #include "bds_acq_scols.h"
 #include "bds_acq_wcols.h"
+#include "bds_acq_refine.h"
 #include "bds_acq_wrows.h"
 #include "bds_internal.h"
 
@@ -390,6 +391,25 @@ struct AcqState {
     CorrJob *d_jobs = nullptr;
     double2 *d_jobout = nullptr;
     size_t jobs_cap = 0;
+    // device refinement chain (bds_acq_refine.h)
+    RefPrn *d_ref_prn = nullptr;
+    size_t ref_prn_cap = 0;
+    RefGlobal *d_ref_g = nullptr;
+    RefCand *d_ref_cand = nullptr;      // [kRefCandCap] coarse candidates, then [kRefCandCap] of the second-peak pass
+    size_t ref_cand_cap = 0;
+    char *d_ref_tabs = nullptr;         // per run: PRN of index pi (int), code-spectrum offset of index pi (long)
+    size_t ref_tabs_cap = 0;
+    double *d_prefix_c = nullptr, *d_prefix_cq = nullptr;  // prefix sums of the block at every 256th sample (exact integers: int8 data)
+    size_t prefix_c_cap = 0, prefix_cq_cap = 0;
+    Extra *d_extra2 = nullptr;          // candidate list / per-PRN maxima / bounds of the B2a second-peak pass
+    size_t extra2_cap = 0;
+    int *d_extra2_count = nullptr;
+    unsigned long long *d_cellmax2 = nullptr;
+    size_t cellmax2_cap = 0;
+    float *d_lb2 = nullptr;
+    size_t lb2_cap = 0;
+    int cands_on_device = 0;            // >0: last_cands of the last run still sits in d_ref_cand (fetched on demand)
+    std::vector<int> cands_prns;
     // last run (diagnostics)
     int D = 0;
     std::vector<int> run_prns;
@@ -416,7 +436,9 @@ void acq_state_free(AcqState *a) {
     for (void *p : {(void *)a->d_sig, (void *)a->d_prim, (void *)a->d_Cs, (void *)a->d_Xs, (void *)a->d_Bw,
                     (void *)a->d_recs, (void *)a->d_rowmax, (void *)a->d_rowarg, (void *)a->d_jobs, (void *)a->d_codes,
                     (void *)a->d_jobout, (void *)a->d_sig64, (void *)a->d_ffa, (void *)a->d_ffb, (void *)a->d_fir, (void *)a->d_cells,
-                    (void *)a->d_extra, (void *)a->d_extra_count, (void *)a->d_cellmax, (void *)a->d_lb})
+                    (void *)a->d_extra, (void *)a->d_extra_count, (void *)a->d_cellmax, (void *)a->d_lb, (void *)a->d_ref_prn,
+                    (void *)a->d_ref_g, (void *)a->d_ref_cand, (void *)a->d_ref_tabs, (void *)a->d_prefix_c, (void *)a->d_prefix_cq,
+                    (void *)a->d_extra2, (void *)a->d_extra2_count, (void *)a->d_cellmax2, (void *)a->d_lb2})
         if (p) (void)hipFree(p);
     delete a;
 }
@@ -920,6 +942,22 @@ extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s_in, const int8_t
     }
     a.n_samples = n_eff;
     a.sigpower_X = 0;
+    if (!r.on) {
+        // every 256th prefix sum for the device refinement chain (the DC of the B1C fine-search block, bds_acq_refine.h)
+        const size_t nc = (size_t)(n_eff >> 8) + 1;
+        std::vector<double> pc(nc);
+        for (size_t i = 0; i < nc; ++i) pc[i] = a.h_prefix[i << 8];
+        if ((rc = ensure(ctx, &a.d_prefix_c, &a.prefix_c_cap, nc))) return rc;
+        BDS_HIP(ctx, hipMemcpyAsync(a.d_prefix_c, pc.data(), sizeof(double) * nc, hipMemcpyHostToDevice, st(ctx)));
+        if (cplx) {
+            std::vector<double> pq(nc);
+            for (size_t i = 0; i < nc; ++i) pq[i] = a.h_prefix_q[i << 8];
+            if ((rc = ensure(ctx, &a.d_prefix_cq, &a.prefix_cq_cap, nc))) return rc;
+            BDS_HIP(ctx, hipMemcpyAsync(a.d_prefix_cq, pq.data(), sizeof(double) * nc, hipMemcpyHostToDevice, st(ctx)));
+            BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));  // (pq leaves scope)
+        }
+        BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));      // (pc leaves scope)
+    }
     ext_sums(a);
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
     return BDS_OK;
@@ -980,14 +1018,18 @@ struct Cell {
     bool operator<(const Cell &o) const { return std::tie(b, lag) < std::tie(o.b, o.lag); }
 };
 
-// multi: every job carries up to kCorrFreqs frequencies (k_corr_f64_multi); out[j * kCorrFreqs + f]
-static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vector<CorrJob> &jobs,
-                    std::vector<double2> &out, bool multi = false) {
-    const int nper = multi ? kCorrFreqs : 1;
-    out.resize(jobs.size() * nper);
-    if (jobs.empty()) return BDS_OK;
-    int rc;
-    // sampled codes the jobs refer to (built once per (slot, mode), cached in the context)
+// sampled code of (slot, mode) for the f64 sums: built once, cached in the context (a.d_codes allocated by the caller)
+static void make_code_table(bds_ctx *ctx, AcqState &a, int slot, int mode) {
+    const size_t t = (size_t)slot * 2 + mode;
+    if (a.code_have[t]) return;
+    CodeTable full = a.tab;
+    full.xlen = a.spc;  // whole table; the coarse jobs read its first X samples
+    const long len = mode ? a.code_stride : a.spc;
+    hipLaunchKernelGGL(k_make_code, dim3(256), dim3(256), 0, st(ctx), full, slot, mode, len, a.d_codes + t * (size_t)a.code_stride);
+    a.code_have[t] = 1;
+}
+
+static int ensure_code_cache(bds_ctx *ctx, AcqState &a, const bds_settings &s) {
     const long stride = a.signal == BDS_SIGNAL_B2A ? std::max<long>(a.spc, (long)s.fineNoncoh * a.spc) : a.spc;
     const size_t ntab = (size_t)BDS_MAX_PRN * 2 * 2;
     if (!a.d_codes || a.code_stride != stride || a.code_have.size() != ntab) {
@@ -997,33 +1039,43 @@ static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vecto
         a.code_stride = stride;
         a.code_have.assign(ntab, 0);
     }
-    CodeTable full = a.tab;
-    full.xlen = a.spc;  // whole table; the coarse jobs read its first X samples
-    for (const CorrJob &j : jobs) {
-        const size_t t = (size_t)j.slot * 2 + j.mode;
-        if (a.code_have[t]) continue;
-        const long len = j.mode ? stride : a.spc;
-        hipLaunchKernelGGL(k_make_code, dim3(256), dim3(256), 0, st(ctx), full, j.slot, j.mode, len,
-                           a.d_codes + t * (size_t)stride);
-        a.code_have[t] = 1;
-    }
-    constexpr int kSlices = 8;  // partial sums per job (k_corr_f64 grid.y)
-    if (a.jobs_cap < jobs.size()) {
-        if (a.d_jobs) (void)hipFree(a.d_jobs), a.d_jobs = nullptr;
-        if (a.d_jobout) (void)hipFree(a.d_jobout), a.d_jobout = nullptr;
-        size_t cap = std::max<size_t>(jobs.size(), 1024), dummy = 0;
-        if ((rc = ensure(ctx, &a.d_jobs, &dummy, cap))) return rc;
-        dummy = 0;
-        if ((rc = ensure(ctx, &a.d_jobout, &dummy, cap * kSlices * kCorrFreqs))) return rc;
-        a.jobs_cap = cap;
-    }
+    return BDS_OK;
+}
+
+constexpr int kCorrSlices = 8;  // partial sums per job (k_corr_f64 grid.y)
+
+static int ensure_job_buffers(bds_ctx *ctx, AcqState &a, size_t njobs) {
+    if (a.jobs_cap >= njobs) return BDS_OK;
+    int rc;
+    if (a.d_jobs) (void)hipFree(a.d_jobs), a.d_jobs = nullptr;
+    if (a.d_jobout) (void)hipFree(a.d_jobout), a.d_jobout = nullptr;
+    size_t cap = std::max<size_t>(njobs, 1024), dummy = 0;
+    if ((rc = ensure(ctx, &a.d_jobs, &dummy, cap))) return rc;
+    dummy = 0;
+    if ((rc = ensure(ctx, &a.d_jobout, &dummy, cap * kCorrSlices * kCorrFreqs))) return rc;
+    a.jobs_cap = cap;
+    return BDS_OK;
+}
+
+// multi: every job carries up to kCorrFreqs frequencies (k_corr_f64_multi); out[j * kCorrFreqs + f]
+static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vector<CorrJob> &jobs,
+                    std::vector<double2> &out, bool multi = false) {
+    const int nper = multi ? kCorrFreqs : 1;
+    out.resize(jobs.size() * nper);
+    if (jobs.empty()) return BDS_OK;
+    int rc;
+    // sampled codes the jobs refer to (built once per (slot, mode), cached in the context)
+    if ((rc = ensure_code_cache(ctx, a, s))) return rc;
+    for (const CorrJob &j : jobs) make_code_table(ctx, a, j.slot, j.mode);
+    constexpr int kSlices = kCorrSlices;
+    if ((rc = ensure_job_buffers(ctx, a, jobs.size()))) return rc;
     BDS_HIP(ctx, hipMemcpyAsync(a.d_jobs, jobs.data(), sizeof(CorrJob) * jobs.size(), hipMemcpyHostToDevice, st(ctx)));
     if (multi)
         hipLaunchKernelGGL(k_corr_f64_multi, dim3((unsigned)jobs.size(), kSlices), dim3(256), 0, st(ctx), a.sview(), a.N,
                            (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
     else
         hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size(), kSlices), dim3(256), 0, st(ctx), a.sview(), a.N,
-                           (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
+                           (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)nullptr);
     BDS_HIP(ctx, hipGetLastError());
     std::vector<double2> part(jobs.size() * kSlices * nper);
     BDS_HIP(ctx, hipMemcpyAsync(part.data(), a.d_jobout, sizeof(double2) * part.size(), hipMemcpyDeviceToHost, st(ctx)));
@@ -1102,6 +1154,7 @@ struct AcqRun {
     double f0 = 0, kDelta = 0;
     float w0 = 1.f, w1 = 1.f;
     bool fsearch = false, wcols = false, multiprn = false, overlap = false;
+    bool dev_refined = false;  // the refinement ran as the device chain
     size_t elem = 8;  // bytes of one stored complex value
     int PB = 1;
     long n_pairs_total = 0, cells_per_pair = 0;
@@ -1136,10 +1189,14 @@ struct AcqRun {
     int search();          // all (PRN, bin) cells: row pass + column pass per group
     int collect();         // row maxima + list to the host; can the sieve be trusted?
     int refine();          // candidates -> f64 coherent sums -> peak, bin, code phase per PRN
+    int metric_b1c_sigpower();
     int metric_b1c();      // GLRT normaliser
     int second_peak_b2a(); // second peak of the winning bin
     int fine_search();     // threshold + fine-Doppler search, results
     int finish();          // timing record
+    // the same decisions as collect() .. fine_search() as one chain of launches with a single download (bds_acq_refine.h)
+    bool device_refine_ok() const;
+    int refine_device();
 };
 
 int AcqRun::setup() {
@@ -1551,7 +1608,7 @@ int AcqRun::refine() {
 
 // sigPower = sqrt(var(sig(1:X)) * X), unbiased variance (B1C/acquisition.m:150)
 // (complex input: var = sum |x - mean|^2 / (X-1), as MATLAB's var of a complex vector)
-int AcqRun::metric_b1c() {
+int AcqRun::metric_b1c_sigpower() {
     // (a property of the loaded block and X: a million-term host sum, kept across calls -- it was ~1.5 ms of every run)
     if (a.sigpower_X != a.X) {
         const double mean = (a.h_prefix[a.X] - a.h_prefix[0]) / (double)a.X;
@@ -1566,6 +1623,11 @@ int AcqRun::metric_b1c() {
         a.sigpower = std::sqrt(var * (double)a.X);
         a.sigpower_X = a.X;
     }
+    return BDS_OK;
+}
+
+int AcqRun::metric_b1c() {
+    if (int rc = metric_b1c_sigpower()) return rc;
     const double sigPower = a.sigpower;
     for (int pi = 0; pi < P; ++pi) {
         res[pi].denom = sigPower;
@@ -1808,6 +1870,208 @@ int AcqRun::fine_search() {
     return BDS_OK;
 }
 
+constexpr int kHostRefine = -1002;   // refine_device: this run needs the host path (never returned through the C ABI)
+constexpr int kRefCandCap = 16384;   // candidates per stage the device chain holds (cfg3: a few hundred in the band)
+constexpr int kExtra2Cap = 1 << 20;  // candidate list of the B2a second-peak pass (one cell per PRN)
+
+bool AcqRun::device_refine_ok() const {
+    const Tuning &tune = ctx->tune;
+    if (!wcols || tune.neigh != 0 || tune.host_refine || a.rs.on || a.skind >= kF64 || P < 1) return false;
+    if (a.signal == BDS_SIGNAL_B2A) {
+        const Plan2D &pl = a.plan;
+        if (!(pl.small && fsearch)) return false;  // the tile kernel's second-peak pass reports per-tile records: host path
+        const size_t cap_cells = a.bw_cap / (size_t)pl.L * 8 / elem / (size_t)ncomp;
+        if ((size_t)P > cap_cells) return false;
+    }
+    return true;
+}
+
+int AcqRun::refine_device() {
+    Plan2D &pl = a.plan;
+    const Tuning &tune = ctx->tune;
+    const hipStream_t sm = stream();
+    const bool b1c = a.signal == BDS_SIGNAL_B1C;
+    int rc;
+    // ---- parameters, buffers, tables ---------------------------------------------------------------
+    RefParams rp{};
+    rp.P = P, rp.D = D, rp.ncomp = ncomp, rp.signal = a.signal;
+    rp.half = a.half && !tune.no_selfcheck ? 1 : 0;
+    rp.cand_cap = kRefCandCap, rp.extra_cap = kExtraCap;
+    rp.kDelta = kDelta;
+    rp.f0 = f0, rp.step = s->acqStep;
+    rp.X = a.X, rp.N = a.N, rp.spc = a.spc, rp.n_samples = a.n_samples;
+    rp.threshold = s->acqThreshold;
+    rp.s2c = (long)std::ceil(s->samplingFreq / s->codeFreqBasis) * 2;  // samples2CodeChip, B2a :137
+    rp.fineNoncoh = s->fineNoncoh;
+    rp.nfine = b1c ? (int)m_round(s->acqStep / 25) * 2 + 1 : (int)m_round(s->acqStep / 25) + 1;  // B1C :267, B2a :265
+    rp.nchunk = (rp.nfine + kCorrFreqs - 1) / kCorrFreqs;
+    rp.cplx = a.cplx ? 1 : 0;
+    if (b1c) {
+        if ((rc = metric_b1c_sigpower())) return rc;
+        rp.sigPower = a.sigpower;
+    }
+    const int fine_per = (b1c ? ncomp : 2 * s->fineNoncoh) * rp.nchunk;
+    if ((rc = ensure_code_cache(ctx, a, *s))) return rc;
+    for (int pi = 0; pi < P; ++pi)
+        for (int comp = 0; comp < ncomp; ++comp) {
+            make_code_table(ctx, a, (prns[pi] - 1) * 2 + comp, 0);
+            if (!b1c) make_code_table(ctx, a, (prns[pi] - 1) * 2 + comp, 1);
+        }
+    if ((rc = ensure_job_buffers(ctx, a, std::max<size_t>((size_t)kRefCandCap * ncomp, (size_t)P * fine_per)))) return rc;
+    if ((rc = ensure(ctx, &a.d_ref_prn, &a.ref_prn_cap, (size_t)P))) return rc;
+    if (!a.d_ref_g) BDS_HIP(ctx, hipMalloc((void **)&a.d_ref_g, sizeof(RefGlobal)));
+    if ((rc = ensure(ctx, &a.d_ref_cand, &a.ref_cand_cap, (size_t)2 * kRefCandCap))) return rc;
+    if ((rc = ensure(ctx, &a.d_ref_tabs, &a.ref_tabs_cap, (sizeof(long) + sizeof(int)) * (size_t)P + 64))) return rc;
+    long *d_cs_of = (long *)a.d_ref_tabs;
+    int *d_prn_of = (int *)(d_cs_of + P);
+    std::vector<long> h_cs(P);
+    for (int pi = 0; pi < P; ++pi) h_cs[pi] = (long)a.cs_slot[prns[pi]] * ncomp * pl.L;
+    BDS_HIP(ctx, hipMemcpyAsync(d_cs_of, h_cs.data(), sizeof(long) * P, hipMemcpyHostToDevice, sm));
+    BDS_HIP(ctx, hipMemcpyAsync(d_prn_of, prns.data(), sizeof(int) * P, hipMemcpyHostToDevice, sm));
+    BDS_HIP(ctx, hipMemsetAsync(a.d_ref_g, 0, sizeof(RefGlobal), sm));
+    BDS_HIP(ctx, hipMemsetAsync(a.d_ref_prn, 0, sizeof(RefPrn) * (size_t)P, sm));
+    const unsigned pb = (unsigned)((P + 63) / 64);
+
+    // ---- coarse refinement: thresholds -> candidates in the band -> f64 sums -> per-PRN maximum ----------------
+    hipLaunchKernelGGL(k_ref_thr<false>, dim3(P), dim3(64), 0, sm, (const unsigned long long *)a.d_cellmax, rp, a.d_ref_prn, a.d_ref_g,
+                       (const int *)a.d_extra_count);
+    hipLaunchKernelGGL(k_ref_compact<false>, dim3(256), dim3(256), 0, sm, (const Extra *)a.d_extra, (const int *)a.d_extra_count, rp,
+                       (const RefPrn *)a.d_ref_prn, (const int *)d_prn_of, (const int4 *)nullptr, a.d_ref_cand, a.d_jobs, a.d_ref_g);
+    hipLaunchKernelGGL(k_ref_count<false>, dim3(1), dim3(1), 0, sm, rp, a.d_ref_g);
+    hipLaunchKernelGGL(k_corr_f64, dim3(1024, kCorrSlices), dim3(256), 0, sm, a.sview(), a.N, (const int8_t *)a.d_codes, a.code_stride,
+                       1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)&a.d_ref_g->njobs);
+    hipLaunchKernelGGL(k_ref_pick<false>, dim3(P), dim3(256), 0, sm, (const RefCand *)a.d_ref_cand, (const double2 *)a.d_jobout, kCorrSlices,
+                       rp, a.d_ref_prn, a.d_ref_g);
+    BDS_HIP(ctx, hipGetLastError());
+
+    // ---- B2a: second peak of the winning bin, outside +-2 chips and within +-1 code (acquisition.m:224-249) -------
+    if (!b1c) {
+        if ((rc = ensure(ctx, &a.d_extra2, &a.extra2_cap, (size_t)kExtra2Cap))) return rc;
+        if (!a.d_extra2_count) BDS_HIP(ctx, hipMalloc((void **)&a.d_extra2_count, sizeof(int)));
+        if ((rc = ensure(ctx, &a.d_cellmax2, &a.cellmax2_cap, (size_t)P))) return rc;
+        if ((rc = ensure(ctx, &a.d_lb2, &a.lb2_cap, (size_t)P))) return rc;
+        BDS_HIP(ctx, hipMemsetAsync(a.d_extra2_count, 0, sizeof(int), sm));
+        BDS_HIP(ctx, hipMemsetAsync(a.d_cellmax2, 0, sizeof(unsigned long long) * (size_t)P, sm));
+        BDS_HIP(ctx, hipMemsetAsync(a.d_lb2, 0, sizeof(float) * (size_t)P, sm));
+        const size_t nb_ = sizeof(int) * P + sizeof(long) * P + sizeof(int4) * P + 64;
+        if ((rc = ensure(ctx, &a.d_cells, &a.cells_cap, nb_))) return rc;
+        int4 *d_rng = (int4 *)a.d_cells;  // 16-byte aligned first
+        long *d_cs = (long *)(d_rng + P);
+        int *d_bin = (int *)(d_cs + P);
+        hipLaunchKernelGGL(k_ref_second_setup, dim3(pb), dim3(64), 0, sm, rp, a.d_ref_prn, (const long *)d_cs_of, d_rng, d_cs, d_bin, a.d_ref_g);
+        const SieveOut so_keep = so;
+        so.recs = nullptr;
+        so.extra = a.d_extra2, so.extra_count = a.d_extra2_count, so.extra_cap = kExtra2Cap;
+        so.cellmax = a.d_cellmax2, so.lb = a.d_lb2, so.lb_div = 1;
+        const CellList cl{d_bin, d_cs, d_rng};
+        launch_list(P, nullptr, cl, 0, nullptr);
+        so = so_keep;
+        RefParams rp2 = rp;
+        rp2.extra_cap = kExtra2Cap;
+        RefCand *cand2 = a.d_ref_cand + kRefCandCap;
+        hipLaunchKernelGGL(k_ref_thr<true>, dim3(P), dim3(64), 0, sm, (const unsigned long long *)a.d_cellmax2, rp2, a.d_ref_prn, a.d_ref_g,
+                           (const int *)a.d_extra2_count);
+        hipLaunchKernelGGL(k_ref_compact<true>, dim3(64), dim3(256), 0, sm, (const Extra *)a.d_extra2, (const int *)a.d_extra2_count, rp2,
+                           (const RefPrn *)a.d_ref_prn, (const int *)d_prn_of, (const int4 *)d_rng, cand2, a.d_jobs, a.d_ref_g);
+        hipLaunchKernelGGL(k_ref_count<true>, dim3(1), dim3(1), 0, sm, rp2, a.d_ref_g);
+        hipLaunchKernelGGL(k_corr_f64, dim3(1024, kCorrSlices), dim3(256), 0, sm, a.sview(), a.N, (const int8_t *)a.d_codes, a.code_stride,
+                           1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)&a.d_ref_g->njobs2);
+        hipLaunchKernelGGL(k_ref_pick<true>, dim3(P), dim3(256), 0, sm, (const RefCand *)cand2, (const double2 *)a.d_jobout, kCorrSlices, rp2,
+                           a.d_ref_prn, a.d_ref_g);
+        BDS_HIP(ctx, hipGetLastError());
+    }
+
+    // ---- threshold + fine-Doppler search --------------------------------------------------------------------
+    hipLaunchKernelGGL(k_ref_fine_jobs, dim3(pb), dim3(64), 0, sm, rp, a.d_ref_prn, (const int *)d_prn_of, a.sview(), (const double *)a.d_prefix_c,
+                       (const double *)a.d_prefix_cq, a.d_jobs, a.d_ref_g);
+    hipLaunchKernelGGL(k_corr_f64_multi, dim3((unsigned)(P * fine_per), kCorrSlices), dim3(256), 0, sm, a.sview(), a.N, (const int8_t *)a.d_codes,
+                       a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
+    hipLaunchKernelGGL(k_ref_fine_pick, dim3(pb), dim3(64), 0, sm, rp, a.d_ref_prn, (const double2 *)a.d_jobout, kCorrSlices);
+    BDS_HIP(ctx, hipGetLastError());
+
+    // ---- the one download -------------------------------------------------------------------------------------
+    std::vector<RefPrn> h_prn(P);
+    RefGlobal h_g{};
+    std::vector<unsigned long long> h_cellmax((size_t)P * D);
+    BDS_HIP(ctx, hipMemcpyAsync(h_prn.data(), a.d_ref_prn, sizeof(RefPrn) * (size_t)P, hipMemcpyDeviceToHost, sm));
+    BDS_HIP(ctx, hipMemcpyAsync(&h_g, a.d_ref_g, sizeof(RefGlobal), hipMemcpyDeviceToHost, sm));
+    BDS_HIP(ctx, hipMemcpyAsync(h_cellmax.data(), a.d_cellmax, sizeof(unsigned long long) * (size_t)P * D, hipMemcpyDeviceToHost, sm));
+    BDS_HIP(ctx, hipStreamSynchronize(sm));
+
+    // ---- the host's share: the checks of collect() / refine() in their order, then the reported numbers -------------
+    a.h_rowmax.resize((size_t)P * D);
+    a.h_rowarg.resize((size_t)P * D);
+    for (size_t i = 0; i < h_cellmax.size(); ++i) unpack_cell(h_cellmax[i], &a.h_rowmax[i], &a.h_rowarg[i]);
+    a.run_prns = prns;
+    a.last.clear();
+    a.last_cands.clear();
+    a.cands_on_device = 0;
+    n_extra = h_g.n_extra;
+    a.n_extra_last = n_extra;
+    const bool bad = (h_g.flags & kRefNonFinite) != 0;
+    if (a.half && ((bad && !tune.no_selfcheck) || tune.test_force_fallback)) return redo(kRedoFp32, bad ? "non-finite row maximum" : "test hook");
+    if (n_extra > kExtraCap && a.half) return redo(kRedoFp32, "overflow list of the sieve ran over at the fp16-storage tolerance");
+    if (n_extra > kExtraCap && !a.no_fast_search) return redo(kRedoPlain, "overflow list of the sieve ran over");
+    if (h_g.flags & kRefCandOverflow) return kHostRefine;  // more candidates in the band than the chain holds
+    res.assign(P, PrnResult{});
+    max_of.assign(P, 0.f);
+    thr_of.assign(P, 0.f);
+    for (int pi = 0; pi < P; ++pi) {
+        const RefPrn &r = h_prn[pi];
+        max_of[pi] = r.max_of, thr_of[pi] = r.thr;
+        const double best = r.ncand > 0 ? combine(a, r.v) : -1.0;
+        res[pi].peak = best;
+        res[pi].fbin = r.b + 1;
+        res[pi].codePhase = (long)r.lag + 1;
+        if (a.half && !tune.no_selfcheck && r.ncand > 0 && std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
+            char msg[160];
+            snprintf(msg, sizeof(msg), "PRN %d: sieve maximum %.9g vs f64 %.9g (rel %.3g > %.3g)", prns[pi], (double)max_of[pi], best,
+                     std::fabs(best - (double)max_of[pi]) / best, 0.5 * kDelta);
+            return redo(kRedoFp32, msg);
+        }
+    }
+    a.cands_on_device = std::min(h_g.ncand, kRefCandCap);
+    a.cands_prns = prns;
+    if (b1c) {
+        if ((rc = metric_b1c())) return rc;
+    } else {
+        if (h_g.n_extra2 > kExtra2Cap || (h_g.flags & kRefCandOverflow)) return kHostRefine;  // (the host pass has the larger list)
+        for (int pi = 0; pi < P; ++pi) {
+            if (h_prn[pi].flags & kRefEmptyRange)
+                return fail(ctx, BDS_ERR_ARG, "PRN %d: empty second-peak range (acquisition.m:248 would fail)", prns[pi]);
+            res[pi].denom = h_prn[pi].nsecond > 0 ? combine(a, h_prn[pi].v2) : -1.0;
+        }
+    }
+    for (int pi = 0; pi < P; ++pi) {
+        const RefPrn &r = h_prn[pi];
+        PrnResult &q = res[pi];
+        const double metric = q.peak / q.denom;  // :252 / B1C :235
+        const bool det = metric > s->acqThreshold;
+        // (the device decided on its own evaluation of the same sums; a disagreement -- a metric within an ulp of the
+        //  threshold -- or a codePhase the device adjusted differently sends the run through the host path)
+        if (det != (r.detected != 0) || q.codePhase != r.codePhase) return kHostRefine;
+    }
+    for (int pi = 0; pi < P; ++pi) {
+        const RefPrn &r = h_prn[pi];
+        PrnResult &q = res[pi];
+        peakMetric[prns[pi] - 1] = q.peak / q.denom;
+        if (!r.detected) continue;
+        q.detected = true;
+        if (r.flags & kRefFineRange) {
+            const long blk = b1c ? a.spc : (long)s->fineNoncoh * a.spc;
+            return fail(ctx, BDS_ERR_ARG, "PRN %d: fine-search block %ld..%ld outside longSignal (%s)", prns[pi], q.codePhase,
+                        q.codePhase + blk - 1, b1c ? "B1C/acquisition.m:253" : "B2a/acquisition.m:290");
+        }
+        const double fb = bin_freq(q.fbin - 1);
+        double cf = b1c ? fb - s->acqStep + 25.0 * r.kbest : fb - s->acqStep / 2 + 25.0 * r.kbest;  // B1C :282-283, B2a :300-301
+        if (cf == 0) cf = 1;  // :333-335
+        carrFreq[prns[pi] - 1] = cf;
+        codePhase[prns[pi] - 1] = (double)q.codePhase;
+        if (detected) detected[prns[pi] - 1] = 1;
+    }
+    return BDS_OK;
+}
+
 int AcqRun::finish() {
     Plan2D &pl = a.plan;
     const Tuning &tune = ctx->tune;
@@ -1861,6 +2125,7 @@ int AcqRun::finish() {
     t.half_storage = a.half ? 1 : 0;  // 0 fp32; 1 fp16 storage (fp32 arithmetic either way)
     t.plan_l1 = pl.L1;
     t.plan_l2 = pl.L2;
+    t.refine_path = dev_refined ? 1 : 0;
     {
         const bool wrows_on = fsearch && a.half && pl.L2 == 4096 && (tune.wrows != 0 || pl.small);
         t.rows_kernel = !fsearch ? 0 : wrows_on ? 2 : 1;
@@ -1902,9 +2167,14 @@ int acq_run_once(bds_ctx *ctx, const bds_settings *s_in, const int32_t *prn_list
     if ((rc = r.setup())) return rc;
     if ((rc = r.forward_all())) return rc;
     if ((rc = r.search())) return rc;
-    if (!(rc = r.collect()) && !(rc = r.refine()) && !(rc = a.signal == BDS_SIGNAL_B1C ? r.metric_b1c() : r.second_peak_b2a()) &&
-        !(rc = r.fine_search()))
-        rc = r.finish();
+    rc = r.device_refine_ok() ? r.refine_device() : kHostRefine;
+    r.dev_refined = rc == BDS_OK;
+    if (rc == kHostRefine) {  // host path: the lists travel to the host, jobs are built there (rounds 1-4)
+        a.cands_on_device = 0;
+        if (!(rc = r.collect()) && !(rc = r.refine()) && !(rc = a.signal == BDS_SIGNAL_B1C ? r.metric_b1c() : r.second_peak_b2a()))
+            rc = r.fine_search();
+    }
+    if (!rc) rc = r.finish();
     if (rc == kRedoFp32 || rc == kRedoPlain) *why = r.why;
     return rc;
 }
@@ -1992,6 +2262,18 @@ extern "C" int bds_acq_grid(bds_ctx *ctx, float *row_max, int32_t *row_arg, int 
 
 extern "C" int bds_acq_candidates(bds_ctx *ctx, int prn, int32_t *bin, int64_t *lag, int cap) {
     if (!ctx || !ctx->acq) return BDS_ERR_ARG;
+    if (ctx->acq->cands_on_device > 0) {  // the device refinement chain keeps its candidates on the device: fetched when asked for
+        bds::AcqState &a = *ctx->acq;
+        std::vector<bds::RefCand> h((size_t)a.cands_on_device);
+        (void)hipSetDevice(ctx->device);
+        if (hipMemcpy(h.data(), a.d_ref_cand, sizeof(bds::RefCand) * h.size(), hipMemcpyDeviceToHost) != hipSuccess)
+            return bds::fail(ctx, BDS_ERR_HIP, "bds_acq_candidates: download failed");
+        a.last_cands.clear();
+        for (const bds::RefCand &c : h)
+            if (c.pi >= 0 && c.pi < (int)a.cands_prns.size()) a.last_cands[a.cands_prns[(size_t)c.pi]].push_back({c.b, (long)c.lag});
+        for (auto &kv : a.last_cands) std::sort(kv.second.begin(), kv.second.end());
+        a.cands_on_device = 0;
+    }
     auto it = ctx->acq->last_cands.find(prn);
     if (it == ctx->acq->last_cands.end()) return 0;
     const int n = (int)it->second.size();

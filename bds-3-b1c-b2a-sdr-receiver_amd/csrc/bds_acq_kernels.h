@@ -398,11 +398,16 @@ constexpr int kCorrFreqs = 6;
 __global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
                                                   const int8_t *__restrict__ codes, long code_stride,
                                                   double inv_fs, const CorrJob *__restrict__ jobs,
-                                                  double2 *__restrict__ out) {
+                                                  double2 *__restrict__ out, const int *__restrict__ njobs_dev) {
     // grid (jobs, slices): every job is cut into gridDim.y contiguous slices whose partial sums the
     // host adds in order -- a handful of million-sample jobs would otherwise run as a handful of
-    // workgroups (a latency chain of ~4000 iterations each)
-    const CorrJob jb = jobs[blockIdx.x];
+    // workgroups (a latency chain of ~4000 iterations each).
+    // njobs_dev: the job count lives on the device (the refinement chain of bds_acq_refine.h builds its jobs there and the host
+    // never learns the count before the launch): a fixed grid walks the jobs; nullptr: one job per workgroup column, as before.
+    const long njobs = njobs_dev ? (long)*njobs_dev : (long)gridDim.x;
+    __shared__ double s_r[256], s_i[256];
+    for (long jx = blockIdx.x; jx < njobs; jx += gridDim.x) {
+    const CorrJob jb = jobs[jx];
     const long slice = ((jb.len + gridDim.y - 1) / gridDim.y + 255) & ~255L;
     const long n_lo = (long)blockIdx.y * slice, n_hi = n_lo + slice < jb.len ? n_lo + slice : jb.len;
     double sr = 0.0, si = 0.0;
@@ -441,7 +446,6 @@ __global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
         sr += x * cr - xq * ci;
         si += x * ci + xq * cr;
     }
-    __shared__ double s_r[256], s_i[256];
     s_r[threadIdx.x] = sr;
     s_i[threadIdx.x] = si;
     __syncthreads();
@@ -452,7 +456,9 @@ __global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[(long)blockIdx.x * gridDim.y + blockIdx.y] = make_double2(s_r[0], s_i[0]);
+    if (threadIdx.x == 0) out[jx * gridDim.y + blockIdx.y] = make_double2(s_r[0], s_i[0]);
+    __syncthreads();  // s_r / s_i are re-used by the next job of this workgroup
+    }
 }
 
 // The same sums for up to kCorrFreqs carrier frequencies that share a job's samples and code (the fine-Doppler search:
@@ -467,6 +473,7 @@ __global__ __launch_bounds__(256) void k_corr_f64_multi(SampleView sig, long n_c
     constexpr int FM = kCorrFreqs;
     const CorrJob jb = jobs[blockIdx.x];
     const int nf = jb.nf;
+    if (nf <= 0) return;  // a place-holder job of the device refinement chain (PRN below the threshold): workgroup-uniform
     const long slice = ((jb.len + gridDim.y - 1) / gridDim.y + 255) & ~255L;
     const long n_lo = (long)blockIdx.y * slice, n_hi = n_lo + slice < jb.len ? n_lo + slice : jb.len;
     double sr[FM], si[FM], wr[FM], wi[FM], cr[FM], ci[FM];

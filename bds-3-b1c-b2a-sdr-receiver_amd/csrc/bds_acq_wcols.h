@@ -45,6 +45,11 @@
 #define BDS_WSYNC() __syncthreads()
 #endif
 
+// cache policy of the column pass's tile-row loads (aux of the buffer load: 0 default, 2 = nt; round 5, tools/exp/r5_nt.sh)
+#ifndef BDS_COLS_AUX
+#define BDS_COLS_AUX 0
+#endif
+
 namespace bds {
 
 template <int DIR>
@@ -209,10 +214,10 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
             }
 #endif
             if constexpr (ILV) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, q * rowstep, 0);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, q * rowstep, BDS_COLS_AUX);
                 pre[q] = make_uint4(v[0], v[1], v[2], v[3]);  // (column 2 cp: data, pilot; column 2 cp + 1: data, pilot)
             } else if constexpr (HS) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, q * rowstep, 0);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, q * rowstep, BDS_COLS_AUX);
                 pre[q] = make_uint2(v[0], v[1]);
             } else {
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, q * rowstep, 0);

@@ -43,6 +43,18 @@ constexpr int kWRowsRegion = 1024;  // elements of a wave's region (4 q' x 256)
 // cycles).  Stride 20 with every octet of e'' shifted by one slot more (mod 4) is clean both ways, and both sides still
 // address it as one per-lane base + a compile-time offset.
 constexpr int kWRowsXS = 20;
+// cache policy of the row pass's streams (round 5, tools/exp/r5_nt.sh): non-temporal loads of the signal-spectrum rows /
+// code-spectrum rows, non-temporal stores of the inter-pass buffer
+#ifndef BDS_ROWS_NT_X
+#define BDS_ROWS_NT_X 0
+#endif
+#ifndef BDS_ROWS_NT_C
+#define BDS_ROWS_NT_C 0
+#endif
+#ifndef BDS_ROWS_NT_ST
+#define BDS_ROWS_NT_ST 0
+#endif
+constexpr bool kRowsNtX = BDS_ROWS_NT_X != 0, kRowsNtC = BDS_ROWS_NT_C != 0, kRowsNtSt = BDS_ROWS_NT_ST != 0;
 constexpr size_t kWRowsLdsBytes = sizeof(float2) * (4 * kWRowsRegion + 256 * kWRowsXS + 4);
 
 // PK: the butterflies and twiddle products on packed fp32 pairs (bds_fft_pk.h: half the vector issue slots for the same pipe time)
@@ -95,17 +107,21 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         // (stored in the order this kernel multiplies them, wrows_perm() of bds_acq_fast.h: element xoff + 256 bh of the row
         //  sits at [16 tid + bh] -- four 16-byte loads per lane, 4 KB contiguous per wave)
         uint32_t xn[16];
-        auto fetch16 = [&](const ST *row, uint32_t(&d)[16]) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(row + 16 * tid);
+        auto fetch16 = [&](const ST *row, uint32_t(&d)[16], auto nt_c) {
+            constexpr bool NT = decltype(nt_c)::value;
+            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+            const u4v *p = reinterpret_cast<const u4v *>(row + 16 * tid);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint4 v = p[k];
+                // NT: read-once streams (the signal spectra: 2.5 GB per Doppler grid, nothing of it survives in L2 / MALL until
+                // the next PRN's launch) are requested non-temporal -- BDS_ROWS_NT_X, measured in tools/exp/r5_nt.sh
+                const u4v v = NT ? __builtin_nontemporal_load(p + k) : p[k];
                 d[4 * k] = v.x, d[4 * k + 1] = v.y, d[4 * k + 2] = v.z, d[4 * k + 3] = v.w;
             }
         };
         auto fetch_x = [&](int g) {
             const int bin = A.cell_bin ? A.cell_bin[g] : A.bin0 + g;
-            fetch16((const ST *)A.Xs + (long)bin * L + (long)k1 * S, xn);
+            fetch16((const ST *)A.Xs + (long)bin * L + (long)k1 * S, xn, std::integral_constant<bool, kRowsNtX>{});
         };
         // The inter-pass twiddle W_L^(k1 e) of output e = tid + 256 p' factors into a per-thread part
         //   wi = W_L^(k1 tid) x storage scale x w16^(u v) (u = tid & 15, v = tid >> 4: undoes the rotated read of phase 1b)
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
         uint32_t cv[NCOMP][16];
 #pragma unroll
         for (int comp = 0; comp < NCOMP; ++comp) {
-            fetch16(Cs + (long)comp * L + (long)k1 * S, cv[comp]);
+            fetch16(Cs + (long)comp * L + (long)k1 * S, cv[comp], std::integral_constant<bool, kRowsNtC>{});
         }
         PH_MARK(16);  // workgroup prologue: twiddles, code rows issued
         for (int g = g0; g < g1; ++g) {
@@ -243,8 +259,13 @@ __global__ __launch_bounds__(256, 2) void k_rows_wave_f(RowsFArgs A) {
                             if (comp == 0) {
                                 r0[ILV_OK ? p : 0] = h;
                             } else {
-                                uint2 *dst2 = (uint2 *)A.Bw + (long)g * L + (long)k1 * S + tid + 256 * p;
-                                *dst2 = make_uint2(r0[ILV_OK ? p : 0], h);
+                                typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+                                u2v *dst2 = (u2v *)A.Bw + (long)g * L + (long)k1 * S + tid + 256 * p;
+                                const u2v val = {r0[ILV_OK ? p : 0], h};
+                                if constexpr (kRowsNtSt)
+                                    __builtin_nontemporal_store(val, dst2);
+                                else
+                                    *dst2 = val;
                             }
                         } else {
                             ST *dst = (ST *)A.Bw + ((long)g * NCOMP + comp) * L + (long)k1 * S + tid;

@@ -69,6 +69,7 @@ Tuning tuning_from_env() {
     t.ilv = geti("BDS_ACQ_ILV", 1);
     t.pk = geti("BDS_ACQ_PK", 1);
     t.small_plan = geti("BDS_ACQ_SMALL", 1);
+    t.host_refine = has("BDS_ACQ_HOSTREFINE");
     t.neigh = std::max(0, std::min(4, geti("BDS_ACQ_NEIGH", 0)));
     t.wcols_qchunk = std::max(1, geti("BDS_ACQ_WCOLS_QCHUNK", 4));
     t.multi_force_rccl = has("BDS_MULTI_FORCE_RCCL");

@@ -47,6 +47,7 @@ struct Tuning {
     int clockprobe = 0;              // BDS_ACQ_CLOCKPROBE: sampled workgroups of the wave-private search kernels time themselves (bds_timing::shader_clock_GHz)
     int wrows = -1;                  // BDS_ACQ_WROWS: wave-private 4096-point row pass (bds_acq_wrows.h); -1 = default on, 0 = k_rows_inv_f
     int small_plan = 1;              // BDS_ACQ_SMALL: small two-component searches on the 80 x 4096 plan (bds_acq_scols.h); 0 = 256 x 1280 as in rounds 1-3
+    bool host_refine = false;        // BDS_ACQ_HOSTREFINE: refinement through the host (lists downloaded, jobs built there: rounds 1-4) instead of the device chain
     int neigh = 0;                   // BDS_ACQ_NEIGH: also refine the +-n bin / lag neighbours of every candidate in f64 (rounds 1-3: 1)
     int pk = 1;                      // BDS_ACQ_PK: packed-fp32 butterflies in the wave-private search kernels (bds_fft_pk.h); 0 = one fp32 instruction per real operation
     int ilv = 1;                     // BDS_ACQ_ILV: the wave-private pair of the 768 x 4096 plan keeps both components of an element side by side in the inter-pass buffer (0 = separate planes)

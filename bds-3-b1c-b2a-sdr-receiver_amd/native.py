@@ -72,7 +72,7 @@ class Timing(C.Structure):
                 ("n_bins", C.c_int32), ("n_prn", C.c_int32), ("n_comp", C.c_int32), ("half_storage", C.c_int32),
                 ("rows_ms", C.c_double), ("cols_ms", C.c_double), ("n_extra", C.c_int64), ("shader_clock_GHz", C.c_double),
                 ("plan_l1", C.c_int32), ("plan_l2", C.c_int32), ("rows_kernel", C.c_int32), ("cols_kernel", C.c_int32),
-                ("kernel_flags", C.c_int32), ("reserved1", C.c_int32)]
+                ("kernel_flags", C.c_int32), ("refine_path", C.c_int32)]
 
 
 class AcqJob(C.Structure):

@@ -333,3 +333,47 @@ def test_tuning_reload_rebuilds_the_spectrum_layout(ctx, monkeypatch):
         monkeypatch.delenv("BDS_ACQ_FORCE_L1L2", raising=False)
         monkeypatch.delenv("BDS_ACQ_WROWS", raising=False)
         ctx.reload_tuning()
+
+
+@pytest.mark.parametrize("case", ["b2a", "b2a_iq", "b1c", "b1c_iq", "b1c_data_only"])
+def test_device_refinement_chain_equals_the_host_path(case, monkeypatch):
+    """Round 5: candidates -> f64 sums -> peak -> (B2a) second peak -> threshold -> fine search as one chain of launches with a
+    single download (csrc/bds_acq_refine.h), against the host-driven refinement of rounds 1-4 (BDS_ACQ_HOSTREFINE=1): the same
+    acqResults, f64 peaks, normalisers, winning bins and refined candidate cells, bit for bit -- real and I/Q records, one
+    and two components."""
+    cplx = case.endswith("_iq")
+    if case == "b2a":
+        s, x, _ = medium_b2a()
+        prns = [5, 9, 19, 33]
+    elif case == "b2a_iq":
+        s, x, _ = cfg1_b2a_iq()
+        prns = [int(p) for p in s.acqSatelliteList]
+    elif case == "b1c_iq":
+        s, x, _ = small_b1c_iq()
+        prns = [int(p) for p in s.acqSatelliteList]
+    else:
+        s, x, _ = small_b1c()
+        prns = [3, 7, 12]
+        if case == "b1c_data_only":
+            s = s.copy(pilotACQflag=0)
+    out = {}
+    for host in ("0", "1"):
+        if host == "1":
+            monkeypatch.setenv("BDS_ACQ_HOSTREFINE", "1")
+        c = bds_amd.native.Context(0)
+        try:
+            c.acq_load(s, x, is_complex=cplx)
+            c.acq_prepare(s)
+            res = c.acq_run(s)
+            tm = c.timing()
+            out[host] = (res, c.acq_peaks(63), [c.acq_candidates(p) for p in prns])
+        finally:
+            c.close()
+        assert tm["refine_path"] == (1 if host == "0" else 0), tm
+    for u, v in zip(out["0"][0], out["1"][0]):
+        assert np.array_equal(u, v)
+    assert np.count_nonzero(out["0"][0][0]) >= 1
+    for u, v in zip(out["0"][1], out["1"][1]):
+        assert np.array_equal(u, v)
+    for u, v in zip(out["0"][2], out["1"][2]):
+        assert len(u) > 0 and np.array_equal(u, v)

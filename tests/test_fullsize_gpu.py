@@ -167,11 +167,12 @@ def test_b1c_wideband_tracking_full_rate(ctx):
 
 
 @pytest.mark.parametrize("env", [{"BDS_ACQ_PK": "0"}, {"BDS_ACQ_PK": "2"}, {"BDS_ACQ_ILV": "0"}, {"BDS_ACQ_PK": "0", "BDS_ACQ_ILV": "0"},
-                                 {"BDS_ACQ_NEIGH": "1"}, {"BDS_ACQ_WROWS": "0"}, {"BDS_ACQ_WCOLS": "0"}])
+                                 {"BDS_ACQ_NEIGH": "1"}, {"BDS_ACQ_WROWS": "0"}, {"BDS_ACQ_WCOLS": "0"}, {"BDS_ACQ_HOSTREFINE": "1"}])
 def test_cfg3_kernel_variants_decide_the_same(env, monkeypatch):
     """The switches of the round-4 search kernels at the cfg3 plan (768 x 4096): plain-fp32 instead of packed butterflies (both
     passes / column pass only), component planes instead of interleaved components, the +-1 neighbours of rounds 1-3 refined
-    as well, the round-2 row / column kernels.  Every variant is a different sieve in front of the same f64 decision: acqResults
+    as well, the round-2 row / column kernels, the refinement through the host (rounds 1-4) instead of the device chain of
+    round 5 (csrc/bds_acq_refine.h).  Every variant is a different sieve in front of the same f64 decision: acqResults
     must be the default's bit for bit, the search grid within the sieve's tolerance of it."""
     s, x, sats, _ = bench.build_workload("b1c")
     prns = [sats[0].prn, 2, sats[1].prn, 33]
@@ -195,6 +196,7 @@ def test_cfg3_kernel_variants_decide_the_same(env, monkeypatch):
         assert np.array_equal(u, v)
     np.testing.assert_allclose(g1, g0, rtol=2e-3)
     assert flags0 == 3  # default: interleaved components + packed butterflies
+    assert tm["refine_path"] == (0 if set(env) & {"BDS_ACQ_NEIGH", "BDS_ACQ_WCOLS", "BDS_ACQ_HOSTREFINE"} else 1)
     if "BDS_ACQ_PK" in env and env["BDS_ACQ_PK"] == "0":
         assert not tm["kernel_flags"] & 2
     if "BDS_ACQ_ILV" in env:
@@ -203,6 +205,31 @@ def test_cfg3_kernel_variants_decide_the_same(env, monkeypatch):
         assert tm["rows_kernel"] == 1 and tm["kernel_flags"] == 0
     if "BDS_ACQ_WCOLS" in env:
         assert tm["cols_kernel"] == 1
+
+
+def test_cfg2_refinement_paths_decide_the_same(monkeypatch):
+    """cfg2 with the refinement as one device chain (default: candidates, f64 sums, peak, second-peak pass, threshold and fine
+    search without a host round trip) and through the host (BDS_ACQ_HOSTREFINE=1, rounds 1-4): acqResults, the f64 peaks, the
+    second peaks and the refined candidate cells are the same."""
+    s, x, sats, _ = bench.build_workload("b2a")
+    out = {}
+    for host in ("0", "1"):
+        if host == "1":
+            monkeypatch.setenv("BDS_ACQ_HOSTREFINE", "1")
+        c = bds_amd.native.Context(0)
+        c.acq_load(s, x)
+        c.acq_prepare(s)
+        res = c.acq_run(s)
+        tm = c.timing()
+        out[host] = (res, c.acq_peaks(63), [c.acq_candidates(p) for p in (1, 19, 63)])
+        c.close()
+        assert tm["refine_path"] == (1 if host == "0" else 0)
+    for u, v in zip(out["0"][0], out["1"][0]):
+        assert np.array_equal(u, v)
+    for u, v in zip(out["0"][1], out["1"][1]):
+        assert np.array_equal(u, v)
+    for u, v in zip(out["0"][2], out["1"][2]):
+        assert len(u) > 0 and np.array_equal(u, v)
 
 
 def test_cfg2_plans_decide_the_same(monkeypatch):
