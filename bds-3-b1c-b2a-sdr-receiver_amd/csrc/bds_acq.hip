@@ -1596,11 +1596,14 @@ int AcqRun::refine() {
         res[pi].codePhase = bc.lag + 1;
         // The sieve's maximum must agree with the f64 value to well inside the tolerance band it was
         // searched with; otherwise its error model does not hold for this input: redo with fp32 storage.
-        if (a.half && !tune.no_selfcheck && !cells[pi].empty() && std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
+        // (round 5: fp32 storage on the specialised kernels is checked the same way against ITS tolerance -- its forward pass
+        //  rotates the carrier in fp32 since round 4 -- and falls back to the run-time-plan kernels)
+        if ((a.half || (fsearch && !a.no_fast_search)) && !tune.no_selfcheck && !cells[pi].empty() &&
+            std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
             char msg[160];
             snprintf(msg, sizeof(msg), "PRN %d: sieve maximum %.9g vs f64 %.9g (rel %.3g > %.3g)", prns[pi], (double)max_of[pi], best,
                      std::fabs(best - (double)max_of[pi]) / best, 0.5 * kDelta);
-            return redo(kRedoFp32, msg);
+            return redo(a.half ? kRedoFp32 : kRedoPlain, msg);
         }
     }
     return BDS_OK;
@@ -2012,7 +2015,11 @@ int AcqRun::refine_device() {
     if (a.half && ((bad && !tune.no_selfcheck) || tune.test_force_fallback)) return redo(kRedoFp32, bad ? "non-finite row maximum" : "test hook");
     if (n_extra > kExtraCap && a.half) return redo(kRedoFp32, "overflow list of the sieve ran over at the fp16-storage tolerance");
     if (n_extra > kExtraCap && !a.no_fast_search) return redo(kRedoPlain, "overflow list of the sieve ran over");
-    if (h_g.flags & kRefCandOverflow) return kHostRefine;  // more candidates in the band than the chain holds
+    auto host_path = [&](const char *reason) {
+        if (tune.verbose) fprintf(stderr, "[bds] device refinement chain hands over to the host path: %s\n", reason);
+        return kHostRefine;
+    };
+    if (h_g.flags & kRefCandOverflow) return host_path("more candidates in the band than the chain holds");
     res.assign(P, PrnResult{});
     max_of.assign(P, 0.f);
     thr_of.assign(P, 0.f);
@@ -2023,11 +2030,12 @@ int AcqRun::refine_device() {
         res[pi].peak = best;
         res[pi].fbin = r.b + 1;
         res[pi].codePhase = (long)r.lag + 1;
-        if (a.half && !tune.no_selfcheck && r.ncand > 0 && std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
+        if ((a.half || (fsearch && !a.no_fast_search)) && !tune.no_selfcheck && r.ncand > 0 &&
+            std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
             char msg[160];
             snprintf(msg, sizeof(msg), "PRN %d: sieve maximum %.9g vs f64 %.9g (rel %.3g > %.3g)", prns[pi], (double)max_of[pi], best,
                      std::fabs(best - (double)max_of[pi]) / best, 0.5 * kDelta);
-            return redo(kRedoFp32, msg);
+            return redo(a.half ? kRedoFp32 : kRedoPlain, msg);
         }
     }
     a.cands_on_device = std::min(h_g.ncand, kRefCandCap);
@@ -2035,7 +2043,7 @@ int AcqRun::refine_device() {
     if (b1c) {
         if ((rc = metric_b1c())) return rc;
     } else {
-        if (h_g.n_extra2 > kExtra2Cap || (h_g.flags & kRefCandOverflow)) return kHostRefine;  // (the host pass has the larger list)
+        if (h_g.n_extra2 > kExtra2Cap) return host_path("candidate list of the second-peak pass ran over");  // (the host pass has the larger list)
         for (int pi = 0; pi < P; ++pi) {
             if (h_prn[pi].flags & kRefEmptyRange)
                 return fail(ctx, BDS_ERR_ARG, "PRN %d: empty second-peak range (acquisition.m:248 would fail)", prns[pi]);
@@ -2049,7 +2057,12 @@ int AcqRun::refine_device() {
         const bool det = metric > s->acqThreshold;
         // (the device decided on its own evaluation of the same sums; a disagreement -- a metric within an ulp of the
         //  threshold -- or a codePhase the device adjusted differently sends the run through the host path)
-        if (det != (r.detected != 0) || q.codePhase != r.codePhase) return kHostRefine;
+        if (det != (r.detected != 0) || q.codePhase != r.codePhase) {
+            if (tune.verbose)
+                fprintf(stderr, "[bds] PRN %d: host metric %.17g (peak %.17g / %.17g) vs device decision %d (best %.17g second %.17g nsecond %d), codePhase %ld vs %ld\n",
+                        prns[pi], metric, q.peak, q.denom, r.detected, r.best, r.second, r.nsecond, q.codePhase, r.codePhase);
+            return host_path("threshold decision or code phase differ between device and host");
+        }
     }
     for (int pi = 0; pi < P; ++pi) {
         const RefPrn &r = h_prn[pi];

@@ -43,8 +43,11 @@ constexpr int kWRowsRegion = 1024;  // elements of a wave's region (4 q' x 256)
 // cycles).  Stride 20 with every octet of e'' shifted by one slot more (mod 4) is clean both ways, and both sides still
 // address it as one per-lane base + a compile-time offset.
 constexpr int kWRowsXS = 20;
-// cache policy of the row pass's streams (round 5, tools/exp/r5_nt.sh): non-temporal loads of the signal-spectrum rows /
-// code-spectrum rows, non-temporal stores of the inter-pass buffer
+// cache policy of the row pass's streams (round 5, tools/exp/r5_nt.sh, profiles/r05_nt_ab.txt; per 201 cells, alternating on one
+// box): non-temporal STORES of the inter-pass buffer pair 3.175 vs 3.189 ms (kept: rows 1.685 vs 1.703, columns 1.451 vs 1.470);
+// non-temporal loads of the signal-spectrum rows 3.40 vs 3.19 (rows 1.93 vs 1.70: dropped), of the code-spectrum rows as well
+// 3.43; the column pass's tile-row loads with aux = 2 (nt) 3.34 (columns 1.63 vs 1.47: the 128-byte lines adjacent tiles share
+// are evicted between them)
 #ifndef BDS_ROWS_NT_X
 #define BDS_ROWS_NT_X 0
 #endif
@@ -52,7 +55,7 @@ constexpr int kWRowsXS = 20;
 #define BDS_ROWS_NT_C 0
 #endif
 #ifndef BDS_ROWS_NT_ST
-#define BDS_ROWS_NT_ST 0
+#define BDS_ROWS_NT_ST 1
 #endif
 constexpr bool kRowsNtX = BDS_ROWS_NT_X != 0, kRowsNtC = BDS_ROWS_NT_C != 0, kRowsNtSt = BDS_ROWS_NT_ST != 0;
 constexpr size_t kWRowsLdsBytes = sizeof(float2) * (4 * kWRowsRegion + 256 * kWRowsXS + 4);

@@ -349,7 +349,7 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
     double acc[kNSums];
 #pragma unroll
     for (int i = 0; i < kNSums; ++i) acc[i] = 0.0;
-    if (PREC < 3 && lane < SEG) {  // rotation of sample j of a segment against its first sample
+    if ((PREC < 3 || PREC == 5) && lane < SEG) {  // rotation of sample j of a segment against its first sample
         const double cyc = g.carrFreq * ((double)lane * p.inv_fs);
         double sn, cs;
         sincospi(2.0 * (cyc - floor(cyc)), &sn, &cs);
@@ -422,6 +422,12 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
             }
             const CT bcf = (CT)bc, bsf = (CT)bs;
             const int lbase = lane * SEG + lane;
+            double trig5 = 0.0, c5 = 1.0, s5 = 0.0;
+            const double dlt5 = w_ref * p.inv_fs;
+            if constexpr (PREC == 5) {  // the reference's trigarg of the segment's first sample and its phasor
+                trig5 = (w_ref * div_by_fs((double)kb, p.fs, p.inv_fs)) + g.remCarr;
+                sincos_strict(trig5, s5, c5);
+            }
             // sample j of the segment, carrier-wiped: (ib, qb).  PREC < 3: the carrier is base x table entry with
             // explicit FMAs (the exact two-rounding rule of the build only matters for the code index), in fp32
             // (PREC 0, 1) or f64 (PREC 2); PREC 3: sin / cos of the reference's own trigarg(k)
@@ -439,6 +445,19 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
                     const double tt = (double)(kb + j) / p.fs;
                     const double trig = (w_ref * tt) + g.remCarr;
                     sincos(trig, &s2, &c2);
+                } else if constexpr (PREC == 5) {
+                    // the same value from one library-free sin / cos per lane and pass: trigarg(k + j) = trigarg(k) + D_j with D_j
+                    // EXACT (difference of two neighbouring f64 values), D_j = j dlt + eps_j with dlt = 2 pi carrFreq / fs and
+                    // |eps_j| ~ 1e-10 rad the reference's own rounding noise, so
+                    //   exp(i trigarg(k + j)) = exp(i trigarg(k)) x exp(i j dlt) x (1 + i eps_j)      (eps^2 / 2 < 1e-19)
+                    // -- the segment's first phasor, the wave's rotation table, a first-order correction: 14 f64 operations per
+                    // sample instead of 40
+                    const double tt = div_by_fs((double)(kb + j), p.fs, p.inv_fs);
+                    const double trig = (w_ref * tt) + g.remCarr;
+                    const double eps = fma(-(double)j, dlt5, trig - trig5);
+                    const CT2 w = s_w[j];
+                    const double c1 = fma(c5, w.x, -(s5 * w.y)), s1 = fma(s5, w.x, c5 * w.y);
+                    c2 = fma(-eps, s1, c1), s2 = fma(eps, c1, s1);
                 } else if constexpr (PREC == 4) {
                     const double tt = div_by_fs((double)(kb + j), p.fs, p.inv_fs);
                     BDS_DASSERT(tt == (double)(kb + j) / p.fs);
@@ -758,7 +777,8 @@ __global__ __launch_bounds__(kTrkThreads) void k_trk_correlate_open(const int8_t
             else if (p.prec == 1) go(mode_c, std::integral_constant<int, 1>{});                             \
             else if (p.prec == 2) go(mode_c, std::integral_constant<int, 2>{});                             \
             else if (p.prec == 3) go(mode_c, std::integral_constant<int, 3>{});                             \
-            else go(mode_c, std::integral_constant<int, 4>{});                                              \
+            else if (p.prec == 4) go(mode_c, std::integral_constant<int, 4>{});                             \
+            else go(mode_c, std::integral_constant<int, 5>{});                                              \
         };                                                                                                  \
         if (p.mode == BDS_TRACK_B2A) gp(std::integral_constant<int, BDS_TRACK_B2A>{});                      \
         else if (p.mode == BDS_TRACK_NB) gp(std::integral_constant<int, BDS_TRACK_NB>{});                   \
@@ -1065,7 +1085,7 @@ static int fill_params(bds_ctx *ctx, const bds_settings &s, TrkParams &p, int n_
         if (ctx->tune.trk_chunk == 2048) p.runs = 8;
         if (ctx->tune.trk_chunk == 4096) p.runs = 16;
         p.chunk = kTrkThreads * p.runs;
-        p.prec = std::max(0, std::min(4, ctx->tune.trk_prec));
+        p.prec = std::max(0, std::min(5, ctx->tune.trk_prec));
         if (ctx->tune.trk_seg == 8 || ctx->tune.trk_seg == 16) p.runs = ctx->tune.trk_seg, p.chunk = kTrkThreads * p.runs;
     }
     p.n_bytes = (long long)(n_bytes / (p.cplx ? 2 : 1));  // whole samples an fread can deliver

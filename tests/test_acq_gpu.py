@@ -356,6 +356,11 @@ def test_device_refinement_chain_equals_the_host_path(case, monkeypatch):
         prns = [3, 7, 12]
         if case == "b1c_data_only":
             s = s.copy(pilotACQflag=0)
+    monkeypatch.setenv("BDS_VERBOSE", "1")  # a hand-over to the host path names its reason on stderr (shown when the test fails)
+    if case.startswith("b1c"):
+        # (these reduced-rate blocks plan 256 x 2048, where the tile column pass with its per-tile records is the default and
+        #  the host path its refinement: the wave-private pass -- what cfg3 runs -- is switched on for them)
+        monkeypatch.setenv("BDS_ACQ_WCOLS", "1")
     out = {}
     for host in ("0", "1"):
         if host == "1":

@@ -212,6 +212,7 @@ def test_cfg2_refinement_paths_decide_the_same(monkeypatch):
     search without a host round trip) and through the host (BDS_ACQ_HOSTREFINE=1, rounds 1-4): acqResults, the f64 peaks, the
     second peaks and the refined candidate cells are the same."""
     s, x, sats, _ = bench.build_workload("b2a")
+    monkeypatch.setenv("BDS_VERBOSE", "1")
     out = {}
     for host in ("0", "1"):
         if host == "1":
