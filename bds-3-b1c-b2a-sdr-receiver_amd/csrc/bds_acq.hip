@@ -392,8 +392,9 @@ struct AcqState {
     double2 *d_jobout = nullptr;
     size_t jobs_cap = 0;
     // device refinement chain (bds_acq_refine.h)
-    RefPrn *d_ref_prn = nullptr;
-    size_t ref_prn_cap = 0;
+    char *d_ref_zero = nullptr;         // one block, zeroed per run: RefGlobal | RefPrn[P] | cellmax2[P] | lb2[P] | extra2_count
+    size_t ref_zero_cap = 0;
+    RefPrn *d_ref_prn = nullptr;        // (pointers into d_ref_zero)
     RefGlobal *d_ref_g = nullptr;
     RefCand *d_ref_cand = nullptr;      // [kRefCandCap] coarse candidates, then [kRefCandCap] of the second-peak pass
     size_t ref_cand_cap = 0;
@@ -403,11 +404,9 @@ struct AcqState {
     size_t prefix_c_cap = 0, prefix_cq_cap = 0;
     Extra *d_extra2 = nullptr;          // candidate list / per-PRN maxima / bounds of the B2a second-peak pass
     size_t extra2_cap = 0;
-    int *d_extra2_count = nullptr;
+    int *d_extra2_count = nullptr;      // (these three: pointers into d_ref_zero)
     unsigned long long *d_cellmax2 = nullptr;
-    size_t cellmax2_cap = 0;
     float *d_lb2 = nullptr;
-    size_t lb2_cap = 0;
     int cands_on_device = 0;            // >0: last_cands of the last run still sits in d_ref_cand (fetched on demand)
     std::vector<int> cands_prns;
     // last run (diagnostics)
@@ -436,9 +435,8 @@ void acq_state_free(AcqState *a) {
     for (void *p : {(void *)a->d_sig, (void *)a->d_prim, (void *)a->d_Cs, (void *)a->d_Xs, (void *)a->d_Bw,
                     (void *)a->d_recs, (void *)a->d_rowmax, (void *)a->d_rowarg, (void *)a->d_jobs, (void *)a->d_codes,
                     (void *)a->d_jobout, (void *)a->d_sig64, (void *)a->d_ffa, (void *)a->d_ffb, (void *)a->d_fir, (void *)a->d_cells,
-                    (void *)a->d_extra, (void *)a->d_extra_count, (void *)a->d_cellmax, (void *)a->d_lb, (void *)a->d_ref_prn,
-                    (void *)a->d_ref_g, (void *)a->d_ref_cand, (void *)a->d_ref_tabs, (void *)a->d_prefix_c, (void *)a->d_prefix_cq,
-                    (void *)a->d_extra2, (void *)a->d_extra2_count, (void *)a->d_cellmax2, (void *)a->d_lb2})
+                    (void *)a->d_extra, (void *)a->d_extra_count, (void *)a->d_cellmax, (void *)a->d_lb, (void *)a->d_ref_zero,
+                    (void *)a->d_ref_cand, (void *)a->d_ref_tabs, (void *)a->d_prefix_c, (void *)a->d_prefix_cq, (void *)a->d_extra2})
         if (p) (void)hipFree(p);
     delete a;
 }
@@ -1075,7 +1073,7 @@ static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vecto
                            (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
     else
         hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size(), kSlices), dim3(256), 0, st(ctx), a.sview(), a.N,
-                           (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)nullptr);
+                           (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)nullptr, 0, 0);
     BDS_HIP(ctx, hipGetLastError());
     std::vector<double2> part(jobs.size() * kSlices * nper);
     BDS_HIP(ctx, hipMemcpyAsync(part.data(), a.d_jobout, sizeof(double2) * part.size(), hipMemcpyDeviceToHost, st(ctx)));
@@ -1247,8 +1245,9 @@ int AcqRun::setup() {
         w1 *= inv;
     }
     fsearch = (pl.fast || (pl.small && a.half)) && !a.no_fast_search;  // fp32-arithmetic specialised kernels (default)
-    // sieve tolerance: every lag within kDelta of a PRN's maximum is re-evaluated in f64.  fp32 storage errs by ~1e-7 of the
-    // PRN maximum.  fp16 storage: three roundings lie between the exact value and the sieve's (signal spectrum, code spectrum,
+    // sieve tolerance: every lag within kDelta of a PRN's maximum is re-evaluated in f64.  fp32 storage (with the fp32 carrier / twiddle
+    // rotations of the forward pass, round 4) errs by 5.3e-7 of the PRN maximum at worst against the f64 oracle (tools/sieve_error.py,
+    // profiles/r05_sieve_error_small.txt: 19x inside its kDelta / 2 = 1e-5; checked at run time like the fp16 mode).  fp16 storage: three roundings lie between the exact value and the sieve's (signal spectrum, code spectrum,
     // inter-pass buffer; 2^-11 relative each).  On noise-like spectra they average out -- 2.5e-4 of the PRN maximum at worst
     // over 63 x 201 rows -- but a spectrum dominated by ONE line (a CW interferer) carries them coherently: 6.4e-4 / 7.9e-4
     // measured at J/N = +20 / +40 dB (tools/sieve_stress.py, profiles/r04_sieve_error.txt), bounded by 3 x 2^-11 = 1.46e-3.
@@ -1921,8 +1920,20 @@ int AcqRun::refine_device() {
             if (!b1c) make_code_table(ctx, a, (prns[pi] - 1) * 2 + comp, 1);
         }
     if ((rc = ensure_job_buffers(ctx, a, std::max<size_t>((size_t)kRefCandCap * ncomp, (size_t)P * fine_per)))) return rc;
-    if ((rc = ensure(ctx, &a.d_ref_prn, &a.ref_prn_cap, (size_t)P))) return rc;
-    if (!a.d_ref_g) BDS_HIP(ctx, hipMalloc((void **)&a.d_ref_g, sizeof(RefGlobal)));
+    // everything the chain wants zeroed lives in ONE block (one fill instead of five):
+    //   RefGlobal | RefPrn[P] | cellmax2[P] | lb2[P] | extra2_count
+    {
+        const size_t o_prn = 64, o_cm2 = o_prn + sizeof(RefPrn) * (size_t)P, o_lb2 = o_cm2 + sizeof(unsigned long long) * (size_t)P;
+        const size_t o_cnt = (o_lb2 + sizeof(float) * (size_t)P + 15) & ~(size_t)15, total = o_cnt + 16;
+        static_assert(sizeof(RefGlobal) <= 64 && sizeof(RefPrn) % 16 == 0, "layout of the zeroed block");
+        if ((rc = ensure(ctx, &a.d_ref_zero, &a.ref_zero_cap, total))) return rc;
+        a.d_ref_g = (RefGlobal *)a.d_ref_zero;
+        a.d_ref_prn = (RefPrn *)(a.d_ref_zero + o_prn);
+        a.d_cellmax2 = (unsigned long long *)(a.d_ref_zero + o_cm2);
+        a.d_lb2 = (float *)(a.d_ref_zero + o_lb2);
+        a.d_extra2_count = (int *)(a.d_ref_zero + o_cnt);
+        BDS_HIP(ctx, hipMemsetAsync(a.d_ref_zero, 0, total, sm));
+    }
     if ((rc = ensure(ctx, &a.d_ref_cand, &a.ref_cand_cap, (size_t)2 * kRefCandCap))) return rc;
     if ((rc = ensure(ctx, &a.d_ref_tabs, &a.ref_tabs_cap, (sizeof(long) + sizeof(int)) * (size_t)P + 64))) return rc;
     long *d_cs_of = (long *)a.d_ref_tabs;
@@ -1931,8 +1942,6 @@ int AcqRun::refine_device() {
     for (int pi = 0; pi < P; ++pi) h_cs[pi] = (long)a.cs_slot[prns[pi]] * ncomp * pl.L;
     BDS_HIP(ctx, hipMemcpyAsync(d_cs_of, h_cs.data(), sizeof(long) * P, hipMemcpyHostToDevice, sm));
     BDS_HIP(ctx, hipMemcpyAsync(d_prn_of, prns.data(), sizeof(int) * P, hipMemcpyHostToDevice, sm));
-    BDS_HIP(ctx, hipMemsetAsync(a.d_ref_g, 0, sizeof(RefGlobal), sm));
-    BDS_HIP(ctx, hipMemsetAsync(a.d_ref_prn, 0, sizeof(RefPrn) * (size_t)P, sm));
     const unsigned pb = (unsigned)((P + 63) / 64);
 
     // ---- coarse refinement: thresholds -> candidates in the band -> f64 sums -> per-PRN maximum ----------------
@@ -1940,9 +1949,8 @@ int AcqRun::refine_device() {
                        (const int *)a.d_extra_count);
     hipLaunchKernelGGL(k_ref_compact<false>, dim3(256), dim3(256), 0, sm, (const Extra *)a.d_extra, (const int *)a.d_extra_count, rp,
                        (const RefPrn *)a.d_ref_prn, (const int *)d_prn_of, (const int4 *)nullptr, a.d_ref_cand, a.d_jobs, a.d_ref_g);
-    hipLaunchKernelGGL(k_ref_count<false>, dim3(1), dim3(1), 0, sm, rp, a.d_ref_g);
     hipLaunchKernelGGL(k_corr_f64, dim3(1024, kCorrSlices), dim3(256), 0, sm, a.sview(), a.N, (const int8_t *)a.d_codes, a.code_stride,
-                       1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)&a.d_ref_g->njobs);
+                       1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)&a.d_ref_g->ncand, kRefCandCap, ncomp);
     hipLaunchKernelGGL(k_ref_pick<false>, dim3(P), dim3(256), 0, sm, (const RefCand *)a.d_ref_cand, (const double2 *)a.d_jobout, kCorrSlices,
                        rp, a.d_ref_prn, a.d_ref_g);
     BDS_HIP(ctx, hipGetLastError());
@@ -1950,12 +1958,6 @@ int AcqRun::refine_device() {
     // ---- B2a: second peak of the winning bin, outside +-2 chips and within +-1 code (acquisition.m:224-249) -------
     if (!b1c) {
         if ((rc = ensure(ctx, &a.d_extra2, &a.extra2_cap, (size_t)kExtra2Cap))) return rc;
-        if (!a.d_extra2_count) BDS_HIP(ctx, hipMalloc((void **)&a.d_extra2_count, sizeof(int)));
-        if ((rc = ensure(ctx, &a.d_cellmax2, &a.cellmax2_cap, (size_t)P))) return rc;
-        if ((rc = ensure(ctx, &a.d_lb2, &a.lb2_cap, (size_t)P))) return rc;
-        BDS_HIP(ctx, hipMemsetAsync(a.d_extra2_count, 0, sizeof(int), sm));
-        BDS_HIP(ctx, hipMemsetAsync(a.d_cellmax2, 0, sizeof(unsigned long long) * (size_t)P, sm));
-        BDS_HIP(ctx, hipMemsetAsync(a.d_lb2, 0, sizeof(float) * (size_t)P, sm));
         const size_t nb_ = sizeof(int) * P + sizeof(long) * P + sizeof(int4) * P + 64;
         if ((rc = ensure(ctx, &a.d_cells, &a.cells_cap, nb_))) return rc;
         int4 *d_rng = (int4 *)a.d_cells;  // 16-byte aligned first
@@ -1976,30 +1978,33 @@ int AcqRun::refine_device() {
                            (const int *)a.d_extra2_count);
         hipLaunchKernelGGL(k_ref_compact<true>, dim3(64), dim3(256), 0, sm, (const Extra *)a.d_extra2, (const int *)a.d_extra2_count, rp2,
                            (const RefPrn *)a.d_ref_prn, (const int *)d_prn_of, (const int4 *)d_rng, cand2, a.d_jobs, a.d_ref_g);
-        hipLaunchKernelGGL(k_ref_count<true>, dim3(1), dim3(1), 0, sm, rp2, a.d_ref_g);
         hipLaunchKernelGGL(k_corr_f64, dim3(1024, kCorrSlices), dim3(256), 0, sm, a.sview(), a.N, (const int8_t *)a.d_codes, a.code_stride,
-                           1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)&a.d_ref_g->njobs2);
+                           1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)&a.d_ref_g->ncand2, kRefCandCap, ncomp);
         hipLaunchKernelGGL(k_ref_pick<true>, dim3(P), dim3(256), 0, sm, (const RefCand *)cand2, (const double2 *)a.d_jobout, kCorrSlices, rp2,
                            a.d_ref_prn, a.d_ref_g);
         BDS_HIP(ctx, hipGetLastError());
     }
 
     // ---- threshold + fine-Doppler search --------------------------------------------------------------------
-    hipLaunchKernelGGL(k_ref_fine_jobs, dim3(pb), dim3(64), 0, sm, rp, a.d_ref_prn, (const int *)d_prn_of, a.sview(), (const double *)a.d_prefix_c,
+    hipLaunchKernelGGL(k_ref_fine_jobs, dim3(P), dim3(64), 0, sm, rp, a.d_ref_prn, (const int *)d_prn_of, a.sview(), (const double *)a.d_prefix_c,
                        (const double *)a.d_prefix_cq, a.d_jobs, a.d_ref_g);
     hipLaunchKernelGGL(k_corr_f64_multi, dim3((unsigned)(P * fine_per), kCorrSlices), dim3(256), 0, sm, a.sview(), a.N, (const int8_t *)a.d_codes,
                        a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
-    hipLaunchKernelGGL(k_ref_fine_pick, dim3(pb), dim3(64), 0, sm, rp, a.d_ref_prn, (const double2 *)a.d_jobout, kCorrSlices);
+    const size_t pick_lds = sizeof(double) * ((size_t)(b1c ? ncomp : 2 * s->fineNoncoh) * rp.nfine + rp.nfine);
+    if (pick_lds > 60000) return kHostRefine;  // (thousands of fine frequencies: the host path has no such limit)
+    hipLaunchKernelGGL(k_ref_fine_pick, dim3(P), dim3(256), pick_lds, sm, rp, a.d_ref_prn, (const double2 *)a.d_jobout, kCorrSlices);
     BDS_HIP(ctx, hipGetLastError());
 
     // ---- the one download -------------------------------------------------------------------------------------
-    std::vector<RefPrn> h_prn(P);
-    RefGlobal h_g{};
+    std::vector<char> h_blk(64 + sizeof(RefPrn) * (size_t)P);  // RefGlobal and RefPrn[P] as they lie in the zeroed block
     std::vector<unsigned long long> h_cellmax((size_t)P * D);
-    BDS_HIP(ctx, hipMemcpyAsync(h_prn.data(), a.d_ref_prn, sizeof(RefPrn) * (size_t)P, hipMemcpyDeviceToHost, sm));
-    BDS_HIP(ctx, hipMemcpyAsync(&h_g, a.d_ref_g, sizeof(RefGlobal), hipMemcpyDeviceToHost, sm));
+    BDS_HIP(ctx, hipMemcpyAsync(h_blk.data(), a.d_ref_zero, h_blk.size(), hipMemcpyDeviceToHost, sm));
     BDS_HIP(ctx, hipMemcpyAsync(h_cellmax.data(), a.d_cellmax, sizeof(unsigned long long) * (size_t)P * D, hipMemcpyDeviceToHost, sm));
     BDS_HIP(ctx, hipStreamSynchronize(sm));
+    RefGlobal h_g;
+    memcpy(&h_g, h_blk.data(), sizeof(h_g));
+    std::vector<RefPrn> h_prn(P);
+    memcpy(h_prn.data(), h_blk.data() + 64, sizeof(RefPrn) * (size_t)P);
 
     // ---- the host's share: the checks of collect() / refine() in their order, then the reported numbers -------------
     a.h_rowmax.resize((size_t)P * D);

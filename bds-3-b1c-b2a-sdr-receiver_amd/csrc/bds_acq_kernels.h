@@ -398,13 +398,15 @@ constexpr int kCorrFreqs = 6;
 __global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
                                                   const int8_t *__restrict__ codes, long code_stride,
                                                   double inv_fs, const CorrJob *__restrict__ jobs,
-                                                  double2 *__restrict__ out, const int *__restrict__ njobs_dev) {
+                                                  double2 *__restrict__ out, const int *__restrict__ njobs_dev, int dev_cap,
+                                                  int dev_mult) {
     // grid (jobs, slices): every job is cut into gridDim.y contiguous slices whose partial sums the
     // host adds in order -- a handful of million-sample jobs would otherwise run as a handful of
     // workgroups (a latency chain of ~4000 iterations each).
     // njobs_dev: the job count lives on the device (the refinement chain of bds_acq_refine.h builds its jobs there and the host
     // never learns the count before the launch): a fixed grid walks the jobs; nullptr: one job per workgroup column, as before.
-    const long njobs = njobs_dev ? (long)*njobs_dev : (long)gridDim.x;
+    // (njobs_dev counts candidates: dev_mult jobs -- components -- each, at most dev_cap of them held)
+    const long njobs = njobs_dev ? (long)min(*njobs_dev, dev_cap) * dev_mult : (long)gridDim.x;
     __shared__ double s_r[256], s_i[256];
     for (long jx = blockIdx.x; jx < njobs; jx += gridDim.x) {
     const CorrJob jb = jobs[jx];
@@ -464,8 +466,8 @@ __global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
 // The same sums for up to kCorrFreqs carrier frequencies that share a job's samples and code (the fine-Doppler search:
 // 17 frequencies 25 Hz apart per (PRN, segment, component) at B2a, 5 at B1C).  One frequency per job made every thread a chain
 // of dependent byte loads per frequency; here a sample and its code value are loaded once and every frequency's phasor is
-// advanced beside the others -- per frequency the operations and their order are those of k_corr_f64 (exact phasor every 16th
-// step and at the circular wrap, constant-angle rotation in between), so the sums are the same bits.
+// advanced beside the others (exact phasor every 64th step and at the circular wrap, constant-angle rotation in between; up to
+// round 4 every 16th step like k_corr_f64: the sums differ from that kernel's at the 1e-15 level and only rank frequencies).
 // out[(job * slices + slice) * kCorrFreqs + f]
 __global__ __launch_bounds__(256) void k_corr_f64_multi(SampleView sig, long n_circ, const int8_t *__restrict__ codes,
                                                         long code_stride, double inv_fs, const CorrJob *__restrict__ jobs,
@@ -477,19 +479,27 @@ __global__ __launch_bounds__(256) void k_corr_f64_multi(SampleView sig, long n_c
     const long slice = ((jb.len + gridDim.y - 1) / gridDim.y + 255) & ~255L;
     const long n_lo = (long)blockIdx.y * slice, n_hi = n_lo + slice < jb.len ? n_lo + slice : jb.len;
     double sr[FM], si[FM], wr[FM], wi[FM], cr[FM], ci[FM];
+    // the per-step rotation of each frequency is the same for every thread: FM lanes evaluate it, LDS hands it round
+    // (round 5: every thread called the f64 sincospi FM times for it -- a quarter of the kernel's 24 calls per thread)
+    __shared__ double s_wr[FM], s_wi[FM];
+    if ((int)threadIdx.x < FM) {
+        const int f = (int)threadIdx.x;
+        const double dcyc = (f < nf ? jb.fr[f] : 0.0) * ((double)blockDim.x * inv_fs);
+        sincospi(2.0 * (dcyc - floor(dcyc)), &s_wi[f], &s_wr[f]);
+    }
+    __syncthreads();
 #pragma unroll
     for (int f = 0; f < FM; ++f) {
         sr[f] = si[f] = 0.0;
         cr[f] = 1.0, ci[f] = 0.0;
-        const double dcyc = (f < nf ? jb.fr[f] : 0.0) * ((double)blockDim.x * inv_fs);
-        sincospi(2.0 * (dcyc - floor(dcyc)), &wi[f], &wr[f]);
+        wr[f] = s_wr[f], wi[f] = s_wi[f];
     }
     int it = 0;
     const long cbase = ((long)jb.slot * 2 + jb.mode) * code_stride + (jb.mode ? jb.code_k0 : 0);
     for (long n = n_lo + threadIdx.x; n < n_hi; n += blockDim.x, ++it) {
         long a = jb.start + n;
         long t = n;
-        bool resync = (it & 15) == 0;
+        bool resync = (it & 63) == 0;  // (exact phasor every 64th step: 64 rotations carry ~7e-15, and these sums only rank frequencies)
         if (jb.circ) {
             if (a >= n_circ) {
                 resync = resync || (a - (long)blockDim.x < n_circ);

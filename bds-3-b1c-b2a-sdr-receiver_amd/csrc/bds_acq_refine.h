@@ -47,8 +47,8 @@ struct RefPrn {  // per PRN of the run
 };
 
 struct RefGlobal {
-    int ncand, njobs;    // coarse refinement
-    int ncand2, njobs2;  // B2a second peak
+    int ncand, pad0;     // candidates of the coarse refinement
+    int ncand2, pad1;    // ... of the B2a second peak
     int flags;
     int n_extra, n_extra2;  // list lengths as the column pass left them (may exceed the capacity: overflow)
     int pad;
@@ -163,24 +163,14 @@ __global__ __launch_bounds__(256) void k_ref_compact(const Extra *__restrict__ e
     }
 }
 
-// the job count of the next k_corr_f64 launch (one thread)
-template <bool SECOND>
-__global__ void k_ref_count(RefParams p, RefGlobal *__restrict__ g) {
-    if (SECOND) {
-        if (g->ncand2 > p.cand_cap) atomicOr(&g->flags, kRefCandOverflow);
-        g->njobs2 = min(g->ncand2, p.cand_cap) * p.ncomp;
-    } else {
-        if (g->ncand > p.cand_cap) atomicOr(&g->flags, kRefCandOverflow);
-        g->njobs = min(g->ncand, p.cand_cap) * p.ncomp;
-    }
-}
-
 // per PRN: the maximum over its candidates' f64 values; ties: first row (bin), then first column (lag).  grid P, 256 threads.
 template <bool SECOND>
 __global__ __launch_bounds__(256) void k_ref_pick(const RefCand *__restrict__ cand, const double2 *__restrict__ jobout, int slices, RefParams p,
                                                   RefPrn *__restrict__ prn, RefGlobal *__restrict__ g) {
     const int pi = blockIdx.x, tid = threadIdx.x;
-    const int n = min(SECOND ? g->ncand2 : g->ncand, p.cand_cap);
+    const int n_all = SECOND ? g->ncand2 : g->ncand;
+    const int n = min(n_all, p.cand_cap);
+    if (pi == 0 && tid == 0 && n_all > p.cand_cap) atomicOr(&g->flags, kRefCandOverflow);  // the host path takes over
     double best = -1.0;
     int bb = 0, bl = 0, bi = -1, cnt = 0;
     auto sums = [&](int i, double2 *v) {
@@ -262,104 +252,132 @@ __global__ void k_ref_second_setup(RefParams p, RefPrn *__restrict__ prn, const 
 
 // threshold decision and the jobs of the fine-Doppler search, at fixed places: PRN pi owns jobs
 //   B1C [pi][comp][chunk], B2a [pi][segment][comp][chunk]   (chunk = up to kCorrFreqs frequencies 25 Hz apart)
-// with nf = 0 for a PRN below the threshold (k_corr_f64_multi skips those).  One thread per PRN.
-__global__ void k_ref_fine_jobs(RefParams p, RefPrn *__restrict__ prn, const int *__restrict__ prn_of, SampleView sig,
-                                const double *__restrict__ prefix_c, const double *__restrict__ prefix_cq, CorrJob *__restrict__ jobs,
-                                RefGlobal *__restrict__ g) {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pi >= p.P) return;
+// with nf = 0 for a PRN below the threshold (k_corr_f64_multi skips those).  One workgroup (64 threads) per PRN: thread 0
+// decides, the DC of the B1C block is summed by all lanes, every thread writes its share of the jobs.
+__global__ __launch_bounds__(64) void k_ref_fine_jobs(RefParams p, RefPrn *__restrict__ prn, const int *__restrict__ prn_of, SampleView sig,
+                                                      const double *__restrict__ prefix_c, const double *__restrict__ prefix_cq,
+                                                      CorrJob *__restrict__ jobs, RefGlobal *__restrict__ g) {
+    const int pi = blockIdx.x, lane = threadIdx.x;
     RefPrn &r = prn[pi];
     const bool b1c = p.signal == BDS_SIGNAL_B1C;
-    const int per = (b1c ? p.ncomp : 2 * p.fineNoncoh) * p.nchunk;
+    const int nseg = b1c ? 1 : p.fineNoncoh, ncp = b1c ? p.ncomp : 2;
+    const int per = nseg * ncp * p.nchunk;
     CorrJob *const mine = jobs + (size_t)pi * per;
-    if (b1c && r.codePhase + p.spc - 1 > p.n_samples) r.codePhase -= p.spc;  // B1C :239-241
-    const double denom = b1c ? p.sigPower : r.second;
-    const double metric = __ddiv_rn(r.best, denom);
-    r.detected = metric > p.threshold ? 1 : 0;
-    r.kbest = 0;
-    r.mean = r.mean_q = 0.0;
-    bool ok = r.detected != 0;
-    if (ok) {
-        const long blk = b1c ? p.spc : (long)p.fineNoncoh * p.spc;
-        if ((b1c && r.codePhase < 1) || r.codePhase - 1 + blk > p.n_samples) {
-            r.flags |= kRefFineRange;
-            atomicOr(&g->flags, kRefFineRange);
-            ok = false;
+    __shared__ long s_cp;
+    __shared__ int s_ok;
+    if (lane == 0) {
+        long cp = r.codePhase;
+        if (b1c && cp + p.spc - 1 > p.n_samples) cp -= p.spc;  // B1C :239-241
+        const double denom = b1c ? p.sigPower : r.second;
+        const double metric = __ddiv_rn(r.best, denom);
+        const int det = metric > p.threshold ? 1 : 0;
+        bool ok = det != 0;
+        int fl = 0;
+        if (ok) {
+            const long blk = b1c ? p.spc : (long)p.fineNoncoh * p.spc;
+            if ((b1c && cp < 1) || cp - 1 + blk > p.n_samples) fl = kRefFineRange, ok = false;
         }
+        r.codePhase = cp, r.detected = det, r.kbest = 0;
+        if (fl) {
+            r.flags |= fl;
+            atomicOr(&g->flags, fl);
+        }
+        s_cp = cp, s_ok = ok ? 1 : 0;
     }
+    __syncthreads();
+    const long cp = s_cp;
+    const bool ok = s_ok != 0;
+    double mean = 0.0, mean_q = 0.0;
     if (ok && b1c) {
         // DC of the block codePhase .. codePhase + spc - 1: exact integer sums (int8 data) from the coarse prefix table
         // (every 256th sample) and the samples between; the host path takes the same integers from its full prefix array
-        auto prefix_at = [&](long n, bool q) {
-            const double *pc = q ? prefix_cq : prefix_c;
-            double acc = pc[n >> 8];
-            for (long m = (n >> 8) << 8; m < n; ++m) {
-                const double2 x = sig.load(m);
-                acc = __dadd_rn(acc, q ? x.y : x.x);
-            }
-            return acc;
-        };
-        const long a0 = r.codePhase - 1, a1 = a0 + p.spc;
-        r.mean = __ddiv_rn(__dsub_rn(prefix_at(a1, false), prefix_at(a0, false)), (double)p.spc);
-        if (p.cplx) r.mean_q = __ddiv_rn(__dsub_rn(prefix_at(a1, true), prefix_at(a0, true)), (double)p.spc);
+        // (any order of adding them gives the same f64: they are integers below 2^53)
+        const long a0 = cp - 1, a1 = a0 + p.spc;
+        double d = 0.0, dq = 0.0;  // prefix(a1) - prefix(a0), this lane's share of the samples in between
+        for (long m = ((a1 >> 8) << 8) + lane; m < a1; m += 64) {
+            const double2 x = sig.load(m);
+            d += x.x, dq += x.y;
+        }
+        for (long m = ((a0 >> 8) << 8) + lane; m < a0; m += 64) {
+            const double2 x = sig.load(m);
+            d -= x.x, dq -= x.y;
+        }
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o), dq += __shfl_xor(dq, o);
+        d += prefix_c[a1 >> 8] - prefix_c[a0 >> 8];
+        mean = __ddiv_rn(d, (double)p.spc);
+        if (p.cplx) {
+            dq += prefix_cq[a1 >> 8] - prefix_cq[a0 >> 8];
+            mean_q = __ddiv_rn(dq, (double)p.spc);
+        }
     }
+    if (lane == 0) r.mean = mean, r.mean_q = mean_q;
     const double fb = ref_bin_freq(p, r.b);
     const double f_lo = b1c ? __dsub_rn(fb, p.step) : __dsub_rn(fb, __ddiv_rn(p.step, 2.0));  // B1C :282-283, B2a :300-301
-    const int nseg = b1c ? 1 : p.fineNoncoh, ncp = b1c ? p.ncomp : 2;
-    for (int seg = 0; seg < nseg; ++seg)
-        for (int comp = 0; comp < ncp; ++comp)
-            for (int ch = 0; ch < p.nchunk; ++ch) {
-                CorrJob j{};
-                j.start = r.codePhase - 1 + (long)seg * p.spc;
-                j.len = p.spc;
-                j.code_k0 = b1c ? 0 : (long)seg * p.spc;
-                j.mean = r.mean;
-                j.mean_q = r.mean_q;
-                j.slot = (prn_of[pi] - 1) * 2 + comp;
-                j.circ = 0;
-                j.mode = b1c ? 0 : 1;
-                const int k0 = ch * kCorrFreqs;
-                j.nf = ok ? min(kCorrFreqs, p.nfine - k0) : 0;
-                for (int f = 0; f < kCorrFreqs; ++f) j.fr[f] = f < j.nf ? __dadd_rn(f_lo, __dmul_rn(25.0, (double)(k0 + f))) : 0.0;
-                j.freq = j.fr[0];
-                mine[((size_t)seg * ncp + comp) * p.nchunk + ch] = j;
-            }
+    for (int i = lane; i < per; i += 64) {
+        const int ch = i % p.nchunk, comp = (i / p.nchunk) % ncp, seg = i / (p.nchunk * ncp);
+        CorrJob j{};
+        j.start = cp - 1 + (long)seg * p.spc;
+        j.len = p.spc;
+        j.code_k0 = b1c ? 0 : (long)seg * p.spc;
+        j.mean = mean;
+        j.mean_q = mean_q;
+        j.slot = (prn_of[pi] - 1) * 2 + comp;
+        j.circ = 0;
+        j.mode = b1c ? 0 : 1;
+        const int k0 = ch * kCorrFreqs;
+        j.nf = ok ? min(kCorrFreqs, p.nfine - k0) : 0;
+        for (int f = 0; f < kCorrFreqs; ++f) j.fr[f] = f < j.nf ? __dadd_rn(f_lo, __dmul_rn(25.0, (double)(k0 + f))) : 0.0;
+        j.freq = j.fr[0];
+        mine[i] = j;
+    }
 }
 
 // per detected PRN: the fine frequency with the largest (non-coherent) sum; the first one on ties (B1C :289-296, B2a :318-325).
-// One thread per PRN (at most 17 frequencies x 15 segments x 2 components x 8 slices of additions).
-__global__ void k_ref_fine_pick(RefParams p, RefPrn *__restrict__ prn, const double2 *__restrict__ jobout, int slices) {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pi >= p.P) return;
+// One workgroup (256 threads) per PRN: the magnitudes of all (segment, component, frequency) sums in parallel, then one
+// thread per frequency adds its segments in order, then the first maximum.
+__global__ __launch_bounds__(256) void k_ref_fine_pick(RefParams p, RefPrn *__restrict__ prn, const double2 *__restrict__ jobout, int slices) {
+    const int pi = blockIdx.x, tid = threadIdx.x;
     RefPrn &r = prn[pi];
-    if (!r.detected || (r.flags & kRefFineRange)) return;
+    if (!r.detected || (r.flags & kRefFineRange)) return;  // (workgroup-uniform)
     const bool b1c = p.signal == BDS_SIGNAL_B1C;
     const int nseg = b1c ? 1 : p.fineNoncoh, ncp = b1c ? p.ncomp : 2;
     const size_t job0 = (size_t)pi * nseg * ncp * p.nchunk;
-    auto at = [&](int seg, int comp, int kf) {
+    extern __shared__ double s_mag[];  // [seg][comp][kf]
+    double *const s_val = s_mag + nseg * ncp * p.nfine;  // [kf]
+    const int total = nseg * ncp * p.nfine;
+    for (int i = tid; i < total; i += 256) {
+        const int kf = i % p.nfine, comp = (i / p.nfine) % ncp, seg = i / (p.nfine * ncp);
         const size_t j = job0 + ((size_t)seg * ncp + comp) * p.nchunk + kf / kCorrFreqs;
         double2 acc = make_double2(0.0, 0.0);
         for (int k = 0; k < slices; ++k) {
             const double2 t = jobout[(j * slices + k) * kCorrFreqs + kf % kCorrFreqs];
             acc.x = __dadd_rn(acc.x, t.x), acc.y = __dadd_rn(acc.y, t.y);
         }
-        return ref_cabs(acc);
-    };
-    double best = -1.0;
-    int kbest = 0;
-    for (int kf = 0; kf < p.nfine; ++kf) {
+        s_mag[i] = ref_cabs(acc);
+    }
+    __syncthreads();
+    if (tid < p.nfine) {
+        const int kf = tid;
         double v;
         if (b1c) {
-            v = at(0, 0, kf);
-            if (p.ncomp == 2) v = __ddiv_rn(__dadd_rn(__dmul_rn(v, 11.0), __dmul_rn(at(0, 1, kf), 29.0)), 40.0);  // :291-292
+            v = s_mag[kf];
+            if (p.ncomp == 2) v = __ddiv_rn(__dadd_rn(__dmul_rn(v, 11.0), __dmul_rn(s_mag[p.nfine + kf], 29.0)), 40.0);  // :291-292
         } else {
             double sd = 0.0, sp = 0.0;
-            for (int seg = 0; seg < nseg; ++seg) sd = __dadd_rn(sd, at(seg, 0, kf)), sp = __dadd_rn(sp, at(seg, 1, kf));
+            for (int seg = 0; seg < nseg; ++seg)
+                sd = __dadd_rn(sd, s_mag[(seg * 2 + 0) * p.nfine + kf]), sp = __dadd_rn(sp, s_mag[(seg * 2 + 1) * p.nfine + kf]);
             v = __dadd_rn(sd, sp);  // :321
         }
-        if (v > best) best = v, kbest = kf;
+        s_val[kf] = v;
     }
-    r.kbest = kbest;
+    __syncthreads();
+    if (tid == 0) {
+        double best = -1.0;
+        int kbest = 0;
+        for (int kf = 0; kf < p.nfine; ++kf)
+            if (s_val[kf] > best) best = s_val[kf], kbest = kf;
+        r.kbest = kbest;
+    }
 }
 
 }  // namespace bds

@@ -214,8 +214,17 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
             }
 #endif
             if constexpr (ILV) {
+#ifdef BDS_COLS_DMA
+                // experiment: the tile rows by LDS DMA -- buffer_load_dwordx4 ... lds, lane i's 16 bytes at
+                // [q][i] of the wave's own region (free until phase A writes: one tile per workgroup) -- read back below
+                typedef __attribute__((address_space(3))) void *lds_vp;
+                const unsigned off = __builtin_amdgcn_readfirstlane(lds_offset(reinterpret_cast<C *>(ldsf) + wave * RS) + q * 1024u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vp)(uintptr_t)off, 16, voff, q * rowstep, 0, BDS_COLS_AUX);
+                pre[q] = make_uint4(0, 0, 0, 0);
+#else
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, q * rowstep, BDS_COLS_AUX);
                 pre[q] = make_uint4(v[0], v[1], v[2], v[3]);  // (column 2 cp: data, pilot; column 2 cp + 1: data, pilot)
+#endif
             } else if constexpr (HS) {
                 const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, q * rowstep, BDS_COLS_AUX);
                 pre[q] = make_uint2(v[0], v[1]);
@@ -324,6 +333,15 @@ __global__ __launch_bounds__(WCols<S>::NT, WCols<S>::kOcc) void k_cols_wave_f(WC
     unsigned cur = 0;
     PH_MARK(15);  // set-up: kernel arguments, item, loads issued
     PH_WAIT_VM();
+#ifdef BDS_COLS_DMA
+    if constexpr (ILV) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint4 *stage = reinterpret_cast<const uint4 *>(reinterpret_cast<C *>(ldsf) + wave * RS) + lane;
+#pragma unroll
+        for (int q = 0; q < R1; ++q) pre0[q] = stage[64 * q];
+        __syncthreads();  // every wave has its rows in registers before phase A writes into the regions
+    }
+#endif
     PH_MARK(0);  // rows of both components + per-lane constants have arrived
 #pragma unroll
     for (int comp = 0; comp < NCOMP; ++comp) {

@@ -28,7 +28,7 @@ int fail(bds_ctx *ctx, int code, const char *fmt, ...) {
 
 // Environment knobs.  The RELEASE library reads four documented ones (include/bds_mi355x.h lists them):
 //   BDS_ACQ_FP16=0      fp32 storage of the spectra and the inter-pass buffer as well (default: fp16 storage, f64 decisions)
-//   BDS_TRK_PREC=0..4   numerics of the tracking correlator (default 4 = strict; 0 = fp32 carrier, 2.4x faster wide-band)
+//   BDS_TRK_PREC=0..5   numerics of the tracking correlator (default 5 = strict; 0 = fp32 carrier, 1.5x faster wide-band)
 //   BDS_VERBOSE         progress / fallback messages on stderr
 //   BDS_ACQ_CLOCKPROBE  sampled workgroups time themselves with the shader clock (bds_timing::shader_clock_GHz)
 // Everything else -- kernel selection, launch shapes, plan overrides, the sieve tolerance, the switches that turn the
@@ -42,7 +42,7 @@ Tuning tuning_from_env() {
     };
     auto has = [](const char *name) { return std::getenv(name) != nullptr; };
     t.fp16_storage = geti("BDS_ACQ_FP16", -1);
-    t.trk_prec = geti("BDS_TRK_PREC", 4);
+    t.trk_prec = geti("BDS_TRK_PREC", 5);
     t.verbose = has("BDS_VERBOSE");
     t.clockprobe = geti("BDS_ACQ_CLOCKPROBE", 0);
 #ifdef BDS_TEST_HOOKS

@@ -1,4 +1,4 @@
-// Strict carrier arithmetic of the tracking correlator (TrkParams::prec 4): plain C++ that compiles for the device
+// Strict carrier arithmetic of the tracking correlator (TrkParams::prec 4 and 5): plain C++ that compiles for the device
 // (bds_track.hip) and for the host (tests/test_strict_math.py builds this very header with g++ and checks it
 // exhaustively / against libm).  Built with -ffp-contract=off: every operation below rounds once, as written.
 #pragma once
@@ -10,7 +10,7 @@
 #endif
 
 namespace bds {
-// ---- the strict carrier (PREC 4, default): sin / cos of the reference's own trigarg(k), without the library calls of PREC 3.
+// ---- the strict carrier (PREC 4; PREC 5, the default, needs it once per lane and pass): sin / cos of the reference's own trigarg(k), without the library calls of PREC 3.
 // k / fs correctly rounded from the correctly rounded reciprocal (Markstein: q0 = RN(k y), r = k - q0 fs exactly by FMA,
 // q = RN(q0 + r y) = RN(k / fs) when y = RN(1 / fs) and q0 is within an ulp; checked exhaustively on the host for the
 // sample counts and rates of the tests, tests/test_abi_and_host.py, and by BDS_DASSERT in the debug build)

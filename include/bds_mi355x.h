@@ -156,9 +156,10 @@ BDS_API void bds_destroy(bds_ctx *ctx);
 /* Environment knobs, read once at bds_create into the context.  The release library reads exactly these:
  *   BDS_ACQ_FP16=0       fp32 storage of the spectra and the inter-pass buffer as well (default: fp16 storage; every reported
  *                        value is decided in f64 either way)
- *   BDS_TRK_PREC=0..4    numerics of the tracking correlator: 4 (default) the reference's own carrier argument per sample in
- *                        f64 -- SURVEY.md 8d tolerances over the whole horizon; 0 fp32 carrier recurrence, ~2.4x faster in
- *                        wide-band mode, 8d tolerances until the first ceil() flip (a few hundred epochs)
+ *   BDS_TRK_PREC=0..5    numerics of the tracking correlator: 5 (default) the reference's own carrier argument per sample in
+ *                        f64 -- SURVEY.md 8d tolerances over the whole horizon (4: the same with a sin / cos per sample);
+ *                        0 fp32 carrier recurrence, ~1.5x faster in wide-band mode, 8d tolerances until the first ceil()
+ *                        flip (a few hundred epochs)
  *   BDS_VERBOSE          progress / fallback messages on stderr
  *   BDS_ACQ_CLOCKPROBE=1 sampled workgroups time themselves with the shader clock (bds_timing.shader_clock_GHz)
  * (plus BDS_MEX_DEVICES in the MEX gateway and BDS_LIB_PATH in the ctypes host).  Kernel-selection, launch-shape and sieve

@@ -1,4 +1,4 @@
-"""csrc/bds_strict_math.h -- the strict carrier of the tracking correlator (TrkParams::prec 4: the reference's own
+"""csrc/bds_strict_math.h -- the strict carrier of the tracking correlator (TrkParams::prec 4 and 5: the reference's own
 trigarg(k) = (carrFreq*2*pi) .* (k ./ fs) + remCarrPhase per sample, tracking.m:303-304, then sin / cos) -- compiled for the
 HOST from the very header the device kernel includes and checked on the CPU: the reciprocal-based division equals IEEE
 division for every sample index below 2^22 at twelve sampling rates, and the branch-free sin / cos stays within an ulp of

@@ -23,17 +23,15 @@ sys.path.insert(0, ROOT)
 
 
 def sysfs_sources():
-    pw, fq = None, None
-    for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
-        for n in ("power1_average", "power1_input"):
-            if os.path.exists(os.path.join(hw, n)):
-                pw = os.path.join(hw, n)
-                break
-        if os.path.exists(os.path.join(hw, "freq1_input")):
-            fq = os.path.join(hw, "freq1_input")
+    """(power file, clock file) of every card the container shows -- a pool box exposes the sensors of all eight GPUs of its
+    host while the process sees one of them: all are sampled, the card that draws the most power under the load is ours."""
+    out = []
+    for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        pw = next((os.path.join(hw, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, n))), None)
+        fq = os.path.join(hw, "freq1_input") if os.path.exists(os.path.join(hw, "freq1_input")) else None
         if pw:
-            break
-    return pw, fq
+            out.append((pw, fq))
+    return out
 
 
 def smi_sample():
@@ -84,23 +82,23 @@ def main():
     ctx.acq_load(s, x)
     ctx.acq_prepare(s)
     ctx.acq_run(s)
-    pw, fq = sysfs_sources()
+    cards = sysfs_sources()
     samples, stop = [], threading.Event()
+
+    def rd(path, scale):
+        try:
+            return float(open(path).read()) * scale
+        except Exception:  # noqa: BLE001
+            return None
 
     def sampler():
         while not stop.is_set():
             t = time.perf_counter()
-            if pw:
-                try:
-                    p = float(open(pw).read()) * 1e-6
-                    f = float(open(fq).read()) * 1e-6 if fq else None
-                except Exception:  # noqa: BLE001
-                    p, f = None, None
-                samples.append((t, p, f))
+            if cards:
+                samples.append((t, [(rd(pw, 1e-6), rd(fq, 1e-6) if fq else None) for pw, fq in cards]))
                 time.sleep(0.05)
             else:
-                p, f = smi_sample()
-                samples.append((t, p, f))
+                samples.append((t, [smi_sample()]))
 
     th = threading.Thread(target=sampler, daemon=True)
     t0 = time.perf_counter()
@@ -115,17 +113,22 @@ def main():
     stop.set()
     th.join(timeout=10)
     ctx.close()
-    # samples of the loaded interval only, the first second dropped (ramp)
-    ld = [(p, f) for t, p, f in samples if t0 + 1.0 <= t <= t1 and p is not None]
+    # samples of the loaded interval only, the first second dropped (ramp); the card with the highest mean power is the one under load
+    rows = [v for t, v in samples if t0 + 1.0 <= t <= t1]
+    ncard = len(rows[0]) if rows else 0
+    mean_p = [sum((r[c][0] or 0.0) for r in rows) / max(1, len(rows)) for c in range(ncard)]
+    mine = max(range(ncard), key=lambda c: mean_p[c]) if ncard else 0
+    ld = [r[mine] for r in rows if r[mine][0] is not None]
     ps = sorted(p for p, _ in ld)
     fs = sorted(f for _, f in ld if f is not None)
+    pw = cards[mine][0] if cards else None
     med = lambda v: v[len(v) // 2] if v else None  # noqa: E731
     print(json.dumps({"label": args.label, "seconds": t1 - t0, "calls": calls, "ms_per_call": (t1 - t0) / calls * 1e3,
                       "pair_ms_mean": sum(pair) / len(pair), "pair_ms_first_last": [pair[0], pair[-1]],
                       "samples_under_load": len(ld), "sample_rate_Hz": len(ld) / max(1e-9, t1 - t0 - 1.0),
                       "power_W": {"min": ps[0] if ps else None, "median": med(ps), "max": ps[-1] if ps else None},
                       "sclk_MHz": {"min": fs[0] if fs else None, "median": med(fs), "max": fs[-1] if fs else None},
-                      "source": "sysfs %s" % pw if pw else "rocm-smi --json", "env": args.env, "notes": notes}))
+                      "source": ("sysfs %s (the hottest of %d cards visible; mean W per card: %s)" % (pw, ncard, [round(v) for v in mean_p])) if pw else "rocm-smi --json", "env": args.env, "notes": notes}))
 
 
 if __name__ == "__main__":
