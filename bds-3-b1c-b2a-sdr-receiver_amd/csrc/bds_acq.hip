@@ -39,294 +39,7 @@ namespace bds {
 
 static const double kPi = 3.14159265358979323846;
 
-// ---------------------------------------------------------------------------------------
-struct Plan2D {
-    long L = 0;
-    int L1 = 0, L2 = 0;
-    Plan1D p1{}, p2{};  // p1: columns (length L1), p2: rows (length L2)
-    TwiddleL twl{};
-    int logT = 0, Spad = 0, nt_cols = 0, nt_rows = 0, ntiles = 0;
-    size_t lds_cols = 0, lds_rows = 0;
-    bool fast = false;  // both lengths have compile-time specialised search kernels (bds_acq_fast.h)
-    bool small = false; // 80 x 4096: wave-private row pass + one-lane-per-column pass (bds_acq_scols.h); fp16 storage, two components
-    float2 *d_tw80 = nullptr;  // w80^k of that column pass
-    float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_hi = nullptr, *d_lo = nullptr;
-    float2 *d_ftab1 = nullptr, *d_ftab2 = nullptr;  // fp32 stage-twiddle tables of the inverse column / row transform
-    float2 *d_wtab = nullptr;                       // per-lane twiddle table of the wave-private column pass (bds_acq_wcols.h)
-    float2 *d_wrtab = nullptr;                      // ... of the wave-private 4096-point row pass (bds_acq_wrows.h)
-    unsigned long long *d_clk = nullptr;            // clock probe sums (BDS_ACQ_CLOCKPROBE): rows {shader, reference}, columns {shader, reference}
-};
-
-static bool is_5smooth(long v) {
-    for (int p : {2, 3, 5})
-        while (v % p == 0) v /= p;
-    return v == 1;
-}
-
-static void factor_radices(int S, Plan1D &p) {
-    // few, large stages: 16s, then one 8/4/2 for the remaining power of two, then 5s and 3s.
-    // The largest radix goes first: the first autosort stage (Ns = 1) needs no twiddles.
-    int v = S, n = 0;
-    int rad[kMaxStages];
-    while (v % 16 == 0) rad[n++] = 16, v /= 16;
-    if (v % 8 == 0) rad[n++] = 8, v /= 8;
-    if (v % 4 == 0) rad[n++] = 4, v /= 4;
-    if (v % 2 == 0) rad[n++] = 2, v /= 2;
-    while (v % 5 == 0) rad[n++] = 5, v /= 5;
-    while (v % 3 == 0) rad[n++] = 3, v /= 3;
-    std::sort(rad, rad + n, [](int a, int b) { return a > b; });
-    p.S = S;
-    p.nstage = n;
-    int ns = 1;
-    for (int i = 0; i < n; ++i) {
-        p.radix[i] = rad[i];
-        p.nb[i] = FastDiv((uint32_t)(S / rad[i]));
-        p.ns[i] = FastDiv((uint32_t)ns);
-        p.tws[i] = S / (ns * rad[i]);
-        ns *= rad[i];
-    }
-}
-
-static constexpr int kMaxColLen = 1280;   // column-pass transform length limit (LDS: T*L1*8 B)
-static constexpr int kMaxRowLen = 8192;   // row-pass transform length limit
-static constexpr int kColPoints = 8192;   // T*L1 budget (<= 72 KiB of LDS: two workgroups per CU)
-
-// Relative cost of one length-S LDS transform per point: every stage is an LDS round trip
-// (dominant) plus radix-dependent arithmetic.
-static double plan_cost(int S) {
-    Plan1D p{};
-    factor_radices(S, p);
-    if (p.nstage > kMaxStages) return 1e30;
-    double c = 0;
-    for (int i = 0; i < p.nstage; ++i) {
-        switch (p.radix[i]) {
-            case 2: c += 1.0; break;
-            case 3: c += 1.1; break;
-            case 4: c += 1.1; break;
-            case 5: c += 1.3; break;
-            case 8: c += 1.3; break;
-            default: c += 1.6; break;
-        }
-    }
-    return c;
-}
-
-static bool fast_cols(int a) { return a == 256 || a == 512 || a == 768 || a == 1024; }
-static bool fast_rows(int b) { return b == 1280 || b == 2048 || b == 3072 || b == 4096; }
-
-// Padded length L >= need (5-smooth) and its split L1 x L2, chosen by a cost model:
-// L * (stage costs of both passes + a memory term) -- a slightly longer transform made of
-// radix-16 stages beats the tightest 5-smooth length made of 3s and 5s.
-// small_ok: the 80 x 4096 plan may be chosen (small_plan_ok(): two components, fp16 storage, the specialised kernels on, and
-// every searched lag inside the output rows k_cols_small_f forms)
-static bool choose_lengths(const Tuning &tune, long need, long &L, int &L1, int &L2, bool small_ok) {
-    const double kMem = 3.0;  // HBM/L2 traffic of the two passes, in units of one LDS stage
-    double best = 1e30;
-    const long lo = std::max<long>(need, 64), hi = lo + lo / 2 + 64;
-    if (tune.force_l1 > 0) {  // BDS_ACQ_FORCE_L1L2 (tuning / tests)
-        const int a = tune.force_l1, b = tune.force_l2;
-        if ((long)a * b >= need && is_5smooth(a) && is_5smooth(b) && a <= kMaxColLen && b <= kMaxRowLen) {
-            L = (long)a * b;
-            L1 = a;
-            L2 = b;
-            return true;
-        }
-    }
-    for (long cand = lo; cand <= hi; ++cand) {
-        if (!is_5smooth(cand)) continue;
-        for (int a = 4; a <= kMaxColLen; ++a) {
-            if (cand % a) continue;
-            const long b = cand / a;
-            if (b > kMaxRowLen || b < a / 4) continue;
-            double c = (double)cand * (plan_cost(a) + plan_cost((int)b) + kMem);
-            if (fast_cols(a) && fast_rows((int)b)) c *= 0.6;  // specialised kernels exist
-            // 80 x 4096 (round 4): 4096-point rows on the wave-private row pass, 80-point columns one lane each -- measured
-            // against 256 x 1280 at cfg2: see DESIGN.md 1.6
-            if (small_ok && a == kSColsLen && b == 4096) c *= 0.4;
-            if (c < best) best = c, L = cand, L1 = a, L2 = (int)b;
-        }
-    }
-    return best < 1e29;
-}
-
-// threads a workgroup needs for T transforms of plan p: every stage must fit
-// (S/R)*T butterflies into floor(16/R) per thread, and loaders hold <= 16 points per thread
-static int threads_for(const Plan1D &p, int T) {
-    long need = ((long)p.S * T + kPointsPerThread - 1) / kPointsPerThread;
-    for (int i = 0; i < p.nstage; ++i) {
-        const int R = p.radix[i], mb = kPointsPerThread / R;
-        need = std::max<long>(need, ((long)(p.S / R) * T + mb - 1) / mb);
-    }
-    need = ((need + 63) / 64) * 64;
-    return (int)std::max<long>(64, need);
-}
-
-static void plan_free(Plan2D &pl) {
-    for (float2 **p : {&pl.d_tw1, &pl.d_tw2, &pl.d_hi, &pl.d_lo, &pl.d_ftab1, &pl.d_ftab2, &pl.d_wtab, &pl.d_wrtab, &pl.d_tw80})
-        if (*p) (void)hipFree(*p), *p = nullptr;
-    if (pl.d_clk) (void)hipFree(pl.d_clk), pl.d_clk = nullptr;
-}
-
-// fp32 stage tables of an inverse transform (bds_fft_t.h tstage TAB): per stage after the first [q][k], entries
-// exp(+2 pi j q k / (NS R))
-static int upload_stage_tables_f32(bds_ctx *ctx, const Plan1D &p, float2 **dptr) {
-    std::vector<float2> h;
-    int ns = 1;
-    for (int s = 0; s < p.nstage; ++s) {
-        const int R = p.radix[s];
-        if (ns > 1)
-            for (int q = 0; q < R; ++q)
-                for (int k = 0; k < ns; ++k) {
-                    const double a = 2.0 * kPi * (double)((long)q * k) / (double)((long)ns * R);
-                    h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
-                }
-        ns *= R;
-    }
-    if (h.empty()) h.push_back(make_float2(1.f, 0.f));
-    BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * h.size()));
-    BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
-    return BDS_OK;
-}
-
-// per-lane twiddle table of the wave-private column pass (layout: wcols_table_entries<S>() in bds_acq_wcols.h), inverse
-// direction, rounded from f64: [p - 1][thread] = w_S^(b p) with b = 16 (thread / 64) + (thread % 64) / 4, then
-// [j - 1][lane] = w_64^(u j) with u = lane / 8 (stage 3 applies the stage-2 twiddle to its inputs, input j being bl = j)
-static int upload_wcols_table(bds_ctx *ctx, int S, float2 **dptr) {
-    const int R1 = S / 64;
-    std::vector<float2> h;
-    for (int p = 1; p < R1; ++p)
-        for (int t = 0; t < 256; ++t) {
-            const int b = 16 * (t >> 6) + ((t & 63) >> 2);
-            const double a = 2.0 * kPi * (double)((b * p) % S) / (double)S;
-            h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
-        }
-    for (int j = 1; j < 8; ++j)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int u = lane >> 3;
-            const double a = 2.0 * kPi * (double)((u * j) % 64) / 64.0;
-            h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
-        }
-    BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * h.size()));
-    BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
-    return BDS_OK;
-}
-
-// per-lane twiddle table of the wave-private 4096-point row pass (layout: bds_acq_wrows.h), inverse direction, rounded from f64
-static int upload_wrows_table(bds_ctx *ctx, float2 **dptr) {
-    std::vector<float2> h;
-    for (int p = 1; p < 16; ++p)
-        for (int b = 0; b < 256; ++b) {
-            const double a = 2.0 * kPi * (double)((b * p) % 4096) / 4096.0;
-            h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
-        }
-    for (int j = 1; j < 16; ++j)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int u = lane >> 2, bl = (j + u) & 15;
-            const double a = 2.0 * kPi * (double)(((u * (bl - u)) % 256 + 256) % 256) / 256.0;
-            h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
-        }
-    for (int k = 0; k < 16; ++k) {
-        const double a = 2.0 * kPi * (double)k / 16.0;
-        h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
-    }
-    for (int u = 0; u < 16; ++u) {
-        const double a = 2.0 * kPi * (double)((u * u) % 256) / 256.0;
-        h.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
-    }
-    BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * h.size()));
-    BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
-    return BDS_OK;
-}
-
-static int upload_twiddles(bds_ctx *ctx, int n, long denom, long step, float2 **dptr) {
-    // table[i] = exp(-2 pi j * (i*step) / denom), computed in f64
-    std::vector<float2> h((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        const long m = ((long)i * step) % denom;
-        const double a = -2.0 * kPi * (double)m / (double)denom;
-        h[i] = make_float2((float)std::cos(a), (float)std::sin(a));
-    }
-    BDS_HIP(ctx, hipMalloc((void **)dptr, sizeof(float2) * (size_t)n));
-    BDS_HIP(ctx, hipMemcpy(*dptr, h.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
-    return BDS_OK;
-}
-
-// The register column pass of the 80 x 4096 plan forms output rows 0 .. kSColsOut - 1 only (bds_acq_scols.h): the plan is
-// eligible -- and gets its cost bonus in choose_lengths -- only when the largest searched lag N - 1 lies in those rows and
-// the kernels that need it will really run (the same predicate sets pl.small).  cfg2: N = 198 750 -> row 48.  B2a at
-// 102 MS/s (N = 204 000 -> row 49) or B1C with pilot at 25 MS/s, cohT 1 (N = 275 000 -> row 67) stay on 256 x 1280.
-static bool small_plan_ok(const Tuning &tune, long n_lags, bool allow_small) {
-    return allow_small && !tune.generic && n_lags >= 1 && (n_lags - 1) / 4096 < kSColsOut;
-}
-
-static int plan_build(bds_ctx *ctx, Plan2D &pl, long need, long n_lags, bool allow_small) {
-    plan_free(pl);
-    const Tuning &tune = ctx->tune;
-    pl.small = false;
-    const bool small_ok = small_plan_ok(tune, n_lags, allow_small);
-    if (!choose_lengths(tune, need, pl.L, pl.L1, pl.L2, small_ok))
-        return fail(ctx, BDS_ERR_UNSUPPORTED, "no two-pass transform plan for length >= %ld", need);
-    factor_radices(pl.L1, pl.p1);
-    factor_radices(pl.L2, pl.p2);
-    int logT = 5;
-    while (logT > 0 && ((long)pl.L1 << logT) > kColPoints) --logT;
-    while (logT > 0 && (1 << logT) > pl.L2) --logT;
-    if (tune.logt >= 0) logT = std::max(0, std::min(logT, tune.logt));  // tuning
-    const bool want_fast = fast_cols(pl.L1) && fast_rows(pl.L2) && !tune.generic;
-    if (want_fast) {  // the specialised column kernels are built for T = 8 (default; fp16-arithmetic ones also T = 4)
-        // 8 columns per workgroup: a tile row is 32 bytes, shared by two lanes (cfg3 search 201.6 -> 196.0 ms,
-        // cfg2 3.09 -> 2.64 ms against T = 4, with 768 x 8 on 512 threads; on 384 threads it was 241 ms)
-        logT = tune.logt == 2 ? 2 : 3;
-    }
-    pl.logT = logT;
-    pl.Spad = lds_span(pl.L1) + 4;  // +4: successive columns start 8 dwords apart in the bank row
-    pl.ntiles = (pl.L2 + (1 << logT) - 1) >> logT;
-    pl.nt_cols = threads_for(pl.p1, 1 << logT);
-    pl.nt_rows = threads_for(pl.p2, 1);
-    if (pl.nt_cols > 1024 || pl.nt_rows > 1024)
-        return fail(ctx, BDS_ERR_UNSUPPORTED, "transform %d x %d exceeds the per-workgroup budget", pl.L1, pl.L2);
-    pl.lds_cols = sizeof(float2) * (size_t)pl.Spad * (size_t)(1 << logT);
-    pl.lds_rows = sizeof(float2) * (size_t)lds_span(pl.L2);
-    pl.fast = want_fast;
-    pl.small = small_ok && pl.L1 == kSColsLen && pl.L2 == 4096;
-    if (tune.verbose) {
-        fprintf(stderr, "[bds] search kernels: %s\n", pl.fast ? "specialised" : "generic");
-        fprintf(stderr, "[bds] plan: need %ld -> L %ld = %d (cols:", need, pl.L, pl.L1);
-        for (int i = 0; i < pl.p1.nstage; ++i) fprintf(stderr, " %d", pl.p1.radix[i]);
-        fprintf(stderr, "; T=%d, %d thr, %zu B LDS) x %d (rows:", 1 << logT, pl.nt_cols, pl.lds_cols, pl.L2);
-        for (int i = 0; i < pl.p2.nstage; ++i) fprintf(stderr, " %d", pl.p2.radix[i]);
-        fprintf(stderr, "; %d thr, %zu B LDS)\n", pl.nt_rows, pl.lds_rows);
-    }
-    int rc;
-    if ((rc = upload_twiddles(ctx, pl.L1, pl.L1, 1, &pl.d_tw1))) return rc;
-    if ((rc = upload_twiddles(ctx, pl.L2, pl.L2, 1, &pl.d_tw2))) return rc;
-    const int nhi = (int)((pl.L + (1L << kTwLoBits) - 1) >> kTwLoBits);
-    if ((rc = upload_twiddles(ctx, nhi, pl.L, 1L << kTwLoBits, &pl.d_hi))) return rc;
-    if ((rc = upload_twiddles(ctx, 1 << kTwLoBits, pl.L, 1, &pl.d_lo))) return rc;
-    if (pl.fast) {
-        if ((rc = upload_stage_tables_f32(ctx, pl.p1, &pl.d_ftab1))) return rc;
-        if ((rc = upload_stage_tables_f32(ctx, pl.p2, &pl.d_ftab2))) return rc;
-        if ((rc = upload_wcols_table(ctx, pl.L1, &pl.d_wtab))) return rc;
-        if (pl.L2 == 4096 && (rc = upload_wrows_table(ctx, &pl.d_wrtab))) return rc;
-        BDS_HIP(ctx, hipMalloc((void **)&pl.d_clk, 4 * sizeof(unsigned long long)));
-        BDS_HIP(ctx, hipMemset(pl.d_clk, 0, 4 * sizeof(unsigned long long)));
-    }
-    if (pl.small) {
-        if ((rc = upload_wrows_table(ctx, &pl.d_wrtab))) return rc;
-        std::vector<float2> h(kSColsLen);
-        for (int k = 0; k < kSColsLen; ++k) {
-            const double ang = 2.0 * kPi * (double)k / (double)kSColsLen;
-            h[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-        }
-        BDS_HIP(ctx, hipMalloc((void **)&pl.d_tw80, sizeof(float2) * h.size()));
-        BDS_HIP(ctx, hipMemcpy(pl.d_tw80, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
-    }
-    pl.p1.tw = pl.d_tw1;
-    pl.p2.tw = pl.d_tw2;
-    pl.twl.hi = pl.d_hi;
-    pl.twl.lo = pl.d_lo;
-    return BDS_OK;
-}
+#include "bds_acq_plan.h"  // Plan2D, choose_lengths, plan_build, the kernels' constant tables
 
 // ---------------------------------------------------------------------------------------
 struct PrnResult {
@@ -354,10 +67,25 @@ struct AcqState {
     int skind = kS8;                // what the search reads: SampleKind
     long n_samples = 0;             // samples of the block the search sees (after resampling, if any)
     ResamplePlan rs;                // resampling branch of the loaded block
-    std::vector<double> h_re, h_im;       // host copy of that block (exact for int8 data)
-    std::vector<double> h_prefix;         // prefix sums (DC means; integers below 2^53 for int8 data)
+    // Host view of that block.  An int8 record is kept as the bytes it came in (interleaved I/Q for a complex one) with its
+    // prefix sums at every 256th sample (round 5: the f64 copies and full-length prefix arrays of rounds 1-4 were 320 MB of host
+    // writes per bds_acq_load at cfg3, 79 of the 291 ms of a cold call); the f64 block of the resampling branch keeps full arrays.
+    std::vector<int8_t> h_s8;
+    std::vector<double> h_cpre, h_cpre_q; // prefix sums of I (and Q) at samples 0, 256, 512, ... (exact integers below 2^53)
+    std::vector<double> h_re, h_im;       // resampling branch only: the conditioned block
+    std::vector<double> h_prefix;         // ... its prefix sums
     std::vector<double> h_prefix_q;       // ... of the imaginary part
     bool cplx = false;              // longSignal = I + 1i*Q (postProcessing.m:92-96)
+    double sample_re(long i) const { return skind >= kF64 ? h_re[(size_t)i] : (double)h_s8[(size_t)(cplx ? 2 * i : i)]; }
+    double sample_im(long i) const { return !cplx ? 0.0 : skind >= kF64 ? h_im[(size_t)i] : (double)h_s8[(size_t)(2 * i + 1)]; }
+    // sum of the first i samples (I part / Q part): for an int8 record the same integer, hence the same f64, in any order of adding
+    double prefix(long i, int q = 0) const {
+        if (skind >= kF64) return q ? h_prefix_q[(size_t)i] : h_prefix[(size_t)i];
+        long acc = 0;
+        const int8_t *b = h_s8.data();
+        for (long m = (i >> 8) << 8; m < i; ++m) acc += cplx ? b[2 * m + q] : b[m];
+        return (q ? h_cpre_q : h_cpre)[(size_t)(i >> 8)] + (double)acc;
+    }
     SampleView sview() const { return SampleView{skind >= kF64 ? (const void *)d_sig64 : (const void *)d_sig, skind, n_samples}; }
     int8_t *d_prim = nullptr;       // [63][2][code_len]
     float2 *d_Cs = nullptr;         // [slots][ncomp][L]
@@ -884,11 +612,21 @@ static int condition_block(bds_ctx *ctx, AcqState &a, const ResamplePlan &r, lon
 // storage scales); keyed by the sizes they were computed for, so a run whose settings changed N re-derives them
 static void ext_sums(AcqState &a) {
     a.sum_abs_ext = a.sum_sq_ext = 0;
-    for (long i = 0; i < a.n_ext; ++i) {
-        const long m = i < a.N ? i : i - a.N;
-        const double v = a.cplx ? std::hypot(a.h_re[(size_t)m], a.h_im[(size_t)m]) : std::fabs(a.h_re[(size_t)m]);
-        a.sum_abs_ext += v;
-        a.sum_sq_ext += v * v;
+    if (a.skind == kS8) {
+        // (integers: the sequential f64 sums of rounds 1-4 were exact too, so these are the same values)
+        long sa = 0, sq = 0;
+        const int8_t *b = a.h_s8.data();
+        for (long m = 0; m < a.N; ++m) sa += std::abs((int)b[m]), sq += (int)b[m] * (int)b[m];
+        long sa2 = 0, sq2 = 0;
+        for (long m = 0; m < a.n_ext - a.N; ++m) sa2 += std::abs((int)b[m]), sq2 += (int)b[m] * (int)b[m];
+        a.sum_abs_ext = (double)(sa + sa2), a.sum_sq_ext = (double)(sq + sq2);
+    } else {
+        for (long i = 0; i < a.n_ext; ++i) {
+            const long m = i < a.N ? i : i - a.N;
+            const double v = a.cplx ? std::hypot(a.sample_re(m), a.sample_im(m)) : std::fabs(a.sample_re(m));
+            a.sum_abs_ext += v;
+            a.sum_sq_ext += v * v;
+        }
     }
     a.sums_N = a.N;
     a.sums_next = a.n_ext;
@@ -908,7 +646,7 @@ extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s_in, const int8_t
     const ResamplePlan r = resample_plan(*s_in);
     BDS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nb = n_samples * (cplx ? 2 : 1);
-    if ((rc = ensure(ctx, &a.d_sig, &a.sig_cap, nb))) return rc;
+    if ((rc = ensure(ctx, &a.d_sig, &a.sig_cap, nb + 16))) return rc;  // (+16: k_corr reads whole dwords, bds_acq_corr.h)
     BDS_HIP(ctx, hipMemcpyAsync(a.d_sig, samples, nb, hipMemcpyHostToDevice, st(ctx)));
     a.cplx = cplx;
     a.rs = r;
@@ -919,42 +657,50 @@ extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s_in, const int8_t
         a.skind = cplx ? kF64C : kF64;
     } else {
         a.skind = cplx ? kS8C : kS8;
-        a.h_re.resize(n_samples);
-        a.h_im.assign(cplx ? n_samples : 0, 0.0);
-        for (size_t i = 0; i < n_samples; ++i) {
-            a.h_re[i] = (double)samples[cplx ? 2 * i : i];
-            if (cplx) a.h_im[i] = (double)samples[2 * i + 1];
-        }
+        a.h_s8.assign(samples, samples + nb);
+        a.h_re.clear(), a.h_im.clear(), a.h_prefix.clear(), a.h_prefix_q.clear();
     }
     if (n_eff < a.N)
         return fail(ctx, BDS_ERR_ARG, "longSignal has %ld samples%s; acquisition needs at least %ld (acquisition.m:140)",
                     n_eff, r.on ? " after resampling" : "", a.N);
-    a.h_prefix.resize((size_t)n_eff + 1);
-    a.h_prefix[0] = 0;
-    a.h_prefix_q.clear();
-    for (long i = 0; i < n_eff; ++i) a.h_prefix[(size_t)i + 1] = a.h_prefix[(size_t)i] + a.h_re[(size_t)i];
-    if (cplx) {
-        a.h_prefix_q.resize((size_t)n_eff + 1);
-        a.h_prefix_q[0] = 0;
-        for (long i = 0; i < n_eff; ++i) a.h_prefix_q[(size_t)i + 1] = a.h_prefix_q[(size_t)i] + a.h_im[(size_t)i];
-    }
     a.n_samples = n_eff;
     a.sigpower_X = 0;
-    if (!r.on) {
-        // every 256th prefix sum for the device refinement chain (the DC of the B1C fine-search block, bds_acq_refine.h)
-        const size_t nc = (size_t)(n_eff >> 8) + 1;
-        std::vector<double> pc(nc);
-        for (size_t i = 0; i < nc; ++i) pc[i] = a.h_prefix[i << 8];
-        if ((rc = ensure(ctx, &a.d_prefix_c, &a.prefix_c_cap, nc))) return rc;
-        BDS_HIP(ctx, hipMemcpyAsync(a.d_prefix_c, pc.data(), sizeof(double) * nc, hipMemcpyHostToDevice, st(ctx)));
+    if (r.on) {
+        a.h_s8.clear(), a.h_cpre.clear(), a.h_cpre_q.clear();
+        a.h_prefix.resize((size_t)n_eff + 1);
+        a.h_prefix[0] = 0;
+        a.h_prefix_q.clear();
+        for (long i = 0; i < n_eff; ++i) a.h_prefix[(size_t)i + 1] = a.h_prefix[(size_t)i] + a.h_re[(size_t)i];
         if (cplx) {
-            std::vector<double> pq(nc);
-            for (size_t i = 0; i < nc; ++i) pq[i] = a.h_prefix_q[i << 8];
-            if ((rc = ensure(ctx, &a.d_prefix_cq, &a.prefix_cq_cap, nc))) return rc;
-            BDS_HIP(ctx, hipMemcpyAsync(a.d_prefix_cq, pq.data(), sizeof(double) * nc, hipMemcpyHostToDevice, st(ctx)));
-            BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));  // (pq leaves scope)
+            a.h_prefix_q.resize((size_t)n_eff + 1);
+            a.h_prefix_q[0] = 0;
+            for (long i = 0; i < n_eff; ++i) a.h_prefix_q[(size_t)i + 1] = a.h_prefix_q[(size_t)i] + a.h_im[(size_t)i];
         }
-        BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));      // (pc leaves scope)
+    } else {
+        // prefix sums at every 256th sample: the host's DC means (AcqState::prefix) and the device refinement chain's (the DC of
+        // the B1C fine-search block, bds_acq_refine.h) both add the few samples in between
+        const size_t nc = (size_t)(n_eff >> 8) + 1;
+        a.h_cpre.resize(nc);
+        a.h_cpre_q.resize(cplx ? nc : 0);
+        long tot = 0, tot_q = 0;
+        const int8_t *b = a.h_s8.data();
+        for (size_t c = 0; c < nc; ++c) {
+            a.h_cpre[c] = (double)tot;
+            if (cplx) a.h_cpre_q[c] = (double)tot_q;
+            const long m0 = (long)c << 8, m1 = std::min(m0 + 256, n_eff);
+            int s0 = 0, s1 = 0;
+            if (cplx)
+                for (long m = m0; m < m1; ++m) s0 += b[2 * m], s1 += b[2 * m + 1];
+            else
+                for (long m = m0; m < m1; ++m) s0 += b[m];
+            tot += s0, tot_q += s1;
+        }
+        if ((rc = ensure(ctx, &a.d_prefix_c, &a.prefix_c_cap, nc))) return rc;
+        BDS_HIP(ctx, hipMemcpyAsync(a.d_prefix_c, a.h_cpre.data(), sizeof(double) * nc, hipMemcpyHostToDevice, st(ctx)));
+        if (cplx) {
+            if ((rc = ensure(ctx, &a.d_prefix_cq, &a.prefix_cq_cap, nc))) return rc;
+            BDS_HIP(ctx, hipMemcpyAsync(a.d_prefix_cq, a.h_cpre_q.data(), sizeof(double) * nc, hipMemcpyHostToDevice, st(ctx)));
+        }
     }
     ext_sums(a);
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
@@ -1032,7 +778,7 @@ static int ensure_code_cache(bds_ctx *ctx, AcqState &a, const bds_settings &s) {
     const size_t ntab = (size_t)BDS_MAX_PRN * 2 * 2;
     if (!a.d_codes || a.code_stride != stride || a.code_have.size() != ntab) {
         if (a.d_codes) (void)hipFree(a.d_codes), a.d_codes = nullptr;
-        hipError_t e = hipMalloc((void **)&a.d_codes, ntab * (size_t)stride);
+        hipError_t e = hipMalloc((void **)&a.d_codes, ntab * (size_t)stride + 16);  // (+16: k_corr reads whole dwords)
         if (e != hipSuccess) return fail(ctx, BDS_ERR_NOMEM, "sampled-code cache: %s", hipGetErrorString(e));
         a.code_stride = stride;
         a.code_have.assign(ntab, 0);
@@ -1055,12 +801,15 @@ static int ensure_job_buffers(bds_ctx *ctx, AcqState &a, size_t njobs) {
     return BDS_OK;
 }
 
-// multi: every job carries up to kCorrFreqs frequencies (k_corr_f64_multi); out[j * kCorrFreqs + f]
+// multi: every job carries up to kCorrFreqs frequencies; out[j * kCorrFreqs + f]
+// nc: jobs come in groups of nc that differ only in their code slot (the components of one candidate / segment) and are
+// summed in one pass (bds_acq_corr.h)
 static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vector<CorrJob> &jobs,
-                    std::vector<double2> &out, bool multi = false) {
+                    std::vector<double2> &out, int nc, bool multi = false) {
     const int nper = multi ? kCorrFreqs : 1;
     out.resize(jobs.size() * nper);
     if (jobs.empty()) return BDS_OK;
+    if (nc < 1 || nc > 2 || jobs.size() % (size_t)nc) return fail(ctx, BDS_ERR_ARG, "run_jobs: %zu jobs in groups of %d", jobs.size(), nc);
     int rc;
     // sampled codes the jobs refer to (built once per (slot, mode), cached in the context)
     if ((rc = ensure_code_cache(ctx, a, s))) return rc;
@@ -1068,12 +817,13 @@ static int run_jobs(bds_ctx *ctx, AcqState &a, const bds_settings &s, std::vecto
     constexpr int kSlices = kCorrSlices;
     if ((rc = ensure_job_buffers(ctx, a, jobs.size()))) return rc;
     BDS_HIP(ctx, hipMemcpyAsync(a.d_jobs, jobs.data(), sizeof(CorrJob) * jobs.size(), hipMemcpyHostToDevice, st(ctx)));
+    const dim3 grid((unsigned)(jobs.size() / (size_t)nc), kSlices);
     if (multi)
-        hipLaunchKernelGGL(k_corr_f64_multi, dim3((unsigned)jobs.size(), kSlices), dim3(256), 0, st(ctx), a.sview(), a.N,
-                           (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
+        launch_corr<kCorrFreqs>(st(ctx), grid, a.sview(), nc, a.N, (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs,
+                                a.d_jobout, nullptr, 0);
     else
-        hipLaunchKernelGGL(k_corr_f64, dim3((unsigned)jobs.size(), kSlices), dim3(256), 0, st(ctx), a.sview(), a.N,
-                           (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)nullptr, 0, 0);
+        launch_corr<1>(st(ctx), grid, a.sview(), nc, a.N, (const int8_t *)a.d_codes, a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs,
+                       a.d_jobout, nullptr, 0);
     BDS_HIP(ctx, hipGetLastError());
     std::vector<double2> part(jobs.size() * kSlices * nper);
     BDS_HIP(ctx, hipMemcpyAsync(part.data(), a.d_jobout, sizeof(double2) * part.size(), hipMemcpyDeviceToHost, st(ctx)));
@@ -1451,644 +1201,7 @@ int AcqRun::search() {
     return BDS_OK;
 }
 
-int AcqRun::collect() {
-    const Tuning &tune = ctx->tune;
-    a.h_rowmax.resize((size_t)P * D);
-    a.h_rowarg.resize((size_t)P * D);
-    n_extra = 0;
-    std::vector<unsigned long long> h_cellmax(wcols ? (size_t)P * D : 0);
-    if (wcols) {
-        BDS_HIP(ctx, hipMemcpyAsync(h_cellmax.data(), a.d_cellmax, sizeof(unsigned long long) * P * D, hipMemcpyDeviceToHost, stream()));
-    } else {
-        BDS_HIP(ctx, hipMemcpyAsync(a.h_rowmax.data(), a.d_rowmax, sizeof(float) * P * D, hipMemcpyDeviceToHost, stream()));
-        BDS_HIP(ctx, hipMemcpyAsync(a.h_rowarg.data(), a.d_rowarg, sizeof(int) * P * D, hipMemcpyDeviceToHost, stream()));
-    }
-    BDS_HIP(ctx, hipMemcpyAsync(&n_extra, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, stream()));
-    BDS_HIP(ctx, hipStreamSynchronize(stream()));
-    for (size_t i = 0; i < h_cellmax.size(); ++i) unpack_cell(h_cellmax[i], &a.h_rowmax[i], &a.h_rowarg[i]);
-    a.run_prns = prns;
-    a.last.clear();
-    {
-        bool bad = false;
-        for (float v : a.h_rowmax) bad = bad || !std::isfinite(v);
-        if (bad && tune.verbose) {
-            int nbad = 0;
-            for (float v : a.h_rowmax) nbad += !std::isfinite(v);
-            fprintf(stderr, "[bds] %d of %zu row maxima are not finite; first rows:", nbad, a.h_rowmax.size());
-            for (size_t i = 0; i < std::min<size_t>(8, a.h_rowmax.size()); ++i) fprintf(stderr, " %g", a.h_rowmax[i]);
-            fprintf(stderr, "  (sX %g sC %g sB %g)\n", a.sX, a.sC, a.sB);
-        }
-        if (a.half && ((bad && !tune.no_selfcheck) || tune.test_force_fallback)) return redo(kRedoFp32, bad ? "non-finite row maximum" : "test hook");
-        if (n_extra > kExtraCap && a.half) return redo(kRedoFp32, "overflow list of the sieve ran over at the fp16-storage tolerance");
-        if (n_extra > kExtraCap && !a.no_fast_search) return redo(kRedoPlain, "overflow list of the sieve ran over");
-    }
-    h_extra.resize((size_t)std::min(n_extra, kExtraCap));
-    if (!h_extra.empty())
-        BDS_HIP(ctx, hipMemcpyAsync(h_extra.data(), a.d_extra, sizeof(Extra) * h_extra.size(), hipMemcpyDeviceToHost, stream()));
-    a.n_extra_last = n_extra;
-    return BDS_OK;
-}
-
-// ---- f64 refinement of the sieve's candidates ---------------------------------------
-int AcqRun::refine() {
-    Plan2D &pl = a.plan;
-    const Tuning &tune = ctx->tune;
-    int rc;
-    cells.assign(P, {});
-    std::vector<CorrJob> jobs;
-    // only the per-workgroup records of rows that reach the tolerance band travel to the host
-    // (the full record array is P*D*tiles*8 B: 104 MB at the B1C config); the wave-private pass keeps no tile records: its list is complete
-    thr_of.assign(P, 0.f);
-    max_of.assign(P, 0.f);
-    std::map<std::pair<int, int>, size_t> row_at;
-    std::vector<Rec> h_recs;
-    {
-        std::vector<std::pair<int, int>> rows;
-        for (int pi = 0; pi < P; ++pi) {
-            float M = -1.f;
-            for (int b = 0; b < D; ++b) M = std::max(M, a.h_rowmax[(size_t)pi * D + b]);
-            max_of[pi] = M;
-            thr_of[pi] = (float)((1.0 - kDelta) * (double)M);
-            for (int b = 0; b < D && !wcols; ++b)
-                if (!(a.h_rowmax[(size_t)pi * D + b] < thr_of[pi])) rows.push_back({pi, b});
-        }
-        const size_t all = (size_t)P * D * pl.ntiles;
-        if (wcols) {
-            // nothing to fetch
-        } else if (all * sizeof(Rec) <= (16u << 20)) {  // small grid (B2a): one copy beats many row copies
-            h_recs.resize(all);
-            BDS_HIP(ctx, hipMemcpyAsync(h_recs.data(), a.d_recs, sizeof(Rec) * all, hipMemcpyDeviceToHost, stream()));
-            for (auto &r : rows) row_at[r] = ((size_t)r.first * D + r.second) * pl.ntiles;
-        } else {
-            h_recs.resize(rows.size() * (size_t)pl.ntiles);
-            for (size_t r = 0; r < rows.size(); ++r) {
-                row_at[rows[r]] = r * (size_t)pl.ntiles;
-                BDS_HIP(ctx, hipMemcpyAsync(&h_recs[r * (size_t)pl.ntiles],
-                                            a.d_recs + ((size_t)rows[r].first * D + rows[r].second) * pl.ntiles,
-                                            sizeof(Rec) * pl.ntiles, hipMemcpyDeviceToHost, stream()));
-            }
-        }
-        BDS_HIP(ctx, hipStreamSynchronize(stream()));  // (also: h_extra has arrived)
-    }
-    {
-        std::vector<std::set<Cell>> cs(P);
-        // (rounds 1-3 also refined the +-1 bin / +-1 lag neighbours of every candidate -- nine f64 sums per candidate.  The
-        //  completeness argument does not use them: the true maximum's sieve value is within kDelta / 2 of it, hence within
-        //  kDelta of the sieve maximum, hence on the list itself.  BDS_ACQ_NEIGH=1 brings them back.)
-        const int nb_r = tune.neigh;
-        auto add = [&](int pi, int b, long lag) {
-            for (int db = -nb_r; db <= nb_r; ++db)
-                for (int dl = -nb_r; dl <= nb_r; ++dl) {
-                    const int bb = b + db;
-                    const long ll = lag + dl;
-                    if (bb >= 0 && bb < D && ll >= 0 && ll < a.N) cs[pi].insert(Cell{bb, ll});
-                }
-        };
-        for (int pi = 0; pi < P; ++pi) {
-            const float thr = thr_of[pi];
-            for (int b = 0; b < D && !wcols; ++b) {
-                if (a.h_rowmax[(size_t)pi * D + b] < thr) continue;
-                const Rec *rr = &h_recs[row_at[{pi, b}]];
-                for (int t = 0; t < pl.ntiles; ++t)
-                    if (rr[t].lag >= 0 && !(rr[t].v < thr)) add(pi, b, rr[t].lag);
-            }
-        }
-        // lags the column pass put on its list (wave-private pass: every candidate; tile pass: those beside their tile's record)
-        for (const Extra &e : h_extra) {
-            const int pi = e.cell / D, b = e.cell % D;
-            if (pi >= 0 && pi < P && e.lag >= 0 && !(e.v < thr_of[pi])) add(pi, b, e.lag);
-        }
-        a.last_cands.clear();
-        for (int pi = 0; pi < P; ++pi) {
-            cells[pi].assign(cs[pi].begin(), cs[pi].end());
-            auto &lc = a.last_cands[prns[pi]];
-            for (const Cell &c : cells[pi]) lc.push_back({c.b, c.lag});
-            for (const Cell &c : cells[pi])
-                for (int comp = 0; comp < ncomp; ++comp) {
-                    CorrJob j{};
-                    j.start = c.lag;
-                    j.len = a.X;
-                    j.freq = bin_freq(c.b);
-                    j.mean = 0;
-                    j.slot = (prns[pi] - 1) * 2 + comp;
-                    j.circ = 1;
-                    j.mode = 0;
-                    jobs.push_back(j);
-                }
-        }
-    }
-    std::vector<double2> jout;
-    if ((rc = run_jobs(ctx, a, *s, jobs, jout))) return rc;
-    res.assign(P, PrnResult{});
-    size_t k = 0;
-    for (int pi = 0; pi < P; ++pi) {
-        double best = -1;
-        Cell bc{0, 0};
-        for (const Cell &c : cells[pi]) {
-            const double v = combine(a, &jout[k]);
-            k += ncomp;
-            // ties: first row / first column, as MATLAB max does (acquisition.m:218-221)
-            if (v > best || (v == best && (c.b < bc.b || (c.b == bc.b && c.lag < bc.lag)))) best = v, bc = c;
-        }
-        res[pi].peak = best;
-        res[pi].fbin = bc.b + 1;
-        res[pi].codePhase = bc.lag + 1;
-        // The sieve's maximum must agree with the f64 value to well inside the tolerance band it was
-        // searched with; otherwise its error model does not hold for this input: redo with fp32 storage.
-        // (round 5: fp32 storage on the specialised kernels is checked the same way against ITS tolerance -- its forward pass
-        //  rotates the carrier in fp32 since round 4 -- and falls back to the run-time-plan kernels)
-        if ((a.half || (fsearch && !a.no_fast_search)) && !tune.no_selfcheck && !cells[pi].empty() &&
-            std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
-            char msg[160];
-            snprintf(msg, sizeof(msg), "PRN %d: sieve maximum %.9g vs f64 %.9g (rel %.3g > %.3g)", prns[pi], (double)max_of[pi], best,
-                     std::fabs(best - (double)max_of[pi]) / best, 0.5 * kDelta);
-            return redo(a.half ? kRedoFp32 : kRedoPlain, msg);
-        }
-    }
-    return BDS_OK;
-}
-
-// sigPower = sqrt(var(sig(1:X)) * X), unbiased variance (B1C/acquisition.m:150)
-// (complex input: var = sum |x - mean|^2 / (X-1), as MATLAB's var of a complex vector)
-int AcqRun::metric_b1c_sigpower() {
-    // (a property of the loaded block and X: a million-term host sum, kept across calls -- it was ~1.5 ms of every run)
-    if (a.sigpower_X != a.X) {
-        const double mean = (a.h_prefix[a.X] - a.h_prefix[0]) / (double)a.X;
-        const double mean_q = a.cplx ? (a.h_prefix_q[a.X] - a.h_prefix_q[0]) / (double)a.X : 0.0;
-        long double acc = 0;
-        for (long i = 0; i < a.X; ++i) {
-            const double d = a.h_re[(size_t)i] - mean;
-            const double dq = a.cplx ? a.h_im[(size_t)i] - mean_q : 0.0;
-            acc += (long double)(d * d + dq * dq);
-        }
-        const double var = (double)(acc / (long double)(a.X - 1));
-        a.sigpower = std::sqrt(var * (double)a.X);
-        a.sigpower_X = a.X;
-    }
-    return BDS_OK;
-}
-
-int AcqRun::metric_b1c() {
-    if (int rc = metric_b1c_sigpower()) return rc;
-    const double sigPower = a.sigpower;
-    for (int pi = 0; pi < P; ++pi) {
-        res[pi].denom = sigPower;
-        if (res[pi].codePhase + a.spc - 1 > a.n_samples) res[pi].codePhase -= a.spc;  // :239-241
-    }
-    return BDS_OK;
-}
-
-// second peak in the winning bin, outside +-2 chips and within +-1 code (B2a/acquisition.m:224-249)
-// (one cell per PRN, a single round of workgroups: the tile kernel with its per-tile records serves this pass; the
-//  wave-private kernel's running bounds have nothing to run on)
-int AcqRun::second_peak_b2a() {
-    Plan2D &pl = a.plan;
-    const int nb_r = ctx->tune.neigh;
-    int rc;
-    const bool small = pl.small && fsearch;  // the 80 x 4096 plan has no tile kernel: its column pass reports as in the search
-    so.cellmax = nullptr;
-    so.lb = nullptr;
-    const long s2c = (long)std::ceil(s->samplingFreq / s->codeFreqBasis) * 2;  // samples2CodeChip :137
-    std::vector<std::array<long, 4>> rng(P);
-    if (small) {  // cell = PRN index: one packed maximum and one running bound per PRN
-        BDS_HIP(ctx, hipMemsetAsync(a.d_cellmax, 0, sizeof(unsigned long long) * (size_t)std::max(P, 1), stream()));
-        BDS_HIP(ctx, hipMemsetAsync(a.d_lb, 0, sizeof(float) * (size_t)std::max(P, 1), stream()));
-        so.cellmax = a.d_cellmax;
-        so.lb = a.d_lb;
-        so.lb_div = 1;
-        so.recs = nullptr;
-    } else {
-        if ((rc = ensure(ctx, &a.d_recs, &a.recs_cap, (size_t)std::max(P, 1) * pl.ntiles))) return rc;
-        so.recs = a.d_recs;
-    }
-    // specialised kernels: all PRNs' (PRN, winning bin) cells in one launch pair through a cell list
-    // (63 tiny launch pairs were ~1 ms of the 2.7 ms refinement at cfg2)
-    const size_t cap_cells = a.bw_cap / (size_t)pl.L * 8 / elem / (size_t)ncomp;  // cells the work buffer holds
-    const bool batched = fsearch && (size_t)P <= cap_cells;
-    BDS_HIP(ctx, hipMemsetAsync(a.d_extra_count, 0, sizeof(int), stream()));  // overflow list of this pass: cell = PRN index
-    std::vector<int> h_bin(P);
-    std::vector<long> h_cs(P);
-    std::vector<int4> h_rng(P);
-    for (int pi = 0; pi < P; ++pi) {
-        const long cp = res[pi].codePhase;
-        const long e1 = cp - s2c, e2 = cp + s2c, e3 = cp - a.spc + s2c, e4 = cp + a.spc - s2c;
-        long lo1 = 1, hi1 = 0, lo2 = 1, hi2 = 0;  // 1-based inclusive, empty when lo > hi
-        if (e1 >= 1) lo1 = std::max<long>(1, e3), hi1 = e1;
-        if (e2 < a.N) lo2 = e2, hi2 = std::min<long>(e4, a.N);
-        rng[pi] = {lo1 - 1, hi1 - 1, lo2 - 1, hi2 - 1};  // 0-based
-        if (hi1 < lo1 && hi2 < lo2)
-            return fail(ctx, BDS_ERR_ARG, "PRN %d: empty second-peak range (acquisition.m:248 would fail)", prns[pi]);
-        h_bin[pi] = res[pi].fbin - 1;
-        h_cs[pi] = (long)a.cs_slot[prns[pi]] * ncomp * pl.L;
-        h_rng[pi] = make_int4((int)rng[pi][0], (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3]);
-        if (!batched)
-            launch_cells(prns[pi], res[pi].fbin - 1, 1, small ? nullptr : a.d_recs + (size_t)pi * pl.ntiles, (int)rng[pi][0],
-                         (int)rng[pi][1], (int)rng[pi][2], (int)rng[pi][3], pi, nullptr);
-    }
-    if (batched && P > 0) {
-        const size_t nb_ = sizeof(int) * P + sizeof(long) * P + sizeof(int4) * P + 64;
-        if ((rc = ensure(ctx, &a.d_cells, &a.cells_cap, nb_))) return rc;
-        int4 *d_rng = (int4 *)a.d_cells;                       // 16-byte aligned first
-        long *d_cs = (long *)(d_rng + P);
-        int *d_bin = (int *)(d_cs + P);
-        BDS_HIP(ctx, hipMemcpyAsync(d_rng, h_rng.data(), sizeof(int4) * P, hipMemcpyHostToDevice, stream()));
-        BDS_HIP(ctx, hipMemcpyAsync(d_cs, h_cs.data(), sizeof(long) * P, hipMemcpyHostToDevice, stream()));
-        BDS_HIP(ctx, hipMemcpyAsync(d_bin, h_bin.data(), sizeof(int) * P, hipMemcpyHostToDevice, stream()));
-        const CellList cl{d_bin, d_cs, d_rng};
-        launch_list(P, small ? nullptr : a.d_recs, cl, 0, nullptr);
-    }
-    BDS_HIP(ctx, hipGetLastError());
-    std::vector<Rec> r2(small ? 0 : (size_t)P * pl.ntiles);
-    std::vector<unsigned long long> h_cm(small ? (size_t)P : 0);
-    int n_extra2 = 0;
-    if (small)
-        BDS_HIP(ctx, hipMemcpyAsync(h_cm.data(), a.d_cellmax, sizeof(unsigned long long) * (size_t)P, hipMemcpyDeviceToHost, stream()));
-    else
-        BDS_HIP(ctx, hipMemcpyAsync(r2.data(), a.d_recs, sizeof(Rec) * r2.size(), hipMemcpyDeviceToHost, stream()));
-    BDS_HIP(ctx, hipMemcpyAsync(&n_extra2, a.d_extra_count, sizeof(int), hipMemcpyDeviceToHost, stream()));
-    BDS_HIP(ctx, hipStreamSynchronize(stream()));
-    if (n_extra2 > kExtraCap && a.half) return redo(kRedoFp32, "overflow list of the second-peak pass ran over at the fp16-storage tolerance");
-    if (n_extra2 > kExtraCap && !a.no_fast_search) return redo(kRedoPlain, "overflow list of the second-peak pass ran over");
-    std::vector<Extra> h_extra2((size_t)std::min(n_extra2, kExtraCap));
-    if (!h_extra2.empty()) {
-        BDS_HIP(ctx, hipMemcpyAsync(h_extra2.data(), a.d_extra, sizeof(Extra) * h_extra2.size(), hipMemcpyDeviceToHost, stream()));
-        BDS_HIP(ctx, hipStreamSynchronize(stream()));
-    }
-
-    std::vector<CorrJob> jobs;
-    std::vector<std::vector<long>> lags(P);
-    for (int pi = 0; pi < P; ++pi) {
-        float M = -1.f;
-        if (small) {
-            int lag_unused;
-            unpack_cell(h_cm[(size_t)pi], &M, &lag_unused);  // (the maximum itself is on the list, like every lag above the threshold)
-        }
-        for (int t = 0; t < pl.ntiles && !small; ++t) M = std::max(M, r2[(size_t)pi * pl.ntiles + t].v);
-        const float thr = (float)((1.0 - kDelta) * (double)M);
-        std::set<long> ls;
-        auto inrange = [&](long l) {
-            return (l >= rng[pi][0] && l <= rng[pi][1]) || (l >= rng[pi][2] && l <= rng[pi][3]);
-        };
-        for (int t = 0; t < pl.ntiles && !small; ++t) {
-            const Rec &r = r2[(size_t)pi * pl.ntiles + t];
-            if (r.lag < 0 || r.v < thr) continue;
-            for (long dl = -nb_r; dl <= nb_r; ++dl)
-                if (inrange(r.lag + dl)) ls.insert(r.lag + dl);
-        }
-        for (const Extra &e : h_extra2)
-            if (e.cell == pi && e.lag >= 0 && !(e.v < thr))
-                for (long dl = -nb_r; dl <= nb_r; ++dl)
-                    if (inrange(e.lag + dl)) ls.insert(e.lag + dl);
-        lags[pi].assign(ls.begin(), ls.end());
-        for (long l : lags[pi])
-            for (int comp = 0; comp < ncomp; ++comp) {
-                CorrJob j{};
-                j.start = l;
-                j.len = a.X;
-                j.freq = bin_freq(res[pi].fbin - 1);
-                j.slot = (prns[pi] - 1) * 2 + comp;
-                j.circ = 1;
-                j.mode = 0;
-                jobs.push_back(j);
-            }
-    }
-    std::vector<double2> jout;
-    if ((rc = run_jobs(ctx, a, *s, jobs, jout))) return rc;
-    size_t k = 0;
-    for (int pi = 0; pi < P; ++pi) {
-        double second = -1;
-        for (size_t i = 0; i < lags[pi].size(); ++i, k += ncomp) second = std::max(second, combine(a, &jout[k]));
-        res[pi].denom = second;
-    }
-    return BDS_OK;
-}
-
-// ---- threshold + fine-Doppler search ---------------------------------------------------
-int AcqRun::fine_search() {
-    int rc;
-    std::vector<CorrJob> jobs;
-    std::vector<int> fine_of(P, -1);
-    int nfine = 0;
-    std::vector<std::vector<double>> fine_frq(P);
-    for (int pi = 0; pi < P; ++pi) {
-        PrnResult &r = res[pi];
-        const double metric = r.peak / r.denom;  // :252 / B1C :235
-        peakMetric[prns[pi] - 1] = metric;
-        if (!(metric > s->acqThreshold)) continue;  // :255 / B1C :244
-        r.detected = true;
-        const double fb = bin_freq(r.fbin - 1);
-        if (a.signal == BDS_SIGNAL_B1C) {
-            nfine = (int)m_round(s->acqStep / 25) * 2 + 1;  // B1C/acquisition.m:267
-            if (r.codePhase < 1 || r.codePhase - 1 + a.spc > a.n_samples)
-                return fail(ctx, BDS_ERR_ARG, "PRN %d: fine-search block %ld..%ld outside longSignal (B1C/acquisition.m:253)",
-                            prns[pi], r.codePhase, r.codePhase + a.spc - 1);
-            const double mean = (a.h_prefix[r.codePhase - 1 + a.spc] - a.h_prefix[r.codePhase - 1]) / (double)a.spc;  // :254
-            const double mean_q = a.cplx ? (a.h_prefix_q[r.codePhase - 1 + a.spc] - a.h_prefix_q[r.codePhase - 1]) / (double)a.spc : 0.0;
-            for (int kf = 0; kf < nfine; ++kf) fine_frq[pi].push_back(fb - s->acqStep + 25.0 * kf);  // :282-283
-            // jobs of one PRN: [component][chunk of up to kCorrFreqs frequencies]
-            for (int comp = 0; comp < ncomp; ++comp)
-                for (int k0 = 0; k0 < nfine; k0 += kCorrFreqs) {
-                    CorrJob j{};
-                    j.start = r.codePhase - 1;
-                    j.len = a.spc;
-                    j.mean = mean;
-                    j.mean_q = mean_q;
-                    j.slot = (prns[pi] - 1) * 2 + comp;
-                    j.circ = 0;
-                    j.mode = 0;
-                    j.nf = std::min(kCorrFreqs, nfine - k0);
-                    for (int f = 0; f < j.nf; ++f) j.fr[f] = fine_frq[pi][k0 + f];
-                    j.freq = j.fr[0];
-                    jobs.push_back(j);
-                }
-        } else {
-            nfine = (int)m_round(s->acqStep / 25) + 1;  // B2a/acquisition.m:265
-            const long nn = (long)s->fineNoncoh * a.spc;
-            if (r.codePhase - 1 + nn > a.n_samples)
-                return fail(ctx, BDS_ERR_ARG, "PRN %d: fine-search block %ld..%ld outside longSignal (B2a/acquisition.m:290)",
-                            prns[pi], r.codePhase, r.codePhase + nn - 1);
-            for (int kf = 0; kf < nfine; ++kf) fine_frq[pi].push_back(fb - s->acqStep / 2 + 25.0 * kf);  // :300-301
-            // jobs of one PRN: [segment][component][chunk of up to kCorrFreqs frequencies]
-            for (int seg = 0; seg < s->fineNoncoh; ++seg)
-                for (int comp = 0; comp < 2; ++comp)
-                    for (int k0 = 0; k0 < nfine; k0 += kCorrFreqs) {
-                        CorrJob j{};
-                        j.start = r.codePhase - 1 + (long)seg * a.spc;
-                        j.len = a.spc;
-                        j.code_k0 = (long)seg * a.spc;
-                        j.slot = (prns[pi] - 1) * 2 + comp;
-                        j.circ = 0;
-                        j.mode = 1;
-                        j.nf = std::min(kCorrFreqs, nfine - k0);
-                        for (int f = 0; f < j.nf; ++f) j.fr[f] = fine_frq[pi][k0 + f];
-                        j.freq = j.fr[0];
-                        jobs.push_back(j);
-                    }
-        }
-        fine_of[pi] = 1;
-    }
-    std::vector<double2> jout;
-    if ((rc = run_jobs(ctx, a, *s, jobs, jout, true))) return rc;
-    const int nchunk = (nfine + kCorrFreqs - 1) / kCorrFreqs;
-    size_t job0 = 0;  // first job of the PRN
-    for (int pi = 0; pi < P; ++pi) {
-        if (fine_of[pi] < 0) continue;
-        // sum of frequency kf of job group (seg, comp): jobs are laid out [seg][comp][chunk]
-        auto at = [&](int seg, int comp, int ncomp_, int kf) {
-            const size_t j = job0 + ((size_t)seg * ncomp_ + comp) * nchunk + kf / kCorrFreqs;
-            return jout[j * kCorrFreqs + kf % kCorrFreqs];
-        };
-        double best = -1;
-        int kbest = 0;
-        for (int kf = 0; kf < nfine; ++kf) {
-            double v;
-            if (a.signal == BDS_SIGNAL_B1C) {
-                v = cabs2(at(0, 0, ncomp, kf));
-                if (ncomp == 2) v = (v * 11 + cabs2(at(0, 1, ncomp, kf)) * 29) / 40;  // :291-292
-            } else {
-                double sd = 0, sp = 0;
-                for (int seg = 0; seg < s->fineNoncoh; ++seg) sd += cabs2(at(seg, 0, 2, kf)), sp += cabs2(at(seg, 1, 2, kf));
-                v = sd + sp;  // :321
-            }
-            if (v > best) best = v, kbest = kf;
-        }
-        job0 += (size_t)(a.signal == BDS_SIGNAL_B1C ? ncomp : 2 * s->fineNoncoh) * nchunk;
-        double cf = fine_frq[pi][kbest];
-        if (cf == 0) cf = 1;  // :333-335
-        carrFreq[prns[pi] - 1] = cf;
-        codePhase[prns[pi] - 1] = (double)res[pi].codePhase;
-        if (a.rs.on) {
-            // results back at the original sampling rate (B2a/acquisition.m:339-356, B1C :311-328)
-            codePhase[prns[pi] - 1] = std::floor((double)(res[pi].codePhase - 1) / s->samplingFreq * a.rs.old_fs) + 1;
-            double doppler;
-            if (s->IF >= s->samplingFreq / 2)
-                doppler = (s->samplingFreq - s->IF) - cf;
-            else
-                doppler = cf - s->IF;
-            carrFreq[prns[pi] - 1] = doppler + a.rs.old_if;
-        }
-        if (detected) detected[prns[pi] - 1] = 1;
-    }
-    return BDS_OK;
-}
-
-constexpr int kHostRefine = -1002;   // refine_device: this run needs the host path (never returned through the C ABI)
-constexpr int kRefCandCap = 16384;   // candidates per stage the device chain holds (cfg3: a few hundred in the band)
-constexpr int kExtra2Cap = 1 << 20;  // candidate list of the B2a second-peak pass (one cell per PRN)
-
-bool AcqRun::device_refine_ok() const {
-    const Tuning &tune = ctx->tune;
-    if (!wcols || tune.neigh != 0 || tune.host_refine || a.rs.on || a.skind >= kF64 || P < 1) return false;
-    if (a.signal == BDS_SIGNAL_B2A) {
-        const Plan2D &pl = a.plan;
-        if (!(pl.small && fsearch)) return false;  // the tile kernel's second-peak pass reports per-tile records: host path
-        const size_t cap_cells = a.bw_cap / (size_t)pl.L * 8 / elem / (size_t)ncomp;
-        if ((size_t)P > cap_cells) return false;
-    }
-    return true;
-}
-
-int AcqRun::refine_device() {
-    Plan2D &pl = a.plan;
-    const Tuning &tune = ctx->tune;
-    const hipStream_t sm = stream();
-    const bool b1c = a.signal == BDS_SIGNAL_B1C;
-    int rc;
-    // ---- parameters, buffers, tables ---------------------------------------------------------------
-    RefParams rp{};
-    rp.P = P, rp.D = D, rp.ncomp = ncomp, rp.signal = a.signal;
-    rp.half = a.half && !tune.no_selfcheck ? 1 : 0;
-    rp.cand_cap = kRefCandCap, rp.extra_cap = kExtraCap;
-    rp.kDelta = kDelta;
-    rp.f0 = f0, rp.step = s->acqStep;
-    rp.X = a.X, rp.N = a.N, rp.spc = a.spc, rp.n_samples = a.n_samples;
-    rp.threshold = s->acqThreshold;
-    rp.s2c = (long)std::ceil(s->samplingFreq / s->codeFreqBasis) * 2;  // samples2CodeChip, B2a :137
-    rp.fineNoncoh = s->fineNoncoh;
-    rp.nfine = b1c ? (int)m_round(s->acqStep / 25) * 2 + 1 : (int)m_round(s->acqStep / 25) + 1;  // B1C :267, B2a :265
-    rp.nchunk = (rp.nfine + kCorrFreqs - 1) / kCorrFreqs;
-    rp.cplx = a.cplx ? 1 : 0;
-    if (b1c) {
-        if ((rc = metric_b1c_sigpower())) return rc;
-        rp.sigPower = a.sigpower;
-    }
-    const int fine_per = (b1c ? ncomp : 2 * s->fineNoncoh) * rp.nchunk;
-    if ((rc = ensure_code_cache(ctx, a, *s))) return rc;
-    for (int pi = 0; pi < P; ++pi)
-        for (int comp = 0; comp < ncomp; ++comp) {
-            make_code_table(ctx, a, (prns[pi] - 1) * 2 + comp, 0);
-            if (!b1c) make_code_table(ctx, a, (prns[pi] - 1) * 2 + comp, 1);
-        }
-    if ((rc = ensure_job_buffers(ctx, a, std::max<size_t>((size_t)kRefCandCap * ncomp, (size_t)P * fine_per)))) return rc;
-    // everything the chain wants zeroed lives in ONE block (one fill instead of five):
-    //   RefGlobal | RefPrn[P] | cellmax2[P] | lb2[P] | extra2_count
-    {
-        const size_t o_prn = 64, o_cm2 = o_prn + sizeof(RefPrn) * (size_t)P, o_lb2 = o_cm2 + sizeof(unsigned long long) * (size_t)P;
-        const size_t o_cnt = (o_lb2 + sizeof(float) * (size_t)P + 15) & ~(size_t)15, total = o_cnt + 16;
-        static_assert(sizeof(RefGlobal) <= 64 && sizeof(RefPrn) % 16 == 0, "layout of the zeroed block");
-        if ((rc = ensure(ctx, &a.d_ref_zero, &a.ref_zero_cap, total))) return rc;
-        a.d_ref_g = (RefGlobal *)a.d_ref_zero;
-        a.d_ref_prn = (RefPrn *)(a.d_ref_zero + o_prn);
-        a.d_cellmax2 = (unsigned long long *)(a.d_ref_zero + o_cm2);
-        a.d_lb2 = (float *)(a.d_ref_zero + o_lb2);
-        a.d_extra2_count = (int *)(a.d_ref_zero + o_cnt);
-        BDS_HIP(ctx, hipMemsetAsync(a.d_ref_zero, 0, total, sm));
-    }
-    if ((rc = ensure(ctx, &a.d_ref_cand, &a.ref_cand_cap, (size_t)2 * kRefCandCap))) return rc;
-    if ((rc = ensure(ctx, &a.d_ref_tabs, &a.ref_tabs_cap, (sizeof(long) + sizeof(int)) * (size_t)P + 64))) return rc;
-    long *d_cs_of = (long *)a.d_ref_tabs;
-    int *d_prn_of = (int *)(d_cs_of + P);
-    std::vector<long> h_cs(P);
-    for (int pi = 0; pi < P; ++pi) h_cs[pi] = (long)a.cs_slot[prns[pi]] * ncomp * pl.L;
-    BDS_HIP(ctx, hipMemcpyAsync(d_cs_of, h_cs.data(), sizeof(long) * P, hipMemcpyHostToDevice, sm));
-    BDS_HIP(ctx, hipMemcpyAsync(d_prn_of, prns.data(), sizeof(int) * P, hipMemcpyHostToDevice, sm));
-    const unsigned pb = (unsigned)((P + 63) / 64);
-
-    // ---- coarse refinement: thresholds -> candidates in the band -> f64 sums -> per-PRN maximum ----------------
-    hipLaunchKernelGGL(k_ref_thr<false>, dim3(P), dim3(64), 0, sm, (const unsigned long long *)a.d_cellmax, rp, a.d_ref_prn, a.d_ref_g,
-                       (const int *)a.d_extra_count);
-    hipLaunchKernelGGL(k_ref_compact<false>, dim3(256), dim3(256), 0, sm, (const Extra *)a.d_extra, (const int *)a.d_extra_count, rp,
-                       (const RefPrn *)a.d_ref_prn, (const int *)d_prn_of, (const int4 *)nullptr, a.d_ref_cand, a.d_jobs, a.d_ref_g);
-    hipLaunchKernelGGL(k_corr_f64, dim3(1024, kCorrSlices), dim3(256), 0, sm, a.sview(), a.N, (const int8_t *)a.d_codes, a.code_stride,
-                       1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)&a.d_ref_g->ncand, kRefCandCap, ncomp);
-    hipLaunchKernelGGL(k_ref_pick<false>, dim3(P), dim3(256), 0, sm, (const RefCand *)a.d_ref_cand, (const double2 *)a.d_jobout, kCorrSlices,
-                       rp, a.d_ref_prn, a.d_ref_g);
-    BDS_HIP(ctx, hipGetLastError());
-
-    // ---- B2a: second peak of the winning bin, outside +-2 chips and within +-1 code (acquisition.m:224-249) -------
-    if (!b1c) {
-        if ((rc = ensure(ctx, &a.d_extra2, &a.extra2_cap, (size_t)kExtra2Cap))) return rc;
-        const size_t nb_ = sizeof(int) * P + sizeof(long) * P + sizeof(int4) * P + 64;
-        if ((rc = ensure(ctx, &a.d_cells, &a.cells_cap, nb_))) return rc;
-        int4 *d_rng = (int4 *)a.d_cells;  // 16-byte aligned first
-        long *d_cs = (long *)(d_rng + P);
-        int *d_bin = (int *)(d_cs + P);
-        hipLaunchKernelGGL(k_ref_second_setup, dim3(pb), dim3(64), 0, sm, rp, a.d_ref_prn, (const long *)d_cs_of, d_rng, d_cs, d_bin, a.d_ref_g);
-        const SieveOut so_keep = so;
-        so.recs = nullptr;
-        so.extra = a.d_extra2, so.extra_count = a.d_extra2_count, so.extra_cap = kExtra2Cap;
-        so.cellmax = a.d_cellmax2, so.lb = a.d_lb2, so.lb_div = 1;
-        const CellList cl{d_bin, d_cs, d_rng};
-        launch_list(P, nullptr, cl, 0, nullptr);
-        so = so_keep;
-        RefParams rp2 = rp;
-        rp2.extra_cap = kExtra2Cap;
-        RefCand *cand2 = a.d_ref_cand + kRefCandCap;
-        hipLaunchKernelGGL(k_ref_thr<true>, dim3(P), dim3(64), 0, sm, (const unsigned long long *)a.d_cellmax2, rp2, a.d_ref_prn, a.d_ref_g,
-                           (const int *)a.d_extra2_count);
-        hipLaunchKernelGGL(k_ref_compact<true>, dim3(64), dim3(256), 0, sm, (const Extra *)a.d_extra2, (const int *)a.d_extra2_count, rp2,
-                           (const RefPrn *)a.d_ref_prn, (const int *)d_prn_of, (const int4 *)d_rng, cand2, a.d_jobs, a.d_ref_g);
-        hipLaunchKernelGGL(k_corr_f64, dim3(1024, kCorrSlices), dim3(256), 0, sm, a.sview(), a.N, (const int8_t *)a.d_codes, a.code_stride,
-                           1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)&a.d_ref_g->ncand2, kRefCandCap, ncomp);
-        hipLaunchKernelGGL(k_ref_pick<true>, dim3(P), dim3(256), 0, sm, (const RefCand *)cand2, (const double2 *)a.d_jobout, kCorrSlices, rp2,
-                           a.d_ref_prn, a.d_ref_g);
-        BDS_HIP(ctx, hipGetLastError());
-    }
-
-    // ---- threshold + fine-Doppler search --------------------------------------------------------------------
-    hipLaunchKernelGGL(k_ref_fine_jobs, dim3(P), dim3(64), 0, sm, rp, a.d_ref_prn, (const int *)d_prn_of, a.sview(), (const double *)a.d_prefix_c,
-                       (const double *)a.d_prefix_cq, a.d_jobs, a.d_ref_g);
-    hipLaunchKernelGGL(k_corr_f64_multi, dim3((unsigned)(P * fine_per), kCorrSlices), dim3(256), 0, sm, a.sview(), a.N, (const int8_t *)a.d_codes,
-                       a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout);
-    const size_t pick_lds = sizeof(double) * ((size_t)(b1c ? ncomp : 2 * s->fineNoncoh) * rp.nfine + rp.nfine);
-    if (pick_lds > 60000) return kHostRefine;  // (thousands of fine frequencies: the host path has no such limit)
-    hipLaunchKernelGGL(k_ref_fine_pick, dim3(P), dim3(256), pick_lds, sm, rp, a.d_ref_prn, (const double2 *)a.d_jobout, kCorrSlices);
-    BDS_HIP(ctx, hipGetLastError());
-
-    // ---- the one download -------------------------------------------------------------------------------------
-    std::vector<char> h_blk(64 + sizeof(RefPrn) * (size_t)P);  // RefGlobal and RefPrn[P] as they lie in the zeroed block
-    std::vector<unsigned long long> h_cellmax((size_t)P * D);
-    BDS_HIP(ctx, hipMemcpyAsync(h_blk.data(), a.d_ref_zero, h_blk.size(), hipMemcpyDeviceToHost, sm));
-    BDS_HIP(ctx, hipMemcpyAsync(h_cellmax.data(), a.d_cellmax, sizeof(unsigned long long) * (size_t)P * D, hipMemcpyDeviceToHost, sm));
-    BDS_HIP(ctx, hipStreamSynchronize(sm));
-    RefGlobal h_g;
-    memcpy(&h_g, h_blk.data(), sizeof(h_g));
-    std::vector<RefPrn> h_prn(P);
-    memcpy(h_prn.data(), h_blk.data() + 64, sizeof(RefPrn) * (size_t)P);
-
-    // ---- the host's share: the checks of collect() / refine() in their order, then the reported numbers -------------
-    a.h_rowmax.resize((size_t)P * D);
-    a.h_rowarg.resize((size_t)P * D);
-    for (size_t i = 0; i < h_cellmax.size(); ++i) unpack_cell(h_cellmax[i], &a.h_rowmax[i], &a.h_rowarg[i]);
-    a.run_prns = prns;
-    a.last.clear();
-    a.last_cands.clear();
-    a.cands_on_device = 0;
-    n_extra = h_g.n_extra;
-    a.n_extra_last = n_extra;
-    const bool bad = (h_g.flags & kRefNonFinite) != 0;
-    if (a.half && ((bad && !tune.no_selfcheck) || tune.test_force_fallback)) return redo(kRedoFp32, bad ? "non-finite row maximum" : "test hook");
-    if (n_extra > kExtraCap && a.half) return redo(kRedoFp32, "overflow list of the sieve ran over at the fp16-storage tolerance");
-    if (n_extra > kExtraCap && !a.no_fast_search) return redo(kRedoPlain, "overflow list of the sieve ran over");
-    auto host_path = [&](const char *reason) {
-        if (tune.verbose) fprintf(stderr, "[bds] device refinement chain hands over to the host path: %s\n", reason);
-        return kHostRefine;
-    };
-    if (h_g.flags & kRefCandOverflow) return host_path("more candidates in the band than the chain holds");
-    res.assign(P, PrnResult{});
-    max_of.assign(P, 0.f);
-    thr_of.assign(P, 0.f);
-    for (int pi = 0; pi < P; ++pi) {
-        const RefPrn &r = h_prn[pi];
-        max_of[pi] = r.max_of, thr_of[pi] = r.thr;
-        const double best = r.ncand > 0 ? combine(a, r.v) : -1.0;
-        res[pi].peak = best;
-        res[pi].fbin = r.b + 1;
-        res[pi].codePhase = (long)r.lag + 1;
-        if ((a.half || (fsearch && !a.no_fast_search)) && !tune.no_selfcheck && r.ncand > 0 &&
-            std::fabs(best - (double)max_of[pi]) > 0.5 * kDelta * best) {
-            char msg[160];
-            snprintf(msg, sizeof(msg), "PRN %d: sieve maximum %.9g vs f64 %.9g (rel %.3g > %.3g)", prns[pi], (double)max_of[pi], best,
-                     std::fabs(best - (double)max_of[pi]) / best, 0.5 * kDelta);
-            return redo(a.half ? kRedoFp32 : kRedoPlain, msg);
-        }
-    }
-    a.cands_on_device = std::min(h_g.ncand, kRefCandCap);
-    a.cands_prns = prns;
-    if (b1c) {
-        if ((rc = metric_b1c())) return rc;
-    } else {
-        if (h_g.n_extra2 > kExtra2Cap) return host_path("candidate list of the second-peak pass ran over");  // (the host pass has the larger list)
-        for (int pi = 0; pi < P; ++pi) {
-            if (h_prn[pi].flags & kRefEmptyRange)
-                return fail(ctx, BDS_ERR_ARG, "PRN %d: empty second-peak range (acquisition.m:248 would fail)", prns[pi]);
-            res[pi].denom = h_prn[pi].nsecond > 0 ? combine(a, h_prn[pi].v2) : -1.0;
-        }
-    }
-    for (int pi = 0; pi < P; ++pi) {
-        const RefPrn &r = h_prn[pi];
-        PrnResult &q = res[pi];
-        const double metric = q.peak / q.denom;  // :252 / B1C :235
-        const bool det = metric > s->acqThreshold;
-        // (the device decided on its own evaluation of the same sums; a disagreement -- a metric within an ulp of the
-        //  threshold -- or a codePhase the device adjusted differently sends the run through the host path)
-        if (det != (r.detected != 0) || q.codePhase != r.codePhase) {
-            if (tune.verbose)
-                fprintf(stderr, "[bds] PRN %d: host metric %.17g (peak %.17g / %.17g) vs device decision %d (best %.17g second %.17g nsecond %d), codePhase %ld vs %ld\n",
-                        prns[pi], metric, q.peak, q.denom, r.detected, r.best, r.second, r.nsecond, q.codePhase, r.codePhase);
-            return host_path("threshold decision or code phase differ between device and host");
-        }
-    }
-    for (int pi = 0; pi < P; ++pi) {
-        const RefPrn &r = h_prn[pi];
-        PrnResult &q = res[pi];
-        peakMetric[prns[pi] - 1] = q.peak / q.denom;
-        if (!r.detected) continue;
-        q.detected = true;
-        if (r.flags & kRefFineRange) {
-            const long blk = b1c ? a.spc : (long)s->fineNoncoh * a.spc;
-            return fail(ctx, BDS_ERR_ARG, "PRN %d: fine-search block %ld..%ld outside longSignal (%s)", prns[pi], q.codePhase,
-                        q.codePhase + blk - 1, b1c ? "B1C/acquisition.m:253" : "B2a/acquisition.m:290");
-        }
-        const double fb = bin_freq(q.fbin - 1);
-        double cf = b1c ? fb - s->acqStep + 25.0 * r.kbest : fb - s->acqStep / 2 + 25.0 * r.kbest;  // B1C :282-283, B2a :300-301
-        if (cf == 0) cf = 1;  // :333-335
-        carrFreq[prns[pi] - 1] = cf;
-        codePhase[prns[pi] - 1] = (double)q.codePhase;
-        if (detected) detected[prns[pi] - 1] = 1;
-    }
-    return BDS_OK;
-}
+#include "bds_acq_decide.h"  // AcqRun::collect .. fine_search (host path), AcqRun::refine_device (device chain)
 
 int AcqRun::finish() {
     Plan2D &pl = a.plan;
@@ -2300,6 +1413,68 @@ extern "C" int bds_acq_candidates(bds_ctx *ctx, int prn, int32_t *bin, int64_t *
         if (lag) lag[i] = it->second[(size_t)i].second + 1;
     }
     return n;
+}
+
+extern "C" int bds_acq_coherent_sums(bds_ctx *ctx, const bds_settings *s_in, int prn, int64_t phase, const double *freqs, int nf, int mode,
+                                     double *out) {
+    using namespace bds;
+    if (!ctx || !ctx->acq || !s_in || !freqs || !out || nf < 1 || nf > 4096 || mode < 0 || mode > 2 || prn < 1 || prn > BDS_MAX_PRN)
+        return BDS_ERR_ARG;
+    AcqState &a = *ctx->acq;
+    bds_settings eff;
+    const bds_settings *s = effective(s_in, &eff);
+    if (a.n_samples <= 0 || a.spc <= 0) return fail(ctx, BDS_ERR_ARG, "bds_acq_coherent_sums: no block loaded (bds_acq_load / bds_acq_run first)");
+    (void)hipSetDevice(ctx->device);
+    const bool b1c = a.signal == BDS_SIGNAL_B1C;
+    const int nc = b1c ? a.ncomp : 2;
+    std::vector<CorrJob> jobs;
+    std::vector<double2> jout;
+    int rc;
+    if (mode == 0) {
+        // the coarse cell (frequency, code phase): acquisition.m:194-209 -- circular, X samples, the sampled code table
+        if (phase < 1 || phase > a.N) return BDS_ERR_ARG;
+        for (int f = 0; f < nf; ++f)
+            for (int c = 0; c < a.ncomp; ++c) {
+                CorrJob j{};
+                j.start = phase - 1, j.len = a.X, j.freq = freqs[f], j.slot = (prn - 1) * 2 + c, j.circ = 1, j.mode = 0;
+                jobs.push_back(j);
+            }
+        if ((rc = run_jobs(ctx, a, *s, jobs, jout, a.ncomp))) return rc;
+        for (size_t i = 0; i < jout.size(); ++i) out[2 * i] = jout[i].x, out[2 * i + 1] = jout[i].y;
+        return (int)jout.size();
+    }
+    // the fine-search block starting at code phase `phase` (B2a/acquisition.m:287-316, B1C/acquisition.m:253-287)
+    const int nseg = b1c ? 1 : s->fineNoncoh;
+    const long blk = (long)nseg * a.spc;
+    if (phase < 1 || phase - 1 + blk > a.n_samples) return BDS_ERR_ARG;
+    double mean = 0, mean_q = 0;
+    if (b1c) {
+        mean = (a.prefix(phase - 1 + a.spc) - a.prefix(phase - 1)) / (double)a.spc;
+        mean_q = a.cplx ? (a.prefix(phase - 1 + a.spc, 1) - a.prefix(phase - 1, 1)) / (double)a.spc : 0.0;
+    }
+    const bool multi = mode == 1;
+    const int per = multi ? kCorrFreqs : 1, nchunk = (nf + per - 1) / per;
+    for (int seg = 0; seg < nseg; ++seg)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int c = 0; c < nc; ++c) {
+                CorrJob j{};
+                j.start = phase - 1 + (long)seg * a.spc, j.len = a.spc, j.code_k0 = b1c ? 0 : (long)seg * a.spc;
+                j.mean = mean, j.mean_q = mean_q, j.slot = (prn - 1) * 2 + c, j.circ = 0, j.mode = b1c ? 0 : 1;
+                j.nf = std::min(per, nf - ch * per);
+                for (int f = 0; f < j.nf; ++f) j.fr[f] = freqs[ch * per + f];
+                j.freq = j.fr[0];
+                jobs.push_back(j);
+            }
+    if ((rc = run_jobs(ctx, a, *s, jobs, jout, nc, multi))) return rc;
+    // out[((seg * nc + c) * nf + f) * 2 + {re, im}]
+    for (int seg = 0; seg < nseg; ++seg)
+        for (int c = 0; c < nc; ++c)
+            for (int f = 0; f < nf; ++f) {
+                const size_t j = ((size_t)seg * nchunk + f / per) * nc + c;
+                const double2 v = jout[j * per + f % per];
+                out[(((size_t)seg * nc + c) * nf + f) * 2] = v.x, out[(((size_t)seg * nc + c) * nf + f) * 2 + 1] = v.y;
+            }
+    return nseg * nc * nf;
 }
 
 extern "C" int bds_acq_peaks(bds_ctx *ctx, int max_prn, double *peak, double *denom, int32_t *fbin) {

@@ -380,171 +380,6 @@ __global__ __launch_bounds__(256) void k_make_code(CodeTable tab, int slot, int 
     }
 }
 
-struct CorrJob {
-    long start;     // first sample (0-based)
-    long len;       // samples to sum
-    long code_k0;   // mode 1: offset of this segment inside the long code
-    double freq;    // [Hz]
-    double mean;    // subtracted from every sample (B1C/acquisition.m:254), else 0
-    double mean_q;  // ... from the Q part of a complex sample
-    int slot;       // code slot (prn_idx*ncomp + comp)
-    int circ;
-    int mode;
-    int nf;         // k_corr_f64_multi: frequencies of this job (1 .. kCorrFreqs), fr[0 .. nf)
-    double fr[6];   // ... the fine-search frequencies that share the job's samples and code [Hz]
-};
-constexpr int kCorrFreqs = 6;
-
-__global__ __launch_bounds__(256) void k_corr_f64(SampleView sig, long n_circ,
-                                                  const int8_t *__restrict__ codes, long code_stride,
-                                                  double inv_fs, const CorrJob *__restrict__ jobs,
-                                                  double2 *__restrict__ out, const int *__restrict__ njobs_dev, int dev_cap,
-                                                  int dev_mult) {
-    // grid (jobs, slices): every job is cut into gridDim.y contiguous slices whose partial sums the
-    // host adds in order -- a handful of million-sample jobs would otherwise run as a handful of
-    // workgroups (a latency chain of ~4000 iterations each).
-    // njobs_dev: the job count lives on the device (the refinement chain of bds_acq_refine.h builds its jobs there and the host
-    // never learns the count before the launch): a fixed grid walks the jobs; nullptr: one job per workgroup column, as before.
-    // (njobs_dev counts candidates: dev_mult jobs -- components -- each, at most dev_cap of them held)
-    const long njobs = njobs_dev ? (long)min(*njobs_dev, dev_cap) * dev_mult : (long)gridDim.x;
-    __shared__ double s_r[256], s_i[256];
-    for (long jx = blockIdx.x; jx < njobs; jx += gridDim.x) {
-    const CorrJob jb = jobs[jx];
-    const long slice = ((jb.len + gridDim.y - 1) / gridDim.y + 255) & ~255L;
-    const long n_lo = (long)blockIdx.y * slice, n_hi = n_lo + slice < jb.len ? n_lo + slice : jb.len;
-    double sr = 0.0, si = 0.0;
-    // carrier by rotation: exact sincospi every 16th sample of a thread (and at the circular
-    // wrap, where the time index jumps), a constant-angle complex rotation in between
-    const double dcyc = jb.freq * ((double)blockDim.x * inv_fs);
-    double wr, wi;
-    sincospi(2.0 * (dcyc - floor(dcyc)), &wi, &wr);
-    double cr = 1.0, ci = 0.0;
-    int it = 0;
-    const long cbase = ((long)jb.slot * 2 + jb.mode) * code_stride + (jb.mode ? jb.code_k0 : 0);
-    for (long n = n_lo + threadIdx.x; n < n_hi; n += blockDim.x, ++it) {
-        long a = jb.start + n;
-        long t = n;
-        bool resync = (it & 15) == 0;
-        if (jb.circ) {
-            if (a >= n_circ) {
-                resync = resync || (a - (long)blockDim.x < n_circ);
-                a -= n_circ;
-            }
-            t = a;
-        }
-        BDS_DASSERT(n >= 0 && (jb.mode ? jb.code_k0 + n : n) < code_stride && jb.slot >= 0 && jb.slot < 2 * BDS_MAX_PRN);
-        const int8_t cv = codes[cbase + n];
-        const double2 xv = sig.load(a);
-        const double x = (xv.x - jb.mean) * (double)cv;
-        const double xq = (xv.y - jb.mean_q) * (double)cv;
-        if (resync) {
-            const double cyc = jb.freq * ((double)t * inv_fs);
-            sincospi(2.0 * (cyc - floor(cyc)), &ci, &cr);
-        } else {
-            const double nr = cr * wr - ci * wi;
-            ci = cr * wi + ci * wr;
-            cr = nr;
-        }
-        sr += x * cr - xq * ci;
-        si += x * ci + xq * cr;
-    }
-    s_r[threadIdx.x] = sr;
-    s_i[threadIdx.x] = si;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            s_r[threadIdx.x] += s_r[threadIdx.x + s];
-            s_i[threadIdx.x] += s_i[threadIdx.x + s];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[jx * gridDim.y + blockIdx.y] = make_double2(s_r[0], s_i[0]);
-    __syncthreads();  // s_r / s_i are re-used by the next job of this workgroup
-    }
-}
-
-// The same sums for up to kCorrFreqs carrier frequencies that share a job's samples and code (the fine-Doppler search:
-// 17 frequencies 25 Hz apart per (PRN, segment, component) at B2a, 5 at B1C).  One frequency per job made every thread a chain
-// of dependent byte loads per frequency; here a sample and its code value are loaded once and every frequency's phasor is
-// advanced beside the others (exact phasor every 64th step and at the circular wrap, constant-angle rotation in between; up to
-// round 4 every 16th step like k_corr_f64: the sums differ from that kernel's at the 1e-15 level and only rank frequencies).
-// out[(job * slices + slice) * kCorrFreqs + f]
-__global__ __launch_bounds__(256) void k_corr_f64_multi(SampleView sig, long n_circ, const int8_t *__restrict__ codes,
-                                                        long code_stride, double inv_fs, const CorrJob *__restrict__ jobs,
-                                                        double2 *__restrict__ out) {
-    constexpr int FM = kCorrFreqs;
-    const CorrJob jb = jobs[blockIdx.x];
-    const int nf = jb.nf;
-    if (nf <= 0) return;  // a place-holder job of the device refinement chain (PRN below the threshold): workgroup-uniform
-    const long slice = ((jb.len + gridDim.y - 1) / gridDim.y + 255) & ~255L;
-    const long n_lo = (long)blockIdx.y * slice, n_hi = n_lo + slice < jb.len ? n_lo + slice : jb.len;
-    double sr[FM], si[FM], wr[FM], wi[FM], cr[FM], ci[FM];
-    // the per-step rotation of each frequency is the same for every thread: FM lanes evaluate it, LDS hands it round
-    // (round 5: every thread called the f64 sincospi FM times for it -- a quarter of the kernel's 24 calls per thread)
-    __shared__ double s_wr[FM], s_wi[FM];
-    if ((int)threadIdx.x < FM) {
-        const int f = (int)threadIdx.x;
-        const double dcyc = (f < nf ? jb.fr[f] : 0.0) * ((double)blockDim.x * inv_fs);
-        sincospi(2.0 * (dcyc - floor(dcyc)), &s_wi[f], &s_wr[f]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int f = 0; f < FM; ++f) {
-        sr[f] = si[f] = 0.0;
-        cr[f] = 1.0, ci[f] = 0.0;
-        wr[f] = s_wr[f], wi[f] = s_wi[f];
-    }
-    int it = 0;
-    const long cbase = ((long)jb.slot * 2 + jb.mode) * code_stride + (jb.mode ? jb.code_k0 : 0);
-    for (long n = n_lo + threadIdx.x; n < n_hi; n += blockDim.x, ++it) {
-        long a = jb.start + n;
-        long t = n;
-        bool resync = (it & 63) == 0;  // (exact phasor every 64th step: 64 rotations carry ~7e-15, and these sums only rank frequencies)
-        if (jb.circ) {
-            if (a >= n_circ) {
-                resync = resync || (a - (long)blockDim.x < n_circ);
-                a -= n_circ;
-            }
-            t = a;
-        }
-        BDS_DASSERT(n >= 0 && (jb.mode ? jb.code_k0 + n : n) < code_stride && jb.slot >= 0 && jb.slot < 2 * BDS_MAX_PRN);
-        const int8_t cv = codes[cbase + n];
-        const double2 xv = sig.load(a);
-        const double x = (xv.x - jb.mean) * (double)cv;
-        const double xq = (xv.y - jb.mean_q) * (double)cv;
-#pragma unroll
-        for (int f = 0; f < FM; ++f) {
-            if (f < nf) {
-                if (resync) {
-                    const double cyc = jb.fr[f] * ((double)t * inv_fs);
-                    sincospi(2.0 * (cyc - floor(cyc)), &ci[f], &cr[f]);
-                } else {
-                    const double nr = cr[f] * wr[f] - ci[f] * wi[f];
-                    ci[f] = cr[f] * wi[f] + ci[f] * wr[f];
-                    cr[f] = nr;
-                }
-                sr[f] += x * cr[f] - xq * ci[f];
-                si[f] += x * ci[f] + xq * cr[f];
-            }
-        }
-    }
-    __shared__ double s_r[256], s_i[256];
-#pragma unroll
-    for (int f = 0; f < FM; ++f) {
-        if (f >= nf) break;
-        __syncthreads();
-        s_r[threadIdx.x] = sr[f];
-        s_i[threadIdx.x] = si[f];
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) {
-                s_r[threadIdx.x] += s_r[threadIdx.x + s];
-                s_i[threadIdx.x] += s_i[threadIdx.x + s];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[((long)blockIdx.x * gridDim.y + blockIdx.y) * FM + f] = make_double2(s_r[0], s_i[0]);
-    }
-}
-
 }  // namespace bds
+
+#include "bds_acq_corr.h"  // CorrJob, k_corr<NC, FM, KIND>: the f64 coherent sums

@@ -43,11 +43,12 @@ struct RefPrn {  // per PRN of the run
     int flags;
     float thr, max_of;    // sieve threshold and sieve maximum of the PRN
     float thr2, max2;     // ... of the second-peak pass
-    int pad;
+    int fine_job0;        // first of this PRN's fine-search jobs in the (compact) job list
 };
 
 struct RefGlobal {
-    int ncand, pad0;     // candidates of the coarse refinement
+    int ncand;           // candidates of the coarse refinement
+    int nfine_units;     // fine-search units (jobs / components) of the detected PRNs: the list holds no place-holders
     int ncand2, pad1;    // ... of the B2a second peak
     int flags;
     int n_extra, n_extra2;  // list lengths as the column pass left them (may exceed the capacity: overflow)
@@ -251,8 +252,9 @@ __global__ void k_ref_second_setup(RefParams p, RefPrn *__restrict__ prn, const 
 }
 
 // threshold decision and the jobs of the fine-Doppler search, at fixed places: PRN pi owns jobs
-//   B1C [pi][comp][chunk], B2a [pi][segment][comp][chunk]   (chunk = up to kCorrFreqs frequencies 25 Hz apart)
-// with nf = 0 for a PRN below the threshold (k_corr_f64_multi skips those).  One workgroup (64 threads) per PRN: thread 0
+//   B1C [pi][chunk][comp], B2a [pi][segment][chunk][comp]   (chunk = up to kCorrFreqs frequencies 25 Hz apart; the components
+//   of a chunk are adjacent: k_corr sums them in one pass)
+// with nf = 0 for a PRN below the threshold (k_corr skips those).  One workgroup (64 threads) per PRN: thread 0
 // decides, the DC of the B1C block is summed by all lanes, every thread writes its share of the jobs.
 __global__ __launch_bounds__(64) void k_ref_fine_jobs(RefParams p, RefPrn *__restrict__ prn, const int *__restrict__ prn_of, SampleView sig,
                                                       const double *__restrict__ prefix_c, const double *__restrict__ prefix_cq,
@@ -262,9 +264,8 @@ __global__ __launch_bounds__(64) void k_ref_fine_jobs(RefParams p, RefPrn *__res
     const bool b1c = p.signal == BDS_SIGNAL_B1C;
     const int nseg = b1c ? 1 : p.fineNoncoh, ncp = b1c ? p.ncomp : 2;
     const int per = nseg * ncp * p.nchunk;
-    CorrJob *const mine = jobs + (size_t)pi * per;
     __shared__ long s_cp;
-    __shared__ int s_ok;
+    __shared__ int s_ok, s_job0;
     if (lane == 0) {
         long cp = r.codePhase;
         if (b1c && cp + p.spc - 1 > p.n_samples) cp -= p.spc;  // B1C :239-241
@@ -282,11 +283,16 @@ __global__ __launch_bounds__(64) void k_ref_fine_jobs(RefParams p, RefPrn *__res
             r.flags |= fl;
             atomicOr(&g->flags, fl);
         }
-        s_cp = cp, s_ok = ok ? 1 : 0;
+        // only a detected PRN gets jobs: the list is compact (its order follows the atomic, a job's sums do not depend on its place)
+        const int job0 = ok ? atomicAdd(&g->nfine_units, per / ncp) * ncp : 0;
+        r.fine_job0 = job0;
+        s_cp = cp, s_ok = ok ? 1 : 0, s_job0 = job0;
     }
     __syncthreads();
     const long cp = s_cp;
     const bool ok = s_ok != 0;
+    if (!ok) return;  // (workgroup-uniform)
+    CorrJob *const mine = jobs + s_job0;
     double mean = 0.0, mean_q = 0.0;
     if (ok && b1c) {
         // DC of the block codePhase .. codePhase + spc - 1: exact integer sums (int8 data) from the coarse prefix table
@@ -311,10 +317,10 @@ __global__ __launch_bounds__(64) void k_ref_fine_jobs(RefParams p, RefPrn *__res
         }
     }
     if (lane == 0) r.mean = mean, r.mean_q = mean_q;
-    const double fb = ref_bin_freq(p, r.b);
+    const double fb = ref_bin_freq(p, prn[pi].b);
     const double f_lo = b1c ? __dsub_rn(fb, p.step) : __dsub_rn(fb, __ddiv_rn(p.step, 2.0));  // B1C :282-283, B2a :300-301
     for (int i = lane; i < per; i += 64) {
-        const int ch = i % p.nchunk, comp = (i / p.nchunk) % ncp, seg = i / (p.nchunk * ncp);
+        const int comp = i % ncp, ch = (i / ncp) % p.nchunk, seg = i / (p.nchunk * ncp);
         CorrJob j{};
         j.start = cp - 1 + (long)seg * p.spc;
         j.len = p.spc;
@@ -341,13 +347,13 @@ __global__ __launch_bounds__(256) void k_ref_fine_pick(RefParams p, RefPrn *__re
     if (!r.detected || (r.flags & kRefFineRange)) return;  // (workgroup-uniform)
     const bool b1c = p.signal == BDS_SIGNAL_B1C;
     const int nseg = b1c ? 1 : p.fineNoncoh, ncp = b1c ? p.ncomp : 2;
-    const size_t job0 = (size_t)pi * nseg * ncp * p.nchunk;
+    const size_t job0 = (size_t)r.fine_job0;
     extern __shared__ double s_mag[];  // [seg][comp][kf]
     double *const s_val = s_mag + nseg * ncp * p.nfine;  // [kf]
     const int total = nseg * ncp * p.nfine;
     for (int i = tid; i < total; i += 256) {
         const int kf = i % p.nfine, comp = (i / p.nfine) % ncp, seg = i / (p.nfine * ncp);
-        const size_t j = job0 + ((size_t)seg * ncp + comp) * p.nchunk + kf / kCorrFreqs;
+        const size_t j = job0 + ((size_t)seg * p.nchunk + kf / kCorrFreqs) * ncp + comp;
         double2 acc = make_double2(0.0, 0.0);
         for (int k = 0; k < slices; ++k) {
             const double2 t = jobout[(j * slices + k) * kCorrFreqs + kf % kCorrFreqs];

@@ -83,7 +83,7 @@ class AcqJob(C.Structure):
 
 EXPORTS = [
     "bds_create", "bds_destroy", "bds_reload_tuning", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_build_flags", "bds_gen_code", "bds_acquire",
-    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_acq_candidates", "bds_get_timing",
+    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_acq_candidates", "bds_acq_coherent_sums", "bds_get_timing",
     "bds_track", "bds_track_mem", "bds_track_loaded_bytes", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
     "bds_calc_weighing_factor", "bds_pre_run", "bds_pre_run_device", "bds_acquire_track",
     "bds_multi_create", "bds_multi_destroy", "bds_multi_last_error", "bds_multi_size", "bds_multi_ctx",
@@ -143,6 +143,8 @@ def lib():
     L.bds_acq_grid.restype, L.bds_acq_grid.argtypes = i32, [vp, C.POINTER(C.c_float), _IP, i32]
     L.bds_acq_candidates.restype, L.bds_acq_candidates.argtypes = i32, [vp, i32, _IP, C.POINTER(C.c_int64), i32]
     L.bds_acq_peaks.restype, L.bds_acq_peaks.argtypes = i32, [vp, i32, _DP, _DP, _IP]
+    L.bds_acq_coherent_sums.restype = i32
+    L.bds_acq_coherent_sums.argtypes = [vp, SP, i32, C.c_int64, _DP, i32, i32, _DP]
     L.bds_get_timing.restype, L.bds_get_timing.argtypes = i32, [vp, C.POINTER(Timing)]
     L.bds_track.restype = i32
     L.bds_track.argtypes = [vp, SP, C.c_char_p, i32, C.POINTER(Channel), C.POINTER(TrackOut)]
@@ -473,6 +475,17 @@ class Context:
         self._check(self._lib.bds_acq_peaks(self._h, max_prn, pk.ctypes.data_as(_DP), dn.ctypes.data_as(_DP),
                                             fb.ctypes.data_as(_IP)))
         return pk, dn, fb
+
+    def acq_coherent_sums(self, settings, prn, phase, freqs, mode):
+        """f64 coherent sums of caller-chosen cells (bds_acq_coherent_sums): complex array, mode 0 [nf, ncomp],
+        modes 1 / 2 [segments * components, nf]."""
+        cs = pack_settings(settings)
+        fr = np.ascontiguousarray(freqs, dtype=np.float64)
+        out = np.zeros(2 * 64 * 2 * max(len(fr), 1) + 16)
+        n = self._check(self._lib.bds_acq_coherent_sums(self._h, C.byref(cs), int(prn), int(phase), fr.ctypes.data_as(_DP), len(fr),
+                                                        int(mode), out.ctypes.data_as(_DP)))
+        z = out[:2 * n:2] + 1j * out[1:2 * n:2]
+        return z.reshape(len(fr), -1) if mode == 0 else z.reshape(-1, len(fr))  # modes 1 / 2: rows = (segment, component)
 
     def timing(self) -> dict:
         t = Timing()

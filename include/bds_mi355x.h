@@ -216,13 +216,23 @@ BDS_API int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *prn_
  * bin, the maximum of results(bin,:) (fp32 search value) and its 1-based lag.
  * row_max/row_arg: [n_prn * n_bins].  Returns n_prn*n_bins or <0. */
 BDS_API int bds_acq_grid(bds_ctx *ctx, float *row_max, int32_t *row_arg, int cap);
-/* Peak / second-peak (B2a) or peak / sigPower (B1C) of the last run, per PRN slot:
- * peak[max_prn], denom[max_prn], fbin[max_prn] (1-based frequency bin). */
 /* Diagnostics of the sieve: the (Doppler bin, code phase) cells of `prn` the last bds_acq_run re-evaluated in
  * f64 (1-based, like the reference's indices into results(bin, codePhase)).  Returns their number (may exceed
  * cap).  Tests use it to check that every cell within the sieve tolerance of the maximum was refined. */
 BDS_API int bds_acq_candidates(bds_ctx *ctx, int prn, int32_t *bin, int64_t *lag, int cap);
+/* Peak / second-peak (B2a) or peak / sigPower (B1C) of the last run, per PRN slot:
+ * peak[max_prn], denom[max_prn], fbin[max_prn] (1-based frequency bin). */
 BDS_API int bds_acq_peaks(bds_ctx *ctx, int max_prn, double *peak, double *denom, int32_t *fbin);
+/* Check entry: the f64 coherent sums the decisions rest on, for caller-chosen cells of the block loaded by the last
+ * bds_acq_load / bds_acq_run (csrc/bds_acq_corr.h), as interleaved (re, im) pairs.  Returns the number of pairs or < 0.
+ *   mode 0  coarse cell (B2a/acquisition.m:194-209, B1C/acquisition.m:198-219): for each of freqs[0 .. nf) and each component,
+ *           sum_n x[(phase-1+n) mod N] code_c(n) exp(+j 2 pi f t/fs), t = the wrapped sample index:  out[(f*ncomp + c)*2]
+ *   mode 1  fine-search block starting at code phase `phase` (B2a :287-316: fineNoncoh segments, both components, long code;
+ *           B1C :253-287: one code period, DC removed), every frequency of freqs[] in the multi-frequency pass:
+ *           out[((seg*ncomp + c)*nf + f)*2]
+ *   mode 2  the same sums, one frequency per pass (what mode 1 must agree with to rounding) */
+BDS_API int bds_acq_coherent_sums(bds_ctx *ctx, const bds_settings *s, int prn, int64_t phase, const double *freqs, int nf, int mode,
+                                  double *out);
 BDS_API int bds_get_timing(bds_ctx *ctx, bds_timing *t);
 
 /* ---- multi-device acquisition -------------------------------------------

@@ -164,3 +164,11 @@ def test_settings_fields_are_required_not_defaulted():
     d = dict(s2.__dict__)
     assert "acqCohT" not in d and "FEBW" not in d
     assert native.pack_settings(s2.copy(dataType="int16")).dataType == 1  # rejected by the library (BDS_ERR_UNSUPPORTED)
+
+
+def test_context_mirror_has_a_method_per_entry_it_wraps():
+    """the ctypes mirror keeps one method per native entry the tests and tools call (an edit that drops one -- timing() once --
+    must fail here, on CPU, not on the GPU box)"""
+    for m in ("acq_load", "acq_prepare", "acq_run", "acq_grid", "acq_peaks", "acq_candidates", "acq_coherent_sums", "timing",
+              "track", "reload_tuning", "device_name"):
+        assert callable(getattr(native.Context, m, None)), m

@@ -8,9 +8,9 @@ The record is made of 20-ms blocks that carry the 12 satellites seamlessly and o
     absoluteSample[k+1] - absoluteSample[k] == ceil((codeLength - remCodePhase[k]) / (codeFreq[k] / fs))  (WB_tracking.m:226-233;
     codeFreq[k] is stored before the epoch's update, :387-389);
   * 12 of 12 loops are locked over the second half and the C/N0 estimates average the injected 47 dB-Hz to within 1 dB;
-  * the first 3 epochs equal the float64 oracle run on the head of the same record (tolerances of SURVEY.md section 8d:
-    I/Q 1e-4 of |P|, carrFreq 1e-3 Hz, codeFreq 1e-6 Hz, absoluteSample exact -- before the first ceil() flip, see
-    tests/test_track_long_gpu.py for what holds after it)."""
+  * the first 200 epochs of three channels equal the float64 oracle run on the head of the same record (tolerances of SURVEY.md section 8d:
+    I/Q 1e-4 of |P|, carrFreq 1e-3 Hz, codeFreq 1e-6 Hz, absoluteSample exact; the strict default correlator has no ceil() flip, see
+    tests/test_track_long_gpu.py)."""
 import os
 
 import numpy as np
@@ -64,11 +64,13 @@ def test_cfg4_twelve_channels_36_seconds_from_a_file(ctx, tmp_path):
 
 
 def test_cfg4_head_against_the_oracle(ctx):
-    """First 3 epochs of the cfg4 record, three of its channels, vs the float64 oracle."""
+    """First 200 epochs (2 s of signal at 99.375 MS/s) of the cfg4 record, three of its channels, vs the float64 oracle at SURVEY 8d:
+    far beyond where the fp32 carrier of rounds 2-4 left the oracle's trajectory (its first ceil() flip came at epoch 142 on the
+    long fixture); the strict default holds every epoch (~80 s of oracle time)."""
     from oracle import tracking as otrk
 
     base = bds_amd.init_settings_b1c(samplingFreq=99.375e6, IF=14.58e6, acqSatelliteList=list(range(1, 64)), acqCohT=10, pilotACQflag=1)
-    s, ch, blocks, order, shift, n, spc = bench.cfg4_record(base, 3)
+    s, ch, blocks, order, shift, n, spc = bench.cfg4_record(base, 200)
     x = bench.record_bytes(blocks, order, shift, n)
     sub = [ch[0], ch[5], ch[11]]
     ref, _ = otrk.tracking(otrk.RawFile(x), sub, s.copy(numberOfChannels=3), mode="WB")
