@@ -42,6 +42,31 @@ static const double kPi = 3.14159265358979323846;
 #include "bds_acq_plan.h"  // Plan2D, choose_lengths, plan_build, the kernels' constant tables
 
 // ---------------------------------------------------------------------------------------
+// Events of a run, kept in the context across runs (a run records ~100 of them -- the timing triples of the sampled launch
+// pairs -- and creating / destroying them was host time of every call): make() hands out the next one of its kind, rewind()
+// starts over.
+struct EventPool {
+    std::vector<hipEvent_t> timed, untimed;
+    size_t nt = 0, nu = 0;
+    void rewind() { nt = nu = 0; }
+    hipError_t make(hipEvent_t *e, unsigned flags = 0) {
+        std::vector<hipEvent_t> &v = flags ? untimed : timed;
+        size_t &n = flags ? nu : nt;
+        if (n == v.size()) {
+            hipEvent_t ne;
+            const hipError_t rc_ = flags ? hipEventCreateWithFlags(&ne, flags) : hipEventCreate(&ne);
+            if (rc_ != hipSuccess) return rc_;
+            v.push_back(ne);
+        }
+        *e = v[n++];
+        return hipSuccess;
+    }
+    ~EventPool() {
+        for (hipEvent_t e : timed) (void)hipEventDestroy(e);
+        for (hipEvent_t e : untimed) (void)hipEventDestroy(e);
+    }
+};
+
 struct PrnResult {
     double peak = 0, denom = 0;
     int fbin = 0;  // 1-based
@@ -76,6 +101,7 @@ struct AcqState {
     std::vector<double> h_prefix;         // ... its prefix sums
     std::vector<double> h_prefix_q;       // ... of the imaginary part
     bool cplx = false;              // longSignal = I + 1i*Q (postProcessing.m:92-96)
+    EventPool events;               // timing / ordering events of a run, re-used across runs
     double sample_re(long i) const { return skind >= kF64 ? h_re[(size_t)i] : (double)h_s8[(size_t)(cplx ? 2 * i : i)]; }
     double sample_im(long i) const { return !cplx ? 0.0 : skind >= kF64 ? h_im[(size_t)i] : (double)h_s8[(size_t)(2 * i + 1)]; }
     // sum of the first i samples (I part / Q part): for an int8 record the same integer, hence the same f64, in any order of adding
@@ -591,7 +617,7 @@ static int condition_block(bds_ctx *ctx, AcqState &a, const ResamplePlan &r, lon
                        (const double *)a.d_fir, kTaps, 1, a.d_ffa);
     const long sig_len = (long)std::floor((double)(n_in - 1) / r.old_fs * r.new_fs);  // :107
     if (sig_len < 1) return fail(ctx, BDS_ERR_ARG, "resampled longSignal is empty");
-    if ((rc = ensure(ctx, &a.d_sig64, &a.sig64_cap, (size_t)sig_len * NCH))) return rc;
+    if ((rc = ensure(ctx, &a.d_sig64, &a.sig64_cap, (size_t)(sig_len + 4) * NCH))) return rc;  // (+4 samples: k_corr reads whole groups of four, bds_acq_corr.h)
     hipLaunchKernelGGL(k_ff_decimate<NCH>, grid, blk, 0, st(ctx), (const double *)a.d_ffa, kFact, sig_len, r.new_fs,
                        r.old_fs, a.d_sig64);
     BDS_HIP(ctx, hipGetLastError());
@@ -855,19 +881,6 @@ namespace {
 constexpr int kExtraCap = 1 << 22;  // entries of the sieve's candidate list (wave-private pass) / overflow list (tile pass)
 constexpr int kSamples = 32;        // launch pairs of a run bracketed by timing events
 
-// events of one run; released on every exit path
-struct EventPool {
-    std::vector<hipEvent_t> all;
-    hipError_t make(hipEvent_t *e, unsigned flags = 0) {
-        const hipError_t rc_ = flags ? hipEventCreateWithFlags(e, flags) : hipEventCreate(e);
-        if (rc_ == hipSuccess) all.push_back(*e);
-        return rc_;
-    }
-    ~EventPool() {
-        for (hipEvent_t e : all) (void)hipEventDestroy(e);
-    }
-};
-
 // packed cell maximum -> (value, 0-based lag); nothing searched / nothing written: (-1, -1)
 void unpack_cell(unsigned long long pk, float *v, int *lag) {
     if (pk == 0) {
@@ -908,7 +921,7 @@ struct AcqRun {
     long n_pairs_total = 0, cells_per_pair = 0;
     SieveOut so{};
     // timing
-    EventPool evp;
+    EventPool &evp;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     hipEvent_t sa[kSamples], sb[kSamples], sm[kSamples];
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
@@ -922,7 +935,7 @@ struct AcqRun {
     std::vector<std::vector<Cell>> cells;
     std::vector<PrnResult> res;
 
-    AcqRun(bds_ctx *c, AcqState &st_, const bds_settings *s_) : ctx(c), a(st_), s(s_) {}
+    AcqRun(bds_ctx *c, AcqState &st_, const bds_settings *s_) : ctx(c), a(st_), s(s_), evp(st_.events) { evp.rewind(); }
     hipStream_t stream() const { return st(ctx); }
     double bin_freq(int b) const { return f0 + s->acqStep * (double)b; }
     int redo(int code, const char *reason) {
