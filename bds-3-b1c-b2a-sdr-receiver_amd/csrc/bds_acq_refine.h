@@ -251,11 +251,13 @@ __global__ void k_ref_second_setup(RefParams p, RefPrn *__restrict__ prn, const 
     bin[pi] = prn[pi].b;
 }
 
-// threshold decision and the jobs of the fine-Doppler search, at fixed places: PRN pi owns jobs
-//   B1C [pi][chunk][comp], B2a [pi][segment][chunk][comp]   (chunk = up to kCorrFreqs frequencies 25 Hz apart; the components
-//   of a chunk are adjacent: k_corr sums them in one pass)
-// with nf = 0 for a PRN below the threshold (k_corr skips those).  One workgroup (64 threads) per PRN: thread 0
-// decides, the DC of the B1C block is summed by all lanes, every thread writes its share of the jobs.
+// threshold decision and the jobs of the fine-Doppler search.  A detected PRN appends its jobs
+//   B1C [chunk][comp], B2a [segment][chunk][comp]   (chunk = up to kCorrFreqs frequencies 25 Hz apart; the components of a
+//   chunk are adjacent: k_corr sums them in one pass)
+// to a compact list (RefGlobal::nfine_units counts its units, RefPrn::fine_job0 is the PRN's first job; the order of the PRNs in
+// the list follows the atomic, a job's sums do not depend on its place); a PRN below the threshold lists nothing.  One
+// workgroup (64 threads) per PRN: thread 0 decides, the DC of the B1C block is summed by all lanes, every thread writes its
+// share of the jobs.
 __global__ __launch_bounds__(64) void k_ref_fine_jobs(RefParams p, RefPrn *__restrict__ prn, const int *__restrict__ prn_of, SampleView sig,
                                                       const double *__restrict__ prefix_c, const double *__restrict__ prefix_cq,
                                                       CorrJob *__restrict__ jobs, RefGlobal *__restrict__ g) {

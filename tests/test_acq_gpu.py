@@ -382,3 +382,50 @@ def test_device_refinement_chain_equals_the_host_path(case, monkeypatch):
         assert np.array_equal(u, v)
     for u, v in zip(out["0"][2], out["1"][2]):
         assert len(u) > 0 and np.array_equal(u, v)
+
+
+def test_device_chain_hands_over_when_the_band_holds_more_candidates_than_it_keeps(monkeypatch):
+    """The device chain keeps 16 384 candidates per stage.  With the tolerance forced to 40 % the two absent PRNs of this block
+    alone put ~40 000 cells into the band (a noise surface of 5e6 Rayleigh cells: exp(-5.5) of them exceed 0.6 of the maximum):
+    the chain must flag the overflow and hand the run to the host path (refine_path 0), whose results equal the default run's."""
+    s, x, _ = medium_b2a()
+    base = bds_amd.acquisition(x, s, verbose=False)
+    monkeypatch.setenv("BDS_ACQ_KDELTA", "0.4")
+    monkeypatch.setenv("BDS_VERBOSE", "1")
+    c = bds_amd.native.Context(0)
+    try:
+        c.acq_load(s, x)
+        c.acq_prepare(s)
+        carr, cph, pm, _ = c.acq_run(s)
+        tm = c.timing()
+        ncand = sum(len(c.acq_candidates(p)) for p in (5, 9, 19, 33))
+    finally:
+        c.close()
+    assert ncand > 16384, ncand
+    assert tm["refine_path"] == 0, tm
+    np.testing.assert_array_equal(carr, base.carrFreq)
+    np.testing.assert_array_equal(cph, base.codePhase)
+    np.testing.assert_allclose(pm, base.peakMetric, rtol=1e-12)
+
+
+def test_b2a_above_the_rate_the_register_column_pass_covers(ctx):
+    """the 80 x 4096 plan's register column pass forms output rows 0 .. 48 only, i.e. lags below 200 704 --
+    enough for N = 198 750 at 99.375 MS/s, not for N = 210 000 at 105 MS/s, where its cost bonus used to pick it all the same and
+    lags >= 200 704 were silently never searched.  Here a satellite sits at 0.97 of a code period, so that its second-period
+    peak (lag ~ 206 850) lies beyond row 48: the plan must be another one and the results the oracle's."""
+    from helpers import spc_of
+    from bds_amd import synth
+    s = bds_amd.init_settings_b2a(samplingFreq=105.0e6, IF=14.58e6, acqSatelliteList=[19, 20, 21], acqSearchBand=800, acqStep=400,
+                                  fineNoncoh=3)
+    spc = spc_of(s)
+    assert 2 * spc == 210000
+    sats = [synth.Sat(19, 310.0, 0.97 * spc, 1.1, 47.0), synth.Sat(20, -200.0, 0.31 * spc, 0.3, 46.0)]
+    x = synth.make_if(s, sats, 6 * spc, seed=4105)
+    ref, got = _compare(s, x, ctx, oacq.acquisition_b2a)
+    tm = ctx.timing()
+    assert tm["plan_l1"] != 80 and tm["n_circ"] == 210000, tm
+    assert got.carrFreq[18] != 0 and got.carrFreq[19] != 0
+    # and the plan is still the small one where it does cover every lag (cfg2's rate)
+    s2, x2, _ = cfg1_b2a()
+    bds_amd.acquisition(x2, s2, verbose=False)
+    assert ctx.timing()["plan_l1"] == 80
