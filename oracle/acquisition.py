@@ -126,10 +126,13 @@ def b2a_coarse_rows(long_signal, settings, prn, bins=None):
         yield b, np.abs(_ifft(x * cd)) + np.abs(_ifft(x * cp))  # :204-209
 
 
-def acquisition_b2a(long_signal, settings, diag=None):
+def acquisition_b2a(long_signal, settings, diag=None, coarse=None):
     """acqResults = acquisition(longSignal, settings)   (B2a/acquisition.m:1).
 
     ``diag`` (optional dict) receives per-PRN intermediate values for tests.
+    ``coarse`` (optional): another evaluator of the Doppler rows -- ``coarse(long_signal, settings, prn)`` returning
+    ``(row_max, row_arg0, col_max, row_of)`` with ``row_of(b)`` = results(b+1, :) -- e.g. the C restatement
+    (``oracle.cfast.backend()``); everything after the rows stays this function's.
     """
     long_signal, settings, old = resample_condition(long_signal, settings)
     spc = codes.samples_per_code(settings)
@@ -145,18 +148,24 @@ def acquisition_b2a(long_signal, settings, diag=None):
         row_arg = np.zeros(len(frq), dtype=np.int64)
         col_max = np.full(n, -np.inf)
         best_row = None
-        for b, row in b2a_coarse_rows(long_signal, settings, prn):
-            row_arg[b] = int(np.argmax(row))
-            row_max[b] = row[row_arg[b]]
-            np.maximum(col_max, row, out=col_max)
-            if best_row is None or row_max[b] > best_row[0]:
-                best_row = (row_max[b], b, row)
+        if coarse is not None:
+            row_max, row_arg, col_max, row_of = coarse(long_signal, settings, prn)
+        else:
+            for b, row in b2a_coarse_rows(long_signal, settings, prn):
+                row_arg[b] = int(np.argmax(row))
+                row_max[b] = row[row_arg[b]]
+                np.maximum(col_max, row, out=col_max)
+                if best_row is None or row_max[b] > best_row[0]:
+                    best_row = (row_max[b], b, row)
         # :218-221   max(max(results,[],2)) -> first row; max(max(results)) -> first column
         fbin = int(np.argmax(row_max))  # 0-based
         code_phase = int(np.argmax(col_max)) + 1  # 1-based
         peak = float(col_max[code_phase - 1])
-        row = best_row[2]
-        assert best_row[1] == fbin
+        if coarse is not None:
+            row = row_of(fbin)
+        else:
+            row = best_row[2]
+            assert best_row[1] == fbin
         # :224-249  second peak in the same bin
         e1 = code_phase - samples2chip
         e2 = code_phase + samples2chip
@@ -237,8 +246,8 @@ def b1c_coarse_rows(long_signal, settings, prn, bins=None):
         yield b, row
 
 
-def acquisition_b1c(long_signal, settings, diag=None):
-    """acqResults = acquisition(longSignal, settings)   (B1C/acquisition.m:1)."""
+def acquisition_b1c(long_signal, settings, diag=None, coarse=None):
+    """acqResults = acquisition(longSignal, settings)   (B1C/acquisition.m:1).  ``coarse``: see acquisition_b2a."""
     long_signal, settings, old = resample_condition(long_signal, settings)
     spc, x_len, n = _b1c_sizes(settings)
     ts = 1.0 / settings.samplingFreq
@@ -251,10 +260,13 @@ def acquisition_b1c(long_signal, settings, diag=None):
         row_max = np.full(len(frq), -np.inf)
         row_arg = np.zeros(len(frq), dtype=np.int64)
         col_max = np.full(n, -np.inf)
-        for b, row in b1c_coarse_rows(long_signal, settings, prn):
-            row_arg[b] = int(np.argmax(row))
-            row_max[b] = row[row_arg[b]]
-            np.maximum(col_max, row, out=col_max)
+        if coarse is not None:
+            row_max, row_arg, col_max, _ = coarse(long_signal, settings, prn)
+        else:
+            for b, row in b1c_coarse_rows(long_signal, settings, prn):
+                row_arg[b] = int(np.argmax(row))
+                row_max[b] = row[row_arg[b]]
+                np.maximum(col_max, row, out=col_max)
         fbin = int(np.argmax(row_max))  # :229
         code_phase = int(np.argmax(col_max)) + 1  # :232
         peak = float(col_max[code_phase - 1])
@@ -294,9 +306,9 @@ def acquisition_b1c(long_signal, settings, diag=None):
     return acq
 
 
-def acquisition(long_signal, settings, diag=None):
+def acquisition(long_signal, settings, diag=None, coarse=None):
     """Dispatch on settings.signal ('B1C' | 'B2A') -- the reference keeps one
     acquisition.m per receiver directory."""
     if str(settings.signal).upper() == "B1C":
-        return acquisition_b1c(long_signal, settings, diag)
-    return acquisition_b2a(long_signal, settings, diag)
+        return acquisition_b1c(long_signal, settings, diag, coarse)
+    return acquisition_b2a(long_signal, settings, diag, coarse)

@@ -107,6 +107,76 @@ def test_b1c_full_grid_absent_prn_against_the_whole_oracle_matrix(ctx):
     assert res.carrFreq[prn - 1] == 0 and res.codePhase[prn - 1] == 0
 
 
+def _usable_cpus():
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(np.ceil(float(q) / float(per)))))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
+def test_b1c_full_grid_many_prns_against_the_c_oracle(ctx):
+    """BASELINE.json configs[2] against the oracle on WHOLE Doppler grids of many PRNs: the ten injected satellites and six absent
+    PRNs by default, all 63 with BDS_TEST_ALL_PRNS=1 (the log of such a run is committed under profiles/).  The rows come from the
+    compiled restatement (oracle/c/acq_oracle.c, OpenMP over the bins: seconds per PRN where the NumPy rows take minutes; the two
+    are held together by tests/test_oracle_c.py), everything after the rows from the NumPy oracle (B1C/acquisition.m:229-307).
+    Per PRN: all 201 sieve row maxima within kDelta / 2, the f64 peak to 1e-9, bin / codePhase / carrFreq exact, peakMetric 1e-9."""
+    import os
+
+    from oracle import cfast
+
+    cfast.build()
+    s, x, sats, _ = bench.build_workload("b1c")
+    res = bds_amd.acquisition(x, s, verbose=False)
+    tm = ctx.timing()
+    rm, ra = ctx.acq_grid(63, 201)
+    pk, dn, fb = ctx.acq_peaks(63)
+    tol = {0: 1e-5, 1: 1e-3}[tm["half_storage"]]  # kDelta / 2 of the mode
+    present = [sat.prn for sat in sats]
+    prns = list(range(1, 64)) if os.environ.get("BDS_TEST_ALL_PRNS") else present + [2, 3, 30, 45, 60, 63]
+    xf = x[:3 * 993750 + 16].astype(np.float64)  # (acquisition touches N + spc - 1 samples, SURVEY Appendix B)
+    rows = {}
+
+    def coarse(long_signal, settings, prn):
+        out = cfast.coarse_rows(long_signal, settings, prn, threads=_usable_cpus())
+        rows[prn] = out
+        return out[0], out[1], out[2], None
+
+    ref = oacq.acquisition_b1c(xf, s.copy(acqSatelliteList=prns), coarse=coarse)
+    worst = 0.0
+    for prn in prns:
+        row_max, row_arg, col_max, _ = rows[prn]
+        np.testing.assert_allclose(rm[prn - 1], row_max, rtol=tol)
+        worst = max(worst, float(np.max(np.abs(rm[prn - 1] - row_max)) / row_max.max()))
+        assert fb[prn - 1] == int(np.argmax(row_max)) + 1
+        np.testing.assert_allclose(pk[prn - 1], col_max.max(), rtol=1e-9)
+        assert res.codePhase[prn - 1] == ref.codePhase[prn - 1] and res.carrFreq[prn - 1] == ref.carrFreq[prn - 1], prn
+        np.testing.assert_allclose(res.peakMetric[prn - 1], ref.peakMetric[prn - 1], rtol=1e-9)
+        assert (ref.carrFreq[prn - 1] != 0) == (prn in present)
+    print(f"cfg3 vs the C oracle: {len(prns)} PRNs x 201 bins, worst sieve row maximum error {worst:.3e} of the PRN maximum "
+          f"(kDelta / 2 = {tol:g})")
+
+
+def test_b2a_full_grid_every_prn_against_the_c_oracle(ctx):
+    """BASELINE.json configs[1], ALL 63 PRNs x 26 bins against the oracle (rows from the compiled restatement, the second peak,
+    the threshold and the fine search of B2a/acquisition.m:213-336 from the NumPy oracle): acqResults exact / 1e-6."""
+    from oracle import cfast
+
+    cfast.build()
+    s, x, sats, _ = bench.build_workload("b2a")
+    res = bds_amd.acquisition(x, s, verbose=False)
+    ref = oacq.acquisition_b2a(x.astype(np.float64), s, coarse=cfast.backend(threads=_usable_cpus()))
+    np.testing.assert_array_equal(res.codePhase, ref.codePhase)
+    np.testing.assert_array_equal(res.carrFreq, ref.carrFreq)
+    np.testing.assert_allclose(res.peakMetric, ref.peakMetric, rtol=1e-6)
+    assert set(np.nonzero(ref.carrFreq)[0] + 1) == {sat.prn for sat in sats}
+
+
 def test_argument_errors_are_reported(ctx):
     s = bds_amd.init_settings_b2a(acqSatelliteList=[5])
     x = np.zeros(1000, dtype=np.int8)
