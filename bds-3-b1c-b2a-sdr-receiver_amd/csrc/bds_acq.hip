@@ -131,6 +131,12 @@ struct AcqState {
     std::vector<char> code_have;     // which (slot, mode) tables exist
     char *d_cells = nullptr;         // cell list of the batched second-peak launch
     size_t cells_cap = 0;
+    char *d_mcells = nullptr;        // cell list of the main search of a small grid (all P x D cells in a few launch pairs) ...
+    size_t mcells_cap = 0;
+    std::vector<long> mcells_cs;     // ... and what it holds: uploaded again only when a run's list differs
+    std::vector<int> mcells_bin;
+    std::vector<long> ref_tabs_cs;   // what d_ref_tabs holds (refinement chain: code-spectrum offset and PRN of every searched PRN)
+    std::vector<int> ref_tabs_prn;
     Extra *d_extra = nullptr;        // overflow list of the column pass (bds_acq_f32.h)
     size_t extra_cap = 0;
     int *d_extra_count = nullptr;
@@ -188,7 +194,7 @@ void acq_state_free(AcqState *a) {
     plan_free(a->plan);
     for (void *p : {(void *)a->d_sig, (void *)a->d_prim, (void *)a->d_Cs, (void *)a->d_Xs, (void *)a->d_Bw,
                     (void *)a->d_recs, (void *)a->d_rowmax, (void *)a->d_rowarg, (void *)a->d_jobs, (void *)a->d_codes,
-                    (void *)a->d_jobout, (void *)a->d_sig64, (void *)a->d_ffa, (void *)a->d_ffb, (void *)a->d_fir, (void *)a->d_cells,
+                    (void *)a->d_jobout, (void *)a->d_sig64, (void *)a->d_ffa, (void *)a->d_ffb, (void *)a->d_fir, (void *)a->d_cells, (void *)a->d_mcells,
                     (void *)a->d_extra, (void *)a->d_extra_count, (void *)a->d_cellmax, (void *)a->d_lb, (void *)a->d_ref_zero,
                     (void *)a->d_ref_cand, (void *)a->d_ref_tabs, (void *)a->d_prefix_c, (void *)a->d_prefix_cq, (void *)a->d_extra2})
         if (p) (void)hipFree(p);
@@ -389,7 +395,14 @@ static int forward(bds_ctx *ctx, AcqState &a, Loader ld, int nb, float2 *dst, lo
     dim3 g1(pl.ntiles, nb), g2(pl.L1, nb);
     hipLaunchKernelGGL(k_cols_fwd<Loader>, g1, dim3(pl.nt_cols), pl.lds_cols, st(ctx), pl.p1, pl.twl, pl.L2,
                        pl.logT, pl.Spad, ld, a.d_Bw, pl.L);
-    if (a.half)  // dst counts in stored elements (fp16 complex)
+    if (fast_rows(pl.L2) && !ctx->tune.generic && !ctx->tune.generic_fwd) {
+        // rows of a specialised length under a run-time-plan column pass (the 80 x 4096 plan of cfg2): the compile-time row pass
+        // (first stage from global memory, last stage to the typed store; 2 080 rows of cfg2 in ~25 us against 78 on the run-time engine)
+        if (a.half)
+            launch_rows_fwd_any<__half2>(ctx, st(ctx), pl, nb, (const float2 *)a.d_Bw, (__half2 *)dst, dst_stride, conj_flag, scale, perm);
+        else
+            launch_rows_fwd_any<float2>(ctx, st(ctx), pl, nb, (const float2 *)a.d_Bw, dst, dst_stride, conj_flag, scale, 0);
+    } else if (a.half)  // dst counts in stored elements (fp16 complex)
         hipLaunchKernelGGL(k_rows_fwd_st<__half2>, g2, dim3(pl.nt_rows), pl.lds_rows, st(ctx), pl.p2,
                            (const float2 *)a.d_Bw, pl.L, (__half2 *)dst, dst_stride, conj_flag, scale, perm);
     else
@@ -405,6 +418,7 @@ struct CellList {
     const long *cs = nullptr;    // element offset of its code spectra from the Cs base
     const int4 *rng = nullptr;   // searched lag ranges (lo1, hi1, lo2, hi2)
     int gc = 1;                  // consecutive listed cells that share their code spectra (one row workgroup walks them)
+    const int *src = nullptr;    // 80 x 4096 plan only: the rows of listed cell g already lie at cell index src[g] of Bw -- no row pass
 };
 // where a column pass reports: per-tile records + the overflow list of the sieve
 struct SieveOut {
@@ -533,10 +547,10 @@ static void launch_fast_f(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const
     // unmasked search (one lag range from 0), fp16 storage, two components
     if constexpr (NC == 2 && std::is_same<ST, __half2>::value) {
         if (pl.small) {  // 80 x 4096: wave-private row pass (components interleaved) + one lane per column and component
-            launch_rows_f<4096, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl, true);
+            if (!cl.src) launch_rows_f<4096, NC, ST>(ctx, st_, pl, Xs, G, bin0, Cs, Bw, out_scale, cl, true);
             if (so.mid) (void)hipEventRecord(so.mid, st_);
             const SColsArgs A{(const float2 *)pl.d_tw80, pl.L2, G, Bw, pl.L, w0, w1, lo1, hi1, lo2, hi2, cl.rng, so.cellmax, so.lb, so.lb_div,
-                              so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep};
+                              so.extra, so.extra_count, so.extra_cap, so.cell0, so.keep, cl.src};
             want_lds(ctx, k_cols_small_f<NC>, kSColsLdsBytes);
             hipLaunchKernelGGL((k_cols_small_f<NC>), dim3((unsigned)(G * (pl.L2 / (kSColsNT / 2)))), dim3(kSColsNT), kSColsLdsBytes, st_, A);
             return;
@@ -1173,11 +1187,17 @@ int AcqRun::search() {
                 h_bin[(size_t)pi * D + b] = b;
                 h_cs[(size_t)pi * D + b] = (long)a.cs_slot[prns[pi]] * ncomp * pl.L;
             }
-        if ((rc = ensure(ctx, &a.d_cells, &a.cells_cap, (sizeof(long) + sizeof(int)) * nc_ + 64))) return rc;
-        long *d_cs = (long *)a.d_cells;
+        const char *before = a.d_mcells;
+        if ((rc = ensure(ctx, &a.d_mcells, &a.mcells_cap, (sizeof(long) + sizeof(int)) * nc_ + 64))) return rc;
+        long *d_cs = (long *)a.d_mcells;
         int *d_bin = (int *)(d_cs + nc_);
-        BDS_HIP(ctx, hipMemcpyAsync(d_cs, h_cs.data(), sizeof(long) * nc_, hipMemcpyHostToDevice, s_main));
-        BDS_HIP(ctx, hipMemcpyAsync(d_bin, h_bin.data(), sizeof(int) * nc_, hipMemcpyHostToDevice, s_main));
+        if (a.d_mcells != before || a.mcells_cs != h_cs || a.mcells_bin != h_bin) {  // (the same PRN list call after call: no upload)
+            a.mcells_cs.clear(), a.mcells_bin.clear();
+            BDS_HIP(ctx, hipMemcpyAsync(d_cs, h_cs.data(), sizeof(long) * nc_, hipMemcpyHostToDevice, s_main));
+            BDS_HIP(ctx, hipMemcpyAsync(d_bin, h_bin.data(), sizeof(int) * nc_, hipMemcpyHostToDevice, s_main));
+            BDS_HIP(ctx, hipStreamSynchronize(s_main));  // (pageable sources: the copies are done before the vectors go)
+            a.mcells_cs = h_cs, a.mcells_bin = h_bin;
+        }
         for (int pi0 = 0; pi0 < P; pi0 += PB, ++pair_idx) {
             const int np_ = std::min(PB, P - pi0);
             CellList cl;

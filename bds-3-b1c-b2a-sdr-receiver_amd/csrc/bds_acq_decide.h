@@ -488,13 +488,19 @@ int AcqRun::refine_device() {
         BDS_HIP(ctx, hipMemsetAsync(a.d_ref_zero, 0, total, sm));
     }
     if ((rc = ensure(ctx, &a.d_ref_cand, &a.ref_cand_cap, (size_t)2 * kRefCandCap))) return rc;
+    const char *tabs_before = a.d_ref_tabs;
     if ((rc = ensure(ctx, &a.d_ref_tabs, &a.ref_tabs_cap, (sizeof(long) + sizeof(int)) * (size_t)P + 64))) return rc;
     long *d_cs_of = (long *)a.d_ref_tabs;
     int *d_prn_of = (int *)(d_cs_of + P);
     std::vector<long> h_cs(P);
     for (int pi = 0; pi < P; ++pi) h_cs[pi] = (long)a.cs_slot[prns[pi]] * ncomp * pl.L;
-    BDS_HIP(ctx, hipMemcpyAsync(d_cs_of, h_cs.data(), sizeof(long) * P, hipMemcpyHostToDevice, sm));
-    BDS_HIP(ctx, hipMemcpyAsync(d_prn_of, prns.data(), sizeof(int) * P, hipMemcpyHostToDevice, sm));
+    if (a.d_ref_tabs != tabs_before || a.ref_tabs_cs != h_cs || a.ref_tabs_prn != prns) {  // (the same PRN list call after call: no upload)
+        a.ref_tabs_cs.clear(), a.ref_tabs_prn.clear();
+        BDS_HIP(ctx, hipMemcpyAsync(d_cs_of, h_cs.data(), sizeof(long) * P, hipMemcpyHostToDevice, sm));
+        BDS_HIP(ctx, hipMemcpyAsync(d_prn_of, prns.data(), sizeof(int) * P, hipMemcpyHostToDevice, sm));
+        BDS_HIP(ctx, hipStreamSynchronize(sm));
+        a.ref_tabs_cs = h_cs, a.ref_tabs_prn = prns;
+    }
     const unsigned pb = (unsigned)((P + 63) / 64);
 
     // ---- coarse refinement: thresholds -> candidates in the band -> f64 sums -> per-PRN maximum ----------------
@@ -511,17 +517,24 @@ int AcqRun::refine_device() {
     // ---- B2a: second peak of the winning bin, outside +-2 chips and within +-1 code (acquisition.m:224-249) -------
     if (!b1c) {
         if ((rc = ensure(ctx, &a.d_extra2, &a.extra2_cap, (size_t)kExtra2Cap))) return rc;
-        const size_t nb_ = sizeof(int) * P + sizeof(long) * P + sizeof(int4) * P + 64;
+        // The main search of a small grid ran ALL P x D cells in one launch pair (multiprn, cfg2: 1 638 cells, 4.3 GB): the rows of every
+        // winning cell still lie in the inter-pass buffer, so the second-peak pass needs no row pass of its own -- its column pass
+        // reads cell pi D + b (round 5: 0.11 ms of cfg2's 0.5 ms refinement; BDS_ACQ_NO_BWREUSE of the hooks build switches back)
+        const bool reuse_bw = multiprn && n_pairs_total == 1 && pl.small && !tune.no_bwreuse;
+        const size_t nb_ = 2 * sizeof(int) * P + sizeof(long) * P + sizeof(int4) * P + 64;
         if ((rc = ensure(ctx, &a.d_cells, &a.cells_cap, nb_))) return rc;
         int4 *d_rng = (int4 *)a.d_cells;  // 16-byte aligned first
         long *d_cs = (long *)(d_rng + P);
         int *d_bin = (int *)(d_cs + P);
-        hipLaunchKernelGGL(k_ref_second_setup, dim3(pb), dim3(64), 0, sm, rp, a.d_ref_prn, (const long *)d_cs_of, d_rng, d_cs, d_bin, a.d_ref_g);
+        int *d_src = d_bin + P;
+        hipLaunchKernelGGL(k_ref_second_setup, dim3(pb), dim3(64), 0, sm, rp, a.d_ref_prn, (const long *)d_cs_of, d_rng, d_cs, d_bin,
+                           reuse_bw ? d_src : (int *)nullptr, a.d_ref_g);
         const SieveOut so_keep = so;
         so.recs = nullptr;
         so.extra = a.d_extra2, so.extra_count = a.d_extra2_count, so.extra_cap = kExtra2Cap;
         so.cellmax = a.d_cellmax2, so.lb = a.d_lb2, so.lb_div = 1;
-        const CellList cl{d_bin, d_cs, d_rng};
+        CellList cl{d_bin, d_cs, d_rng};
+        if (reuse_bw) cl.src = d_src;
         launch_list(P, nullptr, cl, 0, nullptr);
         so = so_keep;
         RefParams rp2 = rp;

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_ref_pick(const RefCand *__restrict__ ca
 
 // B2a: the (PRN, winning bin) cells of the second-peak pass and their two lag ranges (acquisition.m:224-249).  One thread per PRN.
 __global__ void k_ref_second_setup(RefParams p, RefPrn *__restrict__ prn, const long *__restrict__ cs_of, int4 *__restrict__ rng,
-                                   long *__restrict__ cs, int *__restrict__ bin, RefGlobal *__restrict__ g) {
+                                   long *__restrict__ cs, int *__restrict__ bin, int *__restrict__ src, RefGlobal *__restrict__ g) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= p.P) return;
     const long cp = prn[pi].codePhase;
@@ -249,6 +249,8 @@ __global__ void k_ref_second_setup(RefParams p, RefPrn *__restrict__ prn, const 
     rng[pi] = make_int4((int)(lo1 - 1), (int)(hi1 - 1), (int)(lo2 - 1), (int)(hi2 - 1));  // 0-based
     cs[pi] = cs_of[pi];
     bin[pi] = prn[pi].b;
+    // (optional) where the main search left this cell's rows in the inter-pass buffer: cell pi D + b of its one launch pair
+    if (src) src[pi] = pi * p.D + prn[pi].b;
 }
 
 // threshold decision and the jobs of the fine-Doppler search.  A detected PRN appends its jobs

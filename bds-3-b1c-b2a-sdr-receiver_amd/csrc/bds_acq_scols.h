@@ -48,6 +48,8 @@ struct SColsArgs {
     int extra_cap;
     int cell0;
     float keep;
+    const int *cell_src;             // optional: cell g's rows lie at cell index cell_src[g] of Bw (the B2a second-peak pass reading
+                                     // the winning cells straight out of the main search's inter-pass buffer), else at g
 };
 
 // 5-point inverse transform, outputs 0, 1, 2 (and 3 when WITH3): X_c = sum_r t_r w5^(r c)
@@ -81,7 +83,8 @@ __global__ __launch_bounds__(kSColsNT, BDS_SCOLS_OCC) void k_cols_small_f(SColsA
     const int g = item % A.G, tile = item / A.G;
     (void)tiles;
     const int comp = tid & 1, col = tile * (kSColsNT / 2) + (tid >> 1);
-    const uint32_t *src = (const uint32_t *)A.Bw + ((long)g * A.L + col) * 2 + comp;
+    const long gs = A.cell_src ? A.cell_src[g] : g;
+    const uint32_t *src = (const uint32_t *)A.Bw + (gs * A.L + col) * 2 + comp;
     uint32_t in[kSColsLen];
 #pragma unroll
     for (int k1 = 0; k1 < kSColsLen; ++k1) in[k1] = src[(long)k1 * L2 * 2];

@@ -39,6 +39,7 @@ struct Tuning {
     int pbcells = 0;                 // BDS_ACQ_PBCELLS
     double pbcap_gb = 8.0;           // BDS_ACQ_PBCAP_GB
     int rows_grid = 0;                  // BDS_ACQ_ROWS_GRID: workgroups of the (then persistent) row pass; 0 = one per item
+    bool no_bwreuse = false;            // BDS_ACQ_NO_BWREUSE: the B2a second-peak pass runs its own row pass (A/B, tests)
     bool overlap = false;               // BDS_ACQ_OVERLAP: column pass of group k on a second stream beside the row pass of group k+1
     double kdelta = 0;                  // BDS_ACQ_KDELTA: test hook, sieve tolerance override (0 = per-mode default)
     bool no_selfcheck = false;          // BDS_ACQ_NO_SELFCHECK: timing experiments with invalid results (no re-run)

@@ -120,9 +120,10 @@ def _usable_cpus():
     return n
 
 
-def test_b1c_full_grid_many_prns_against_the_c_oracle(ctx):
-    """BASELINE.json configs[2] against the oracle on WHOLE Doppler grids of many PRNs: the ten injected satellites and six absent
-    PRNs by default, all 63 with BDS_TEST_ALL_PRNS=1 (the log of such a run is committed under profiles/).  The rows come from the
+def test_b1c_full_grid_every_prn_against_the_c_oracle(ctx):
+    """BASELINE.json configs[2] against the oracle on the WHOLE Doppler grid of EVERY PRN (63 x 201 cells x 1 987 500 lags; ~2.5 min
+    on the 16 CPUs of the pool's GPU boxes, profiles/r05_cfg3_all_prns_vs_c_oracle.txt; BDS_TEST_FEW_PRNS=1 keeps the ten injected
+    satellites and six absent PRNs).  The rows come from the
     compiled restatement (oracle/c/acq_oracle.c, OpenMP over the bins: seconds per PRN where the NumPy rows take minutes; the two
     are held together by tests/test_oracle_c.py), everything after the rows from the NumPy oracle (B1C/acquisition.m:229-307).
     Per PRN: all 201 sieve row maxima within kDelta / 2, the f64 peak to 1e-9, bin / codePhase / carrFreq exact, peakMetric 1e-9."""
@@ -138,7 +139,7 @@ def test_b1c_full_grid_many_prns_against_the_c_oracle(ctx):
     pk, dn, fb = ctx.acq_peaks(63)
     tol = {0: 1e-5, 1: 1e-3}[tm["half_storage"]]  # kDelta / 2 of the mode
     present = [sat.prn for sat in sats]
-    prns = list(range(1, 64)) if os.environ.get("BDS_TEST_ALL_PRNS") else present + [2, 3, 30, 45, 60, 63]
+    prns = present + [2, 3, 30, 45, 60, 63] if os.environ.get("BDS_TEST_FEW_PRNS") else list(range(1, 64))
     xf = x[:3 * 993750 + 16].astype(np.float64)  # (acquisition touches N + spc - 1 samples)
     rows = {}
 
@@ -284,9 +285,12 @@ def test_cfg2_refinement_paths_decide_the_same(monkeypatch):
     s, x, sats, _ = bench.build_workload("b2a")
     monkeypatch.setenv("BDS_VERBOSE", "1")
     out = {}
-    for host in ("0", "1"):
-        if host == "1":
-            monkeypatch.setenv("BDS_ACQ_HOSTREFINE", "1")
+    # "0": the device chain, its second-peak pass reading the winning cells out of the main search's inter-pass buffer (round 5);
+    # "2": the device chain with a row pass of its own for those cells (BDS_ACQ_NO_BWREUSE=1); "1": the host path
+    for host, var in (("0", None), ("2", "BDS_ACQ_NO_BWREUSE"), ("1", "BDS_ACQ_HOSTREFINE")):
+        monkeypatch.delenv("BDS_ACQ_NO_BWREUSE", raising=False)
+        if var:
+            monkeypatch.setenv(var, "1")
         c = bds_amd.native.Context(0)
         c.acq_load(s, x)
         c.acq_prepare(s)
@@ -294,13 +298,14 @@ def test_cfg2_refinement_paths_decide_the_same(monkeypatch):
         tm = c.timing()
         out[host] = (res, c.acq_peaks(63), [c.acq_candidates(p) for p in (1, 19, 63)])
         c.close()
-        assert tm["refine_path"] == (1 if host == "0" else 0)
-    for u, v in zip(out["0"][0], out["1"][0]):
-        assert np.array_equal(u, v)
-    for u, v in zip(out["0"][1], out["1"][1]):
-        assert np.array_equal(u, v)
-    for u, v in zip(out["0"][2], out["1"][2]):
-        assert len(u) > 0 and np.array_equal(u, v)
+        assert tm["refine_path"] == (0 if host == "1" else 1)
+    for other in ("1", "2"):
+        for u, v in zip(out["0"][0], out[other][0]):
+            assert np.array_equal(u, v)
+        for u, v in zip(out["0"][1], out[other][1]):
+            assert np.array_equal(u, v)
+        for u, v in zip(out["0"][2], out[other][2]):
+            assert len(u) > 0 and np.array_equal(u, v)
 
 
 def test_cfg2_plans_decide_the_same(monkeypatch):
