@@ -19,8 +19,9 @@
  * Acquisition runs on ONE GPU unless BDS_MEX_DEVICES=n (n > 1, or 0 = every visible GPU) opts into the multi-device
  * path of the library (bds_multi_create + RCCL all-reduce): that path has only ever run on one-GPU boxes (with the exchange
  * forced, and with two contexts aliased onto one device), so it is not the default of a MATLAB session.
- * tests/test_mex_syntax.py compiles this file with -fsyntax-only against a header that declares the MEX API
- * (syntax evidence only: no MATLAB exists in the build image).
+ * No MATLAB exists in the build image: tests/test_mex_syntax.py compiles this file with -fsyntax-only against a header that
+ * declares the MEX API, and tests/test_mex_mock.py builds it against a small stand-in for the MEX runtime
+ * (tests/mex_stub/mex_mock.c) and runs every command and every error exit through ctypes.
  */
 #include <stdlib.h>
 #include <string.h>

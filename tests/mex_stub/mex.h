@@ -1,6 +1,9 @@
-/* Declarations of the part of MATLAB's C MEX / Matrix API that mex/bds_mex.c uses, for a -fsyntax-only compile
- * (tests/test_mex_syntax.py).  Nothing here is ever linked or executed: it only lets the compiler check the
- * gateway's syntax and its calls into include/bds_mi355x.h in an image that has no MATLAB. */
+/* Declarations of the part of MATLAB's C MEX / Matrix API that mex/bds_mex.c uses.  Two uses in an image that has no MATLAB:
+ *   tests/test_mex_syntax.py   -fsyntax-only compile of the gateway against these declarations and include/bds_mi355x.h;
+ *   tests/test_mex_mock.py     the gateway compiled for real against tests/mex_stub/mex_mock.c -- a small stand-in for the MEX
+ *                              runtime (arrays, structs, strings, error exit by longjmp) -- and EXECUTED through ctypes: what
+ *                              MATLAB would hand to mexFunction goes in, what it would get back is compared with the ctypes host path.
+ * Neither is MATLAB: semantics are those documented for the R2018a interleaved-complex API. */
 #ifndef BDS_TEST_MEX_STUB_H
 #define BDS_TEST_MEX_STUB_H
 #include <stdbool.h>
@@ -34,4 +37,6 @@ void mxSetField(mxArray *s, size_t index, const char *name, mxArray *v);
 void mxDestroyArray(mxArray *a);
 void *mxCalloc(size_t n, size_t size);
 void mxFree(void *p);
+mxArray *mxCreateString(const char *str);
+mxArray *mxCreateLogicalScalar(bool v);
 #endif

@@ -1,6 +1,6 @@
 """mex/bds_mex.c has never met MATLAB's compiler (none exists in this image).  This compiles it with
 -fsyntax-only against tests/mex_stub/mex.h (declarations of the MEX API functions it uses) and the real
-include/bds_mi355x.h: syntax evidence only -- every library entry the gateway calls is type-checked against the
+include/bds_mi355x.h (tests/test_mex_mock.py goes further and executes the gateway against a mock MEX runtime) -- every library entry the gateway calls is type-checked against the
 C ABI, and a field the gateway forgets to require would show up in the field-list check below."""
 import os
 import re
