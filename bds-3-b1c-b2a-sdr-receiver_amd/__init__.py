@@ -12,7 +12,7 @@ All numeric work happens in ``libbds_mi355x.so`` (HIP kernels for gfx950) throug
 the C ABI of ``include/bds_mi355x.h``; there is no CPU fallback.
 """
 from .settings import Settings, init_settings_b1c, init_settings_b2a  # noqa: F401
-from .acquisition import acquisition, GPU_acquisition, AcqResults, get_context  # noqa: F401
+from .acquisition import acquisition, GPU_acquisition, AcqResults, get_context, release_context  # noqa: F401
 from .tracking import tracking, NB_tracking, WB_tracking, pre_run, acquire_track, TrackResults  # noqa: F401
 from .framesync import frame_sync, unpack_cplx  # noqa: F401
 from .distributed import shard_prns, shard_joint, sharded_acquisition, sharded_acquisition_joint  # noqa: F401

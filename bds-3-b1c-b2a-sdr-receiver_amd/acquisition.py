@@ -24,6 +24,14 @@ def get_context(device: int = 0) -> native.Context:
     return _ctx[device]
 
 
+def release_context(device: int = 0) -> None:
+    """Destroy the process-wide context of a device (its HBM -- IF block, code spectra, the inter-pass buffer of the search --
+    goes back to the device); the next call builds a new one."""
+    c = _ctx.pop(device, None)
+    if c is not None:
+        c.close()
+
+
 class AcqResults(SimpleNamespace):
     """acqResults struct (B2a/acquisition.m:161-165)."""
 

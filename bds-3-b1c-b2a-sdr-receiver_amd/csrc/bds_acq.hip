@@ -131,6 +131,8 @@ struct AcqState {
     std::vector<char> code_have;     // which (slot, mode) tables exist
     char *d_cells = nullptr;         // cell list of the batched second-peak launch
     size_t cells_cap = 0;
+    double pair_gb = 0;              // bds_acq_set_pair_budget_gb (overrides the BDS_ACQ_PAIR_GB of the context's tuning)
+    bool pair_gb_set = false;
     char *d_mcells = nullptr;        // cell list of the main search of a small grid (all P x D cells in a few launch pairs) ...
     size_t mcells_cap = 0;
     std::vector<long> mcells_cs;     // ... and what it holds: uploaded again only when a run's list differs
@@ -580,8 +582,15 @@ static void launch_fast_f(bds_ctx *ctx, hipStream_t st_, const Plan2D &pl, const
     if (so.cols_stream) (void)hipEventRecord(so.ev_cols, sc);
 }
 
-// inter-pass work buffer: two halves of `group` cells each (float2-sized elements)
-static size_t bw_batches(const AcqState &a) { return (size_t)std::max(2 * a.group * a.ncomp, 8); }
+// inter-pass work buffer in float2-sized elements per transform length: the `group` cells of one launch pair at the storage type of
+// the search (fp16 complex: half an element) -- which is also what the forward pass of `group` bins needs at fp32 -- , twice that
+// when the column pass runs beside the next group's row pass (BDS_ACQ_OVERLAP).  (Rounds 1-5 kept two fp32-sized halves whatever
+// the mode: 20 GB at cfg3 where 5 are used -- and every GiB a context frees is a GiB the driver clears before the next user gets it.)
+static size_t bw_batches(const AcqState &a, const Tuning &tune) {
+    const int per_cell = a.half ? 1 : 2;                                  // float2-sized elements per cell and two components
+    const int search = (a.group * a.ncomp * per_cell + 1) / 2 * (tune.overlap ? 2 : 1);
+    return (size_t)std::max(std::max(search, std::min(a.group, a.D > 0 ? a.D : a.group)), 8);
+}
 
 // cells per launch pair for a search over D bins: the whole Doppler row of a PRN when the two
 // halves of the inter-pass buffer stay under 24 GiB (B1C cfg3: 201 cells, 20 GiB of the 288)
@@ -759,7 +768,7 @@ extern "C" int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s_in) {
     if ((rc = set_lds_limits(ctx))) return rc;
     Plan2D &pl = a.plan;
     pick_group(a, *s);
-    if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a) * (size_t)pl.L))) return rc;
+    if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a, ctx->tune) * (size_t)pl.L))) return rc;
     std::vector<int> todo;
     for (int i = 0; i < s->n_acq; ++i)
         if (!a.cs_slot.count(s->acqSatelliteList[i]) &&
@@ -778,7 +787,7 @@ extern "C" int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s_in) {
         a.cs_cap_slots = need_slots;
     }
     // conj(fft([table zeros]))/L per PRN and component (B2a/acquisition.m:175-184, B1C/acquisition.m:174-187)
-    const int chunk = (int)bw_batches(a);
+    const int chunk = (int)bw_batches(a, ctx->tune);
     for (int prn : todo) {
         const int slot = (int)a.cs_slot.size();
         CodeLoader ld{a.tab, (prn - 1) * 2};
@@ -940,6 +949,7 @@ struct AcqRun {
     hipEvent_t sa[kSamples], sb[kSamples], sm[kSamples];
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_cols[2] = {nullptr, nullptr};
     int nsamp = 0;
+    double samp_cells = 0;  // cells of the sampled multi-PRN pairs
     bool mids = false;  // the sampled pairs carry a mid event (fp32-arithmetic kernels)
     size_t half_bytes = 0;  // one group of cells in the inter-pass buffer
     // the sieve's output and the decisions made on it
@@ -985,7 +995,7 @@ int AcqRun::setup() {
     ncomp = a.ncomp;
     pick_group(a, *s);
     G = a.group;
-    if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a) * (size_t)pl.L))) return rc;
+    if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a, ctx->tune) * (size_t)pl.L))) return rc;
     if ((rc = ensure(ctx, &a.d_Xs, &a.xs_cap, (size_t)D * pl.L))) return rc;
 
     BDS_HIP(ctx, evp.make(&ev0));
@@ -1064,14 +1074,43 @@ int AcqRun::setup() {
         so.recs = a.d_recs;
     }
     elem = a.half ? 4 : 8;
-    // Small Doppler grids (B2a: 26 bins): one launch pair carries the whole rows of several PRNs through
-    // a cell list, so that the grids fill the chip and a row workgroup still walks one PRN's bins.
-    multiprn = fsearch && (D <= 104 || tune.multi_any) && P > 1 && !tune.nomulti;
-    // (measured at cfg2, 63 PRNs x 26 bins: 104 cells per pair 3.9 ms, 208 -> 3.6, 416 -> 3.2, 832 -> 3.1, all 1638 -> 3.0;
-    //  the fused fp16 chain of round 2 4.0); the work buffer is capped at 8 GiB
-    const long pb_cap = std::max<long>(1, (long)(tune.pbcap_gb * 1073741824.0 / ((double)ncomp * (double)pl.L * (double)elem)));
-    const long pb_cells = tune.pbcells ? tune.pbcells : pb_cap;
-    PB = multiprn ? (int)std::min<long>(P, std::max<long>(2, std::min(pb_cells, pb_cap) / D)) : 1;
+    // One launch pair carries the whole Doppler rows of SEVERAL PRNs through a cell list: the grids fill the chip, a row workgroup
+    // walks all the bins of one PRN (its code rows and twiddles set up once per D cells), the row workgroups of different PRNs
+    // read the same spectrum rows at about the same time, and a call is a few long launches instead of many short ones.
+    //   cfg2 (63 PRNs x 26 bins, round 3): 104 cells per pair 3.9 ms, 208 -> 3.6, 416 -> 3.2, 832 -> 3.1, all 1638 -> 3.0.
+    //   cfg3 (63 PRNs x 201 bins, round 5, profiles/r05_multiprn_full*.txt, per call on one box): one PRN per pair 197.0 ms,
+    //   8 PRNs 197.5, 11 PRNs 199.1 (202.3), 16 PRNs 192.8, 21 PRNs 191.8 (196.7), 32 PRNs 195.0 (202.3) -- 2.5 - 3.6 % for an
+    //   inter-pass buffer of 106 - 162 GB, which is what 288 GB of HBM are for.
+    // What that costs is memory, and time when it changes hands: a FRESH hipMalloc of 150 GiB takes 0.4 ms on these boxes, but freed
+    // device memory is cleared by the driver at ~33 GB/s and an allocation that needs it waits -- 150 GiB allocated again after a free:
+    // 4.5 - 4.8 s (tools/probe/alloc_probe.hip, profiles/r05_alloc_probe.txt).  A first call in a fresh process costs the same in both
+    // modes (bench.py `cold`: 234 vs 266 ms); a process that builds and destroys contexts, or the next process on the device, pays for
+    // the clearing.  So it is a SERVING mode, chosen by the deployment (BDS_ACQ_PAIR_GB / bds_acq_set_pair_budget_gb: GiB, or "auto"
+    // = 60 % of the device memory that is free, counting what this context already holds), not the default: the default keeps one
+    // PRN's Doppler row per pair on big grids and a right-sized buffer (cfg3: 5 GB), a footprint a host can plan with.
+    // Small grids (D <= 104: cfg2's 63 x 26 cells are 4.3 GB) batch up to 8 GiB either way.  The PRNs are dealt evenly over the
+    // pairs; with room for less than two PRNs' cells a pair is one group of one PRN.
+    // (BDS_ACQ_NOMULTI / BDS_ACQ_MULTI_ANY / BDS_ACQ_PBCELLS / BDS_ACQ_PBCAP_GB of the hooks build: off / on / cells per pair / budget.)
+    const double pair_gb = tune.pbcap_gb > 0 ? tune.pbcap_gb : a.pair_gb_set ? a.pair_gb : tune.pair_gb;
+    multiprn = fsearch && P > 1 && !tune.nomulti && (D <= 104 || tune.multi_any || pair_gb != 0);
+    PB = 1;
+    if (multiprn) {
+        double budget = (pair_gb > 0 ? pair_gb : 8.0) * 1073741824.0;
+        if (pair_gb < 0) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)16 << 30;
+            budget = 0.6 * ((double)fr + (double)a.bw_cap * sizeof(float2));
+        }
+        const long pb_cap = (long)(budget / ((double)ncomp * (double)pl.L * (double)elem));  // cells
+        const long pb_cells = tune.pbcells ? std::min<long>(tune.pbcells, pb_cap) : pb_cap;
+        const long pb_max = std::min<long>(P, std::max<long>(D <= 104 ? 2 : 1, pb_cells / D));
+        if (pb_max < 2) {
+            multiprn = false;
+        } else {
+            const long np_ = (P + pb_max - 1) / pb_max;
+            PB = (int)((P + np_ - 1) / np_);
+        }
+    }
     n_pairs_total = (long)P * ((D + G - 1) / G);
     cells_per_pair = G;
     if (multiprn) n_pairs_total = (P + PB - 1) / PB, cells_per_pair = (long)PB * D;
@@ -1089,7 +1128,7 @@ int AcqRun::setup() {
 
 int AcqRun::forward_all() {
     Plan2D &pl = a.plan;
-    const int chunk = (int)bw_batches(a);
+    const int chunk = (int)bw_batches(a, ctx->tune);
     for (int b0 = 0; b0 < D; b0 += chunk) {
         const int nb = std::min(chunk, D - b0);
         SignalLoader ld{a.sview(), a.N, a.n_ext, f0, s->acqStep, 1.0 / a.fs, b0};
@@ -1176,9 +1215,16 @@ int AcqRun::search() {
     const long sample_every = std::max<long>(1, n_pairs_total / kSamples);
     long pair_idx = 0, group_idx = 0;
     if (multiprn) {
-        // float2-sized elements the PB*D cells of one launch pair occupy
-        const size_t need = ((size_t)PB * D * ncomp * elem + 7) / 8;
-        if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, std::max(need, bw_batches(a)) * (size_t)pl.L))) return rc;
+        // float2-sized elements the PB*D cells of one launch pair occupy; if the device cannot give that much after all (another
+        // process took it since setup() asked), halve the PRNs per pair
+        for (;;) {
+            const size_t need = ((size_t)PB * D * ncomp * elem + 7) / 8;
+            if (!(rc = ensure(ctx, &a.d_Bw, &a.bw_cap, std::max(need, bw_batches(a, ctx->tune)) * (size_t)pl.L))) break;
+            if (PB <= 2) return rc;
+            PB = (PB + 1) / 2;
+            n_pairs_total = (P + PB - 1) / PB, cells_per_pair = (long)PB * D;
+            if (ctx->tune.verbose) fprintf(stderr, "[bds] inter-pass buffer: allocation failed, %d PRNs per launch pair instead\n", PB);
+        }
         const size_t nc_ = (size_t)P * D;
         std::vector<int> h_bin(nc_);
         std::vector<long> h_cs(nc_);
@@ -1204,10 +1250,15 @@ int AcqRun::search() {
             cl.bin = d_bin + (size_t)pi0 * D;
             cl.cs = d_cs + (size_t)pi0 * D;
             cl.gc = D;
-            const bool sample = np_ == PB && (pair_idx % sample_every) == 0 && nsamp < kSamples;
+            // (a call is a handful of pairs: all of them are timed, the last, shorter one included -- cell_pair_ms and
+            //  cells_per_pair are then the means a kernel trace of the call shows)
+            const bool sample = (np_ == PB || n_pairs_total <= kSamples) && (pair_idx % sample_every) == 0 && nsamp < kSamples;
             if (sample) BDS_HIP(ctx, hipEventRecord(sa[nsamp], s_main));
             launch_list(np_ * D, wcols ? nullptr : a.d_recs + (size_t)pi0 * D * pl.ntiles, cl, pi0 * D, sample ? sm[nsamp] : nullptr);
-            if (sample) BDS_HIP(ctx, hipEventRecord(sb[nsamp++], s_main));
+            if (sample) {
+                BDS_HIP(ctx, hipEventRecord(sb[nsamp++], s_main));
+                samp_cells += (double)np_ * D;
+            }
         }
     } else {
         for (int pi = 0; pi < P; ++pi) {
@@ -1279,7 +1330,7 @@ int AcqRun::finish() {
     }
     // overlapped passes: the average launch-pair duration is the search time over the pair count
     t.cell_pair_ms = nsamp ? acc / nsamp : (n_pairs_total ? t.search_ms / (double)n_pairs_total : 0);
-    t.cells_per_pair = (int)cells_per_pair;
+    t.cells_per_pair = samp_cells > 0 && nsamp ? samp_cells / nsamp : (double)cells_per_pair;
     t.n_pairs = n_pairs_total;
     t.fft_len = pl.L;
     t.n_circ = a.N;
@@ -1345,6 +1396,16 @@ int acq_run_once(bds_ctx *ctx, const bds_settings *s_in, const int32_t *prn_list
 
 }  // namespace
 }  // namespace bds
+
+/* Serving mode of the search (see AcqRun::setup): budget of the inter-pass buffer in GiB; 0 = lean, < 0 = 60 % of the free device memory */
+extern "C" int bds_acq_set_pair_budget_gb(bds_ctx *ctx, double gib) {
+    if (!ctx) return BDS_ERR_ARG;
+    if (!(gib == gib)) return fail(ctx, BDS_ERR_ARG, "bds_acq_set_pair_budget_gb: not a number");
+    if (!ctx->acq) ctx->acq = new AcqState();
+    ctx->acq->pair_gb = gib;
+    ctx->acq->pair_gb_set = true;
+    return BDS_OK;
+}
 
 extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t *prn_list, int n_prn, int max_prn,
                            double *carrFreq, double *codePhase, double *peakMetric, int32_t *detected) {

@@ -31,6 +31,8 @@ int fail(bds_ctx *ctx, int code, const char *fmt, ...) {
 //   BDS_TRK_PREC=0..5   numerics of the tracking correlator (default 5 = strict; 0 = fp32 carrier, 1.5x faster wide-band)
 //   BDS_VERBOSE         progress / fallback messages on stderr
 //   BDS_ACQ_CLOCKPROBE  sampled workgroups time themselves with the shader clock (bds_timing::shader_clock_GHz)
+//   BDS_ACQ_PAIR_GB     serving mode of the search: several PRNs per launch pair, inter-pass buffer of so many GiB ("auto": 60 % of the
+//                       free device memory); default 0 = lean (bds_acq_set_pair_budget_gb is the same switch for a host program)
 // Everything else -- kernel selection, launch shapes, plan overrides, the sieve tolerance, the switches that turn the
 // completeness self-check off or force a fallback -- exists only in the TEST-HOOKS build (BDS_TEST_HOOKS=1 ./build.sh ->
 // libbds_mi355x_hooks.so, what tests/ load): a stray variable in a MATLAB session cannot change what the release library decides.
@@ -45,6 +47,7 @@ Tuning tuning_from_env() {
     t.trk_prec = geti("BDS_TRK_PREC", 5);
     t.verbose = has("BDS_VERBOSE");
     t.clockprobe = geti("BDS_ACQ_CLOCKPROBE", 0);
+    if (const char *e = std::getenv("BDS_ACQ_PAIR_GB")) t.pair_gb = (e[0] == 'a' || e[0] == 'A') ? -1.0 : std::atof(e);
 #ifdef BDS_TEST_HOOKS
     if (const char *e = std::getenv("BDS_ACQ_FORCE_L1L2")) {
         int a = 0, b = 0;

@@ -37,7 +37,9 @@ struct Tuning {
     int gchunk = 34;                 // BDS_ACQ_GCHUNK: cells one row-pass workgroup walks through
     bool multi_any = false, nomulti = false;  // BDS_ACQ_MULTI_ANY / BDS_ACQ_NOMULTI: multi-PRN launch pairs
     int pbcells = 0;                 // BDS_ACQ_PBCELLS
-    double pbcap_gb = 8.0;           // BDS_ACQ_PBCAP_GB
+    double pbcap_gb = 0;             // BDS_ACQ_PBCAP_GB (hooks): budget of the inter-pass buffer of a multi-PRN launch pair, overrides pair_gb
+    double pair_gb = 0;              // BDS_ACQ_PAIR_GB (release knob): 0 = lean (one PRN's Doppler row per launch pair on big grids; small grids
+                                     // batch up to 8 GiB), > 0 = as many PRNs per pair as fit so many GiB, < 0 ("auto") = 60 % of the free device memory
     int rows_grid = 0;                  // BDS_ACQ_ROWS_GRID: workgroups of the (then persistent) row pass; 0 = one per item
     bool no_bwreuse = false;            // BDS_ACQ_NO_BWREUSE: the B2a second-peak pass runs its own row pass (A/B, tests)
     bool overlap = false;               // BDS_ACQ_OVERLAP: column pass of group k on a second stream beside the row pass of group k+1

@@ -83,7 +83,7 @@ class AcqJob(C.Structure):
 
 EXPORTS = [
     "bds_create", "bds_destroy", "bds_reload_tuning", "bds_last_error", "bds_device_name", "bds_abi_check", "bds_build_flags", "bds_gen_code", "bds_acquire",
-    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_acq_candidates", "bds_acq_coherent_sums", "bds_get_timing",
+    "bds_acq_load", "bds_acq_prepare", "bds_acq_run", "bds_acq_set_pair_budget_gb", "bds_resample_plan", "bds_fir1_bandpass", "bds_frame_sync", "bds_sync_pattern", "bds_unpack_cplx", "bds_unpack_cplx_file", "bds_acq_grid", "bds_acq_peaks", "bds_acq_candidates", "bds_acq_coherent_sums", "bds_get_timing",
     "bds_track", "bds_track_mem", "bds_track_loaded_bytes", "bds_track_correlate", "bds_calc_loop_coef", "bds_calc_loop_coef_carr",
     "bds_calc_weighing_factor", "bds_pre_run", "bds_pre_run_device", "bds_acquire_track",
     "bds_multi_create", "bds_multi_destroy", "bds_multi_last_error", "bds_multi_size", "bds_multi_ctx",
@@ -392,6 +392,13 @@ class Context:
     def acq_prepare(self, settings):
         cs = pack_settings(settings)
         self._check(self._lib.bds_acq_prepare(self._h, C.byref(cs)))
+
+    def acq_set_pair_budget(self, gib):
+        """bds_acq_set_pair_budget_gb: serving mode of the search -- several PRNs' Doppler rows per launch pair, inter-pass buffer of
+        `gib` GiB ("auto" / negative: 60 % of the free device memory; 0: lean, the default).  Takes effect at the next acq_run."""
+        g = -1.0 if (isinstance(gib, str) and gib.lower().startswith("a")) else float(gib)
+        self._lib.bds_acq_set_pair_budget_gb.argtypes = [C.c_void_p, C.c_double]
+        self._check(self._lib.bds_acq_set_pair_budget_gb(self._h, g))
 
     def acq_run(self, settings, prn_list=None):
         cs = pack_settings(settings)

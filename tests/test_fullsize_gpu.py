@@ -281,12 +281,14 @@ def test_b1c_wideband_tracking_full_rate(ctx):
 
 
 @pytest.mark.parametrize("env", [{"BDS_ACQ_PK": "0"}, {"BDS_ACQ_PK": "2"}, {"BDS_ACQ_ILV": "0"}, {"BDS_ACQ_PK": "0", "BDS_ACQ_ILV": "0"},
-                                 {"BDS_ACQ_NEIGH": "1"}, {"BDS_ACQ_WROWS": "0"}, {"BDS_ACQ_WCOLS": "0"}, {"BDS_ACQ_HOSTREFINE": "1"}])
+                                 {"BDS_ACQ_NEIGH": "1"}, {"BDS_ACQ_WROWS": "0"}, {"BDS_ACQ_WCOLS": "0"}, {"BDS_ACQ_HOSTREFINE": "1"},
+                                 {"BDS_ACQ_PAIR_GB": "auto"}, {"BDS_ACQ_PAIR_GB": "11"}, {"BDS_ACQ_PAIR_GB": "auto", "BDS_ACQ_WCOLS": "0"}])
 def test_cfg3_kernel_variants_decide_the_same(env, monkeypatch):
     """The switches of the round-4 search kernels at the cfg3 plan (768 x 4096): plain-fp32 instead of packed butterflies (both
     passes / column pass only), component planes instead of interleaved components, the +-1 neighbours of rounds 1-3 refined
     as well, the round-2 row / column kernels, the refinement through the host (rounds 1-4) instead of the device chain of
-    round 5 (csrc/bds_acq_refine.h).  Every variant is a different sieve in front of the same f64 decision: acqResults
+    round 5 (csrc/bds_acq_refine.h), the serving mode of the search (BDS_ACQ_PAIR_GB, a release knob: all four PRNs' Doppler rows in
+    one launch pair / two PRNs per pair at 11 GiB / with the tile column pass).  Every variant is a different sieve in front of the same f64 decision: acqResults
     must be the default's bit for bit, the search grid within the sieve's tolerance of it."""
     s, x, sats, _ = bench.build_workload("b1c")
     prns = [sats[0].prn, 2, sats[1].prn, 33]
@@ -310,6 +312,10 @@ def test_cfg3_kernel_variants_decide_the_same(env, monkeypatch):
         assert np.array_equal(u, v)
     np.testing.assert_allclose(g1, g0, rtol=2e-3)
     assert flags0 == 3  # default: interleaved components + packed butterflies
+    if "BDS_ACQ_PAIR_GB" in env:
+        assert tm["n_pairs"] == (1 if env["BDS_ACQ_PAIR_GB"] == "auto" else 2) and tm["cells_per_pair"] == 201 * 4 / tm["n_pairs"]
+    else:
+        assert tm["n_pairs"] == 4 and tm["cells_per_pair"] == 201
     assert tm["refine_path"] == (0 if set(env) & {"BDS_ACQ_NEIGH", "BDS_ACQ_WCOLS", "BDS_ACQ_HOSTREFINE"} else 1)
     if "BDS_ACQ_PK" in env and env["BDS_ACQ_PK"] == "0":
         assert not tm["kernel_flags"] & 2

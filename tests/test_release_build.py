@@ -1,5 +1,5 @@
 """The RELEASE library (libbds_mi355x.so: what bench.py, smoke() and a MATLAB host load) against the test-hooks build the
-rest of the suite runs on: it reads four documented environment knobs and nothing else, so no stray BDS_* variable of a host
+rest of the suite runs on: it reads five documented environment knobs and nothing else, so no stray BDS_* variable of a host
 session can switch off the completeness self-check, widen the sieve tolerance, force a fallback or redirect dlopen."""
 import json
 import os
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "bds-3-b1c-b2a-sdr-receiver_amd")
 RELEASE = os.path.join(PKG, "libbds_mi355x.so")
 HOOKS = os.path.join(PKG, "libbds_mi355x_hooks.so")
-DOCUMENTED = {"BDS_ACQ_FP16", "BDS_TRK_PREC", "BDS_VERBOSE", "BDS_ACQ_CLOCKPROBE"}
+DOCUMENTED = {"BDS_ACQ_FP16", "BDS_TRK_PREC", "BDS_VERBOSE", "BDS_ACQ_CLOCKPROBE", "BDS_ACQ_PAIR_GB"}
 
 
 def env_names(path):
