@@ -551,7 +551,7 @@ def clock_leg(local_rank, s, x):
         tm = c.timing()
     finally:
         c.close()
-    return {"shader_clock_GHz": tm.get("shader_clock_GHz"), "pair_ms": tm["cell_pair_ms"]}
+    return {"shader_clock_GHz": tm.get("shader_clock_GHz"), "pair_ms": tm["cell_pair_ms"], "cells_per_pair": tm["cells_per_pair"]}
 
 
 def main():
@@ -821,7 +821,10 @@ def main():
                 valu["shader_clock_GHz"] = ck["shader_clock_GHz"]
                 valu["shader_clock_source"] = "measured in this run (one extra call, BDS_ACQ_CLOCKPROBE=1: sampled workgroups, s_memtime against s_memrealtime)"
                 valu["bound_ms_at_shader_clock"] = valu["bound_ms"] * valu["clock_GHz"] / ck["shader_clock_GHz"]
-                valu["frac_of_issue_bound_at_shader_clock"] = valu["bound_ms_at_shader_clock"] / ck["pair_ms"] if ck["pair_ms"] else None
+                # (the clock probe runs a lean context: its pair is one PRN's cells -- compare at the same cells per pair)
+                valu["frac_of_issue_bound_at_shader_clock"] = (valu["bound_ms_at_shader_clock"] * ck["cells_per_pair"] / cells_per_pair / ck["pair_ms"]
+                                                               if ck["pair_ms"] and cells_per_pair else None)
+                valu["shader_clock_probe_pair"] = {"pair_ms": ck["pair_ms"], "cells_per_pair": ck["cells_per_pair"], "mode": "lean context"}
         if world == 1 and len(sigs) == 1 and args.prns == 63 and not args.no_cold:
             out["cold"] = {names[0]: cold_leg(local_rank, s, x)}
             if names == ["b1c"]:

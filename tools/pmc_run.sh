@@ -2,7 +2,9 @@
 # Collect PMC counters for a short B1C bench run, one rocprofv3 pass per counter set
 # (--pmc only: never combined with trace domains, see the gpurun rules).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="${BENCH_ARGS:---workload b1c --steps 1 --warmup 0 --no-cpu-baseline --no-tracking --no-strict-f32 --no-b2a --prns 2}"
+# (--prns 32: the headline's serving mode carries 32 PRNs' Doppler rows per launch pair -- 6432 cells --, and what the row workgroups
+#  of the PRNs share in L2 is part of the traffic figure; PMC_CELLS of tools/r5_collect.sh must say the same)
+ARGS="${BENCH_ARGS:---workload b1c --steps 1 --warmup 0 --no-cpu-baseline --no-tracking --no-strict-f32 --no-b2a --no-cold --prns 32}"
 i=0
 while read -r set; do
   [ -z "$set" ] && continue

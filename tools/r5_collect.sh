@@ -9,8 +9,8 @@ cp gpurun_out/kernel_stats_trk_WB.txt profiles/r05_trk_wb_kernel_stats.txt
 tail -1 gpurun_out/bench_b1c.json > profiles/r05_bench_b1c.json
 tail -1 gpurun_out/bench_b2a.json > profiles/r05_bench_b2a.json
 cp gpurun_out/bench_under_rocprof_b1c.json profiles/r05_bench_b1c_under_rocprof.json 2>/dev/null
-python tools/make_traffic.py gpurun_out/pmc_summary_default.txt b1c 201 profiles/r05_b1c_pmc.txt k_cols_wave_f "round 5" > /dev/null
-python tools/make_valu.py gpurun_out/pmc_summary_default.txt profiles/r04_isa_mix.json b1c 201 "round 5" > /dev/null
+python tools/make_traffic.py gpurun_out/pmc_summary_default.txt b1c ${PMC_CELLS:-6432} profiles/r05_b1c_pmc.txt k_cols_wave_f "round 5" > /dev/null
+python tools/make_valu.py gpurun_out/pmc_summary_default.txt profiles/r04_isa_mix.json b1c ${PMC_CELLS:-6432} "round 5" > /dev/null
 python - <<'PY'
 import json
 j = json.load(open("profiles/r05_bench_b1c.json")); r = j["roofline"]; v = r.get("valu") or {}
