@@ -133,6 +133,8 @@ struct AcqState {
     size_t cells_cap = 0;
     double pair_gb = 0;              // bds_acq_set_pair_budget_gb (overrides the BDS_ACQ_PAIR_GB of the context's tuning)
     bool pair_gb_set = false;
+    int pb_last = 0;                 // PRNs per launch pair the last run settled on, and what it was decided for: the next run with
+    double pb_key[6] = {0};          // the same (P, D, L, element size, components, budget) takes it without asking the driver again
     char *d_mcells = nullptr;        // cell list of the main search of a small grid (all P x D cells in a few launch pairs) ...
     size_t mcells_cap = 0;
     std::vector<long> mcells_cs;     // ... and what it holds: uploaded again only when a run's list differs
@@ -1094,7 +1096,12 @@ int AcqRun::setup() {
     const double pair_gb = tune.pbcap_gb > 0 ? tune.pbcap_gb : a.pair_gb_set ? a.pair_gb : tune.pair_gb;
     multiprn = fsearch && P > 1 && !tune.nomulti && (D <= 104 || tune.multi_any || pair_gb != 0);
     PB = 1;
-    if (multiprn) {
+    const double pb_key[6] = {(double)P, (double)D, (double)pl.L, (double)elem, (double)ncomp, pair_gb + (tune.pbcells ? 1e6 * tune.pbcells : 0)};
+    const bool pb_known = multiprn && a.pb_last > 0 && !memcmp(pb_key, a.pb_key, sizeof(pb_key));
+    if (pb_known) {
+        PB = a.pb_last;
+        multiprn = PB >= 2;
+    } else if (multiprn) {
         double budget = (pair_gb > 0 ? pair_gb : 8.0) * 1073741824.0;
         if (pair_gb < 0) {
             size_t fr = 0, tot = 0;
@@ -1110,6 +1117,10 @@ int AcqRun::setup() {
             const long np_ = (P + pb_max - 1) / pb_max;
             PB = (int)((P + np_ - 1) / np_);
         }
+    }
+    if (!pb_known && !tune.nomulti && fsearch && P > 1) {
+        memcpy(a.pb_key, pb_key, sizeof(pb_key));
+        a.pb_last = multiprn ? PB : 1;
     }
     n_pairs_total = (long)P * ((D + G - 1) / G);
     cells_per_pair = G;
@@ -1222,6 +1233,7 @@ int AcqRun::search() {
             if (!(rc = ensure(ctx, &a.d_Bw, &a.bw_cap, std::max(need, bw_batches(a, ctx->tune)) * (size_t)pl.L))) break;
             if (PB <= 2) return rc;
             PB = (PB + 1) / 2;
+            a.pb_last = PB;
             n_pairs_total = (P + PB - 1) / PB, cells_per_pair = (long)PB * D;
             if (ctx->tune.verbose) fprintf(stderr, "[bds] inter-pass buffer: allocation failed, %d PRNs per launch pair instead\n", PB);
         }
