@@ -61,7 +61,7 @@ struct Tuning {
     int trk_chunk = 0;               // BDS_TRK_CHUNK: samples per correlate workgroup (0 = per-mode default)
     bool trk_nofuse_update = false;  // BDS_TRK_NOFUSE_UPDATE: loop update as its own launch per epoch instead of at the head of the next correlate launch
     bool trk_persample = false;      // BDS_TRK_PERSAMPLE: per-sample tracking correlator instead of the run-based one
-    int trk_prec = 5;                // BDS_TRK_PREC: carrier / prefix-sum numerics of the run-based correlator (bds_track.hip, TrkParams::prec; 5 = strict, the default; 4 = the same values with a sin / cos per sample)
+    int trk_prec = 4;                // BDS_TRK_PREC: carrier / prefix-sum numerics of the run-based correlator (bds_track.hip, TrkParams::prec; 4 = strict, the default: a sin / cos of the reference's trigarg per sample; 5 = the same argument by angle addition)
     int trk_seg = 0;                 // BDS_TRK_SEG: samples per lane and pass of the run-based correlator (8 / 16; 0 = per-signal default)
 };
 Tuning tuning_from_env();

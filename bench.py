@@ -257,7 +257,9 @@ def tracking_leg(name, local_rank, base):
             "int8_read_GBps": samples / (dev_ms * 1e-3) / 1e9,  # one byte per sample per channel (algorithmic)
             "correlator_GMACs": samples * macs / (dev_ms * 1e-3) / 1e9, "macs_per_sample": macs,
             "channels_locked": locked,
-            "numerics": "strict (default, BDS_TRK_PREC=5): the reference's trigarg(k) per sample in f64 (one sin/cos per 16 samples + exact angle addition), f64 prefix sums -- SURVEY 8d over the whole 3 600 / 49 000-epoch horizon",
+            "numerics": "strict (default, BDS_TRK_PREC=4): sin / cos of the reference's own trigarg(k) per sample in f64, f64 prefix sums -- 1e-13 of |P| from the "
+                        "float64 oracle; SURVEY 8d until a channel's first ceil() flip (cfg4 at full rate: 11 of 12 channels over all 3 600 epochs, "
+                        "profiles/r05_cfg4_full_vs_c_oracle.txt)",
             "fp32_carrier_ms_per_epoch": fast_ms / epochs,
             "fp32_carrier_note": "BDS_TRK_PREC=0: fp32 carrier recurrence + fp32 prefix sums; 8d tolerances hold until its first ceil() flip (epoch 142 / 1 588), a bounded floor after it",
             "note": "device time of the epoch loop (one launch per epoch: correlate + the previous epoch's loop update; record window in HBM); locked synthetic record "

@@ -156,10 +156,12 @@ BDS_API void bds_destroy(bds_ctx *ctx);
 /* Environment knobs, read once at bds_create into the context.  The release library reads exactly these:
  *   BDS_ACQ_FP16=0       fp32 storage of the spectra and the inter-pass buffer as well (default: fp16 storage; every reported
  *                        value is decided in f64 either way)
- *   BDS_TRK_PREC=0..5    numerics of the tracking correlator: 5 (default) the reference's own carrier argument per sample in
- *                        f64 -- SURVEY.md 8d tolerances over the whole horizon (4: the same with a sin / cos per sample);
- *                        0 fp32 carrier recurrence, ~1.5x faster in wide-band mode, 8d tolerances until the first ceil()
- *                        flip (a few hundred epochs)
+ *   BDS_TRK_PREC=0..5    numerics of the tracking correlator: 4 (default) a sin / cos of the reference's own carrier argument
+ *                        trigarg(k) per sample in f64 -- correlator sums 1e-13 of |P| from the float64 oracle, the loop state
+ *                        bit-identical for hundreds of epochs, SURVEY.md 8d until a channel's first ceil() flip (cfg4 at full
+ *                        rate: 11 of 12 channels over all 3 600 epochs); 5: the same argument by angle addition (one sin / cos
+ *                        per 16 samples), 12 % faster, 4e-10 of |P| (6 of 12 channels); 0: fp32 carrier recurrence, ~1.5x
+ *                        faster in wide-band mode, first flip after a few hundred epochs
  *   BDS_VERBOSE          progress / fallback messages on stderr
  *   BDS_ACQ_CLOCKPROBE=1 sampled workgroups time themselves with the shader clock (bds_timing.shader_clock_GHz)
  *   BDS_ACQ_PAIR_GB=n|auto serving mode of the search: several PRNs' Doppler rows per launch pair, inter-pass buffer of n GiB

@@ -123,3 +123,60 @@ def backend(threads=0):
         return rm, ra, cm, row_of
 
     return coarse
+
+
+# ---- tracking: one epoch's sample loop by oracle/c/trk_oracle.c --------------------------------------------------------------------
+_code_cache = {}
+
+
+def _code_f64(a):
+    if a is None:
+        return None
+    key = id(a)
+    hit = _code_cache.get(key)
+    if hit is None or hit[0] is not a:
+        if len(_code_cache) > 256:
+            _code_cache.clear()
+        hit = (a, np.ascontiguousarray(a, dtype=np.float64))
+        _code_cache[key] = hit
+    return hit[1]
+
+
+def trk_epoch(raw8, blk, iq, rem_code, step, spc_el, scale, rem_carr, carr_freq, fs, b2a, dcode, pcode, p6code):
+    """The ``correlate=`` evaluator of oracle.tracking.tracking on the C restatement: (sums[18], t_p_last, trig_end)."""
+    L = lib()
+    if not getattr(L, "_trk_ready", False):
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.bds_oracle_trk_epoch.argtypes = [ctypes.POINTER(ctypes.c_int8), ctypes.c_long, ctypes.c_int] + [ctypes.c_double] * 7 + [ctypes.c_int, dp, dp, dp,
+                                                                                                                                 dp, dp, dp]
+        L.bds_oracle_trk_epoch.restype = ctypes.c_int
+        L._trk_ready = True
+    raw8 = np.ascontiguousarray(raw8, dtype=np.int8)
+    sums = np.zeros(18)
+    t_p = ctypes.c_double()
+    t_e = ctypes.c_double()
+    d, p, p6 = _code_f64(dcode), _code_f64(pcode), _code_f64(p6code)
+    rc = L.bds_oracle_trk_epoch(raw8.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)), int(blk), 1 if iq else 0, float(rem_code), float(step),
+                                float(spc_el), float(scale), float(rem_carr), float(carr_freq), float(fs), 1 if b2a else 0, _dp(d), _dp(p), _dp(p6),
+                                _dp(sums), ctypes.byref(t_p), ctypes.byref(t_e))
+    if rc:
+        raise RuntimeError(f"bds_oracle_trk_epoch: {rc}")
+    return sums, t_p.value, t_e.value
+
+
+def tracking_parallel(data, channel, settings, mode=None, threads=None):
+    """oracle.tracking.tracking with the sample loops in C, one thread per channel (the channels are independent loops over the same
+    record; ctypes releases the interpreter lock inside the C call).  ``data``: the record as an int8 array (np.memmap works).
+    Returns the list of per-channel results in channel order (a channel that hits the end of the record keeps status '-', like the
+    reference's first such channel; later channels are still run -- the callers here use records that are long enough)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import tracking as _trk
+
+    def one(ch):
+        res, _ = _trk.tracking(_trk.RawFile(data), [ch], settings.copy(numberOfChannels=1), mode=mode, correlate=trk_epoch)
+        return res[0]
+
+    n = len(channel)
+    with ThreadPoolExecutor(max_workers=max(1, min(n, threads or n))) as ex:
+        return list(ex.map(one, channel))

@@ -42,6 +42,12 @@ class RawFile:
         self.pos += out.size
         return out, out.size
 
+    def read_raw(self, count: int):
+        """The same read without the conversion to double (for a ``correlate=`` evaluator that takes the int8 samples)."""
+        out = np.ascontiguousarray(self.data[self.pos: self.pos + count], dtype=np.int8)
+        self.pos += out.size
+        return out, out.size
+
 
 # --- loop coefficients ---------------------------------------------------------
 def calc_loop_coef(lbw, zeta, k):
@@ -179,11 +185,14 @@ def _template(n, m, mode, pilot):
     return r
 
 
-def tracking(fid: RawFile, channel, settings, mode=None, trace=None):
+def tracking(fid: RawFile, channel, settings, mode=None, trace=None, correlate=None):
     """[trackResults, channel] = tracking(fid, channel, settings).
 
     mode: 'B2A' (B2a/tracking.m), 'NB' (B1C/NB_tracking.m), 'WB' (B1C/WB_tracking.m);
     default from settings.signal / settings.pilotTRKflag as B1C/postProcessing.m:137-143 does.
+    correlate (optional): another evaluator of one epoch's sample loop -- ``correlate(raw_int8, blk, iq, rem_code, step, spc_el, scale,
+    rem_carr, carr_freq, fs, b2a, dcode, pcode | None, p6code | None)`` returning ``(sums[18], t_p_last, trig_end)`` -- e.g. the C
+    restatement (``oracle.cfast.trk_epoch``); the loop filters, discriminators and C/N0 stay this function's.
     """
     if mode is None:
         if str(settings.signal).upper() == "B2A":
@@ -249,69 +258,93 @@ def tracking(fid: RawFile, channel, settings, mode=None, trace=None):
             r.absoluteSample[k - 1] = fid.tell() / adapt  # :226
             step = code_freq / fs  # :230
             blk = int(np.ceil((code_len - rem_code) / step))  # :233
-            raw, nread = fid.read(adapt * blk)
-            if adapt == 2:
-                raw = raw[0::2] + 1j * raw[1::2]
-            if nread != adapt * blk:  # :250-254  partial results, status stays '-'
-                aborted = True
-                break
-            r.remCodePhase[k - 1] = rem_code  # :258
-            kk = np.arange(blk, dtype=np.float64)
-            scale = 1.0 if b2a else 2.0
-
-            def taps(off):
-                # (rem +- spc)[*2] : step[*2] : ...  -> start + k*inc   (:260-263, WB:289-292)
-                t = (rem_code + off) * scale + kk * (step * scale)
-                return t, np.ceil(t).astype(np.int64) + 1
-
-            t_e, i_e = taps(-spc_el)
-            t_l, i_l = taps(+spc_el)
-            t_p, i_p = taps(0.0)
-            e_c, l_c, p_c = dcode[i_e - 1], dcode[i_l - 1], dcode[i_p - 1]
-            if pilot:
-                pe_c, pl_c, pp_c = pcode[i_e - 1], pcode[i_l - 1], pcode[i_p - 1]
-                if mode == "WB":  # WB:298,311,324
-                    p6e = p6code[np.ceil(t_e * 6).astype(np.int64)]
-                    p6l = p6code[np.ceil(t_l * 6).astype(np.int64)]
-                    p6p = p6code[np.ceil(t_p * 6).astype(np.int64)]
-            if b2a:
-                rem_code = (t_p[blk - 1] + step) - code_len  # :295
+            if correlate is not None:
+                raw8, nread = fid.read_raw(adapt * blk)
+                if nread != adapt * blk:  # :250-254
+                    aborted = True
+                    break
+                r.remCodePhase[k - 1] = rem_code  # :258
+                scale = 1.0 if b2a else 2.0
+                sums, t_p_last, trig_end = correlate(raw8, blk, adapt == 2, rem_code, step, spc_el, scale, rem_carr, carr_freq, fs, b2a,
+                                                     dcode, pcode if pilot else None, p6code if (pilot and mode == "WB") else None)
+                rem_code = (t_p_last + step) - code_len if b2a else t_p_last / 2 + step - code_len  # :295 / WB:327
+                r.remCarrPhase[k - 1] = rem_carr  # :300
+                rem_carr = float(np.fmod(trig_end, two_pi))  # :305
+                I_E, Q_E, I_P, Q_P, I_L, Q_L = (float(v) for v in sums[0:6])
+                if pilot:
+                    pI_E, pQ_E, pI_P, pQ_P, pI_L, pQ_L = (float(v) for v in sums[6:12])
+                    if mode == "WB":
+                        sI_E, sQ_E, sI_P, sQ_P, sI_L, sQ_L = (float(v) for v in sums[12:18])
+                        cI_E = -s433 * sI_E + s2933 * pQ_E  # WB:375-380 QMBOC composite
+                        cQ_E = -s433 * sQ_E - s2933 * pI_E
+                        cI_P = -s433 * sI_P + s2933 * pQ_P
+                        cQ_P = -s433 * sQ_P - s2933 * pI_P
+                        cI_L = -s433 * sI_L + s2933 * pQ_L
+                        cQ_L = -s433 * sQ_L - s2933 * pI_L
             else:
-                rem_code = t_p[blk - 1] / 2 + step - code_len  # WB:327
+                raw, nread = fid.read(adapt * blk)
+                if adapt == 2:
+                    raw = raw[0::2] + 1j * raw[1::2]
+                if nread != adapt * blk:  # :250-254  partial results, status stays '-'
+                    aborted = True
+                    break
+                r.remCodePhase[k - 1] = rem_code  # :258
+                kk = np.arange(blk, dtype=np.float64)
+                scale = 1.0 if b2a else 2.0
 
-            r.remCarrPhase[k - 1] = rem_carr  # :300
-            time = np.arange(blk + 1, dtype=np.float64) / fs  # :303
-            trig = ((carr_freq * 2.0 * np.pi) * time) + rem_carr  # :304
-            rem_carr = float(np.fmod(trig[blk], two_pi))  # :305
-            if b2a:
-                carr = np.exp(1j * trig[:blk])  # :309
-                mixed = carr * raw
-                q_bb = mixed.real  # :313
-                i_bb = mixed.imag  # :314
-            else:
-                carr = np.exp(-1j * trig[:blk])  # NB:320
-                mixed = carr * raw
-                i_bb = mixed.real
-                q_bb = mixed.imag
+                def taps(off):
+                    # (rem +- spc)[*2] : step[*2] : ...  -> start + k*inc   (:260-263, WB:289-292)
+                    t = (rem_code + off) * scale + kk * (step * scale)
+                    return t, np.ceil(t).astype(np.int64) + 1
 
-            I_E, Q_E = np.sum(e_c * i_bb), np.sum(e_c * q_bb)
-            I_P, Q_P = np.sum(p_c * i_bb), np.sum(p_c * q_bb)
-            I_L, Q_L = np.sum(l_c * i_bb), np.sum(l_c * q_bb)
-            if pilot:
-                pI_E, pQ_E = np.sum(pe_c * i_bb), np.sum(pe_c * q_bb)
-                pI_P, pQ_P = np.sum(pp_c * i_bb), np.sum(pp_c * q_bb)
-                pI_L, pQ_L = np.sum(pl_c * i_bb), np.sum(pl_c * q_bb)
-                if mode == "WB":
-                    sI_E, sQ_E = np.sum(p6e * i_bb), np.sum(p6e * q_bb)
-                    sI_P, sQ_P = np.sum(p6p * i_bb), np.sum(p6p * q_bb)
-                    sI_L, sQ_L = np.sum(p6l * i_bb), np.sum(p6l * q_bb)
-                    # WB:375-380 QMBOC composite
-                    cI_E = -s433 * sI_E + s2933 * pQ_E
-                    cQ_E = -s433 * sQ_E - s2933 * pI_E
-                    cI_P = -s433 * sI_P + s2933 * pQ_P
-                    cQ_P = -s433 * sQ_P - s2933 * pI_P
-                    cI_L = -s433 * sI_L + s2933 * pQ_L
-                    cQ_L = -s433 * sQ_L - s2933 * pI_L
+                t_e, i_e = taps(-spc_el)
+                t_l, i_l = taps(+spc_el)
+                t_p, i_p = taps(0.0)
+                e_c, l_c, p_c = dcode[i_e - 1], dcode[i_l - 1], dcode[i_p - 1]
+                if pilot:
+                    pe_c, pl_c, pp_c = pcode[i_e - 1], pcode[i_l - 1], pcode[i_p - 1]
+                    if mode == "WB":  # WB:298,311,324
+                        p6e = p6code[np.ceil(t_e * 6).astype(np.int64)]
+                        p6l = p6code[np.ceil(t_l * 6).astype(np.int64)]
+                        p6p = p6code[np.ceil(t_p * 6).astype(np.int64)]
+                if b2a:
+                    rem_code = (t_p[blk - 1] + step) - code_len  # :295
+                else:
+                    rem_code = t_p[blk - 1] / 2 + step - code_len  # WB:327
+
+                r.remCarrPhase[k - 1] = rem_carr  # :300
+                time = np.arange(blk + 1, dtype=np.float64) / fs  # :303
+                trig = ((carr_freq * 2.0 * np.pi) * time) + rem_carr  # :304
+                rem_carr = float(np.fmod(trig[blk], two_pi))  # :305
+                if b2a:
+                    carr = np.exp(1j * trig[:blk])  # :309
+                    mixed = carr * raw
+                    q_bb = mixed.real  # :313
+                    i_bb = mixed.imag  # :314
+                else:
+                    carr = np.exp(-1j * trig[:blk])  # NB:320
+                    mixed = carr * raw
+                    i_bb = mixed.real
+                    q_bb = mixed.imag
+
+                I_E, Q_E = np.sum(e_c * i_bb), np.sum(e_c * q_bb)
+                I_P, Q_P = np.sum(p_c * i_bb), np.sum(p_c * q_bb)
+                I_L, Q_L = np.sum(l_c * i_bb), np.sum(l_c * q_bb)
+                if pilot:
+                    pI_E, pQ_E = np.sum(pe_c * i_bb), np.sum(pe_c * q_bb)
+                    pI_P, pQ_P = np.sum(pp_c * i_bb), np.sum(pp_c * q_bb)
+                    pI_L, pQ_L = np.sum(pl_c * i_bb), np.sum(pl_c * q_bb)
+                    if mode == "WB":
+                        sI_E, sQ_E = np.sum(p6e * i_bb), np.sum(p6e * q_bb)
+                        sI_P, sQ_P = np.sum(p6p * i_bb), np.sum(p6p * q_bb)
+                        sI_L, sQ_L = np.sum(p6l * i_bb), np.sum(p6l * q_bb)
+                        # WB:375-380 QMBOC composite
+                        cI_E = -s433 * sI_E + s2933 * pQ_E
+                        cQ_E = -s433 * sQ_E - s2933 * pI_E
+                        cI_P = -s433 * sI_P + s2933 * pQ_P
+                        cQ_P = -s433 * sQ_P - s2933 * pI_P
+                        cI_L = -s433 * sI_L + s2933 * pQ_L
+                        cQ_L = -s433 * sQ_L - s2933 * pI_L
 
             with np.errstate(all="ignore"):
                 carr_err = np.arctan(np.float64(Q_P) / np.float64(I_P)) / two_pi  # :337

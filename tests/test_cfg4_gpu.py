@@ -63,23 +63,109 @@ def test_cfg4_twelve_channels_36_seconds_from_a_file(ctx, tmp_path):
     assert abs(float(np.mean(cnos)) - 47.0) < 1.0, cnos
 
 
-def test_cfg4_head_against_the_oracle(ctx):
-    """First 200 epochs (2 s of signal at 99.375 MS/s) of the cfg4 record, three of its channels, vs the float64 oracle at SURVEY 8d:
-    far beyond where the fp32 carrier of rounds 2-4 left the oracle's trajectory (its first ceil() flip came at epoch 142 on the
-    long fixture); the strict default holds every epoch (~80 s of oracle time)."""
-    from oracle import tracking as otrk
-
-    base = bds_amd.init_settings_b1c(samplingFreq=99.375e6, IF=14.58e6, acqSatelliteList=list(range(1, 64)), acqCohT=10, pilotACQflag=1)
-    s, ch, blocks, order, shift, n, spc = bench.cfg4_record(base, 200)
-    x = bench.record_bytes(blocks, order, shift, n)
-    sub = [ch[0], ch[5], ch[11]]
-    ref, _ = otrk.tracking(otrk.RawFile(x), sub, s.copy(numberOfChannels=3), mode="WB")
-    got, _ = bds_amd.tracking(x, sub, s.copy(numberOfChannels=3), mode="WB")
+def _compare_with_oracle(ref, got, n_epochs):
+    worst = dict(iq=0.0, carr=0.0, code=0.0)
     for r, g in zip(ref, got):
-        assert g.status == "T"
-        np.testing.assert_array_equal(g.absoluteSample, r.absoluteSample)
+        assert g.status == "T" and r.status == "T"
+        np.testing.assert_array_equal(g.absoluteSample[:n_epochs], r.absoluteSample[:n_epochs])
         p = np.hypot(r.I_P, r.Q_P).max()
         for f in ("I_E", "I_P", "I_L", "Q_E", "Q_P", "Q_L", "Pilot_I_E", "Pilot_I_P", "Pilot_I_L", "Pilot_Q_E", "Pilot_Q_P", "Pilot_Q_L"):
-            np.testing.assert_allclose(getattr(g, f), getattr(r, f), rtol=0, atol=1e-4 * p, err_msg=f)
-        np.testing.assert_allclose(g.carrFreq, r.carrFreq, rtol=0, atol=1e-3)
-        np.testing.assert_allclose(g.codeFreq, r.codeFreq, rtol=0, atol=1e-6)
+            np.testing.assert_allclose(getattr(g, f)[:n_epochs], getattr(r, f)[:n_epochs], rtol=0, atol=1e-4 * p, err_msg=f)
+            worst["iq"] = max(worst["iq"], float(np.max(np.abs(getattr(g, f)[:n_epochs] - getattr(r, f)[:n_epochs])) / p))
+        np.testing.assert_allclose(g.carrFreq[:n_epochs], r.carrFreq[:n_epochs], rtol=0, atol=1e-3)
+        np.testing.assert_allclose(g.codeFreq[:n_epochs], r.codeFreq[:n_epochs], rtol=0, atol=1e-6)
+        worst["carr"] = max(worst["carr"], float(np.max(np.abs(g.carrFreq[:n_epochs] - r.carrFreq[:n_epochs]))))
+        worst["code"] = max(worst["code"], float(np.max(np.abs(g.codeFreq[:n_epochs] - r.codeFreq[:n_epochs]))))
+    return worst
+
+
+def test_cfg4_head_against_the_oracle(ctx):
+    """First 400 epochs (4 s of signal at 99.375 MS/s) of the cfg4 record, ALL 12 channels, vs the float64 oracle at SURVEY 8d: far
+    beyond where the fp32 carrier of rounds 2-4 left the oracle's trajectory (its first ceil() flip came at epoch 142 on the long
+    fixture); the strict default holds every epoch.  The oracle's sample loops run in C (oracle/c/trk_oracle.c, one thread per
+    channel; held against the all-NumPy epoch by tests/test_oracle_c.py), its loop filters in oracle/tracking.py."""
+    from oracle import cfast
+
+    cfast.build()
+    n_ep = 400
+    base = bds_amd.init_settings_b1c(samplingFreq=99.375e6, IF=14.58e6, acqSatelliteList=list(range(1, 64)), acqCohT=10, pilotACQflag=1)
+    s, ch, blocks, order, shift, n, spc = bench.cfg4_record(base, n_ep)
+    x = bench.record_bytes(blocks, order, shift, n)
+    ref = cfast.tracking_parallel(x, ch, s, mode="WB")
+    got, _ = bds_amd.tracking(x, ch, s, mode="WB")
+    worst = _compare_with_oracle(ref, got, n_ep)
+    print(f"cfg4 head, 12 channels x {n_ep} epochs vs the oracle: worst I/Q {worst['iq']:.2e} of |P|, carrFreq {worst['carr']:.2e} Hz, "
+          f"codeFreq {worst['code']:.2e} Hz")
+
+
+def _episodes(bad):
+    """[(first, last)] runs of epochs outside the tolerance, runs less than 20 epochs apart merged (one loop transient)"""
+    idx = np.nonzero(bad)[0]
+    out = []
+    for k in idx:
+        if out and k - out[-1][1] <= 20:
+            out[-1][1] = int(k)
+        else:
+            out.append([int(k), int(k)])
+    return out
+
+
+@pytest.mark.skipif(not os.environ.get("BDS_TEST_CFG4_FULL"), reason="BASELINE configs[3] at full size against the oracle: ~3 min of host time "
+                    "(BDS_TEST_CFG4_FULL=1; the log of such a run is profiles/r05_cfg4_full_vs_c_oracle.txt)")
+def test_cfg4_whole_horizon_against_the_c_oracle(ctx, tmp_path):
+    """BASELINE.json configs[3] literally: 12 channels x 36 000 ms at 99.375 MS/s from the 3.6 GB file, every epoch of every channel
+    against the float64 oracle (sample loops in C, one thread per channel).  absoluteSample must be exact everywhere.  SURVEY 8d's
+    closed-loop tolerances (I/Q 1e-4 of |P|, carrFreq 1e-3 Hz, codeFreq 1e-6 Hz) hold on every channel up to its first ceil() flip:
+    the HIP path and the oracle agree to ~4e-10 of |P| and ~1e-12 chip, 43 200 epoch-channels of 1e6 samples x 21 code-index
+    ceil()s each put ~2 samples within that distance of a chip boundary, ONE flipped sample is 2 |x| ~ 40 against a tolerance of
+    1e-4 |P| ~ 20, and from there on the two loops -- both locked on the same satellite -- differ by a bounded floor that sustains
+    itself (a code phase 1e-6 chip apart flips ~20 samples per epoch).  DESIGN.md section 2: any two float64 implementations that
+    differ in a sin or a summation order do this to each other, MATLAB and NumPy included: the correlator sums of the HIP path are
+    1e-13 of |P| from the oracle's, which moves codeFreq by an ulp now and then and remCodePhase with it by an ulp of the code length
+    (1.8e-12 chip; tools/exp/r5_cfg4_flip.py).  Measured (profiles/r05_cfg4_full_vs_c_oracle.txt): with the default correlator
+    (BDS_TRK_PREC=4) 11 of 12 channels inside 8d over all 3 600 epochs, one separates at epoch 1 530 on a single BOC(6,1) sample;
+    with BDS_TRK_PREC=5 (4e-10 from the oracle) six separate between epochs 1 531 and 3 517.
+    Asserted: few such separations, each starting from a single-sample-sized discrepancy, the floor after them bounded (I/Q 1e-2 of
+    |P|, carrFreq 0.06 Hz, codeFreq 0.02 Hz: the bounds tests/test_track_long_gpu.py held the fp32 carrier to); 8d everywhere else."""
+    from oracle import cfast
+
+    cfast.build()
+    base = bds_amd.init_settings_b1c(samplingFreq=99.375e6, IF=14.58e6, acqSatelliteList=list(range(1, 64)), acqCohT=10, pilotACQflag=1)
+    s, ch, blocks, order, shift, n, spc = bench.cfg4_record(base, EPOCHS)
+    path = os.path.join(os.environ.get("BDS_BENCH_TMP", str(tmp_path)), "cfg4_full.bin")
+    bench.write_record(path, blocks, order, shift, n)
+    try:
+        got, _ = bds_amd.tracking(path, ch, s, mode="WB")
+        data = np.memmap(path, dtype=np.int8, mode="r")
+        ref = cfast.tracking_parallel(data, ch, s, mode="WB")
+        del data
+    finally:
+        os.remove(path)
+    iq_fields = ("I_E", "I_P", "I_L", "Q_E", "Q_P", "Q_L", "Pilot_I_E", "Pilot_I_P", "Pilot_I_L", "Pilot_Q_E", "Pilot_Q_P", "Pilot_Q_L")
+    n_bad = n_eps = 0
+    quiet = dict(iq=0.0, carr=0.0, code=0.0)
+    for c, (r, g) in enumerate(zip(ref, got)):
+        assert g.status == "T" and r.status == "T"
+        np.testing.assert_array_equal(g.absoluteSample, r.absoluteSample)  # every block size of every epoch
+        p = np.hypot(r.I_P, r.Q_P).max()
+        d_iq = np.max(np.stack([np.abs(getattr(g, f) - getattr(r, f)) for f in iq_fields]), axis=0) / p
+        d_carr, d_code = np.abs(g.carrFreq - r.carrFreq), np.abs(g.codeFreq - r.codeFreq)
+        bad = (d_iq > 1e-4) | (d_carr > 1e-3) | (d_code > 1e-6)
+        eps = _episodes(bad)
+        for a, b in eps:
+            print(f"  channel {c} (PRN {r.PRN}): epochs {a + 1}..{b + 1} outside 8d ({b - a + 1} epochs): first discrepancy {d_iq[a] * p:.1f} "
+                  f"(= {d_iq[a]:.2e} of |P|), worst I/Q {d_iq[a:b + 1].max():.2e} of |P|, carrFreq {d_carr[a:b + 1].max():.2e} Hz, "
+                  f"codeFreq {d_code[a:b + 1].max():.2e} Hz")
+            assert d_iq[a] * p <= 4 * 127 * 2          # starts with a few samples' worth, not with a wrong trajectory
+            assert d_iq[a:b + 1].max() <= 1e-2 and d_code[a:b + 1].max() <= 0.02 and d_carr[a:b + 1].max() <= 0.06
+        n_bad += int(bad.sum())
+        n_eps += len(eps)
+        ok = ~bad
+        quiet["iq"] = max(quiet["iq"], float(d_iq[ok].max()))
+        quiet["carr"] = max(quiet["carr"], float(d_carr[ok].max()))
+        quiet["code"] = max(quiet["code"], float(d_code[ok].max()))
+    total = EPOCHS * len(ref)
+    print(f"cfg4 whole horizon, 12 channels x {EPOCHS} epochs x 99.375 MS/s vs the oracle: absoluteSample exact on all {total} epoch-channels; "
+          f"{total - n_bad} inside SURVEY 8d (worst there: I/Q {quiet['iq']:.2e} of |P|, carrFreq {quiet['carr']:.2e} Hz, codeFreq {quiet['code']:.2e} Hz); "
+          f"{n_eps} separation(s) after a ceil() flip, {n_bad} epoch-channels after them")
+    assert n_eps <= 8 and n_bad <= 0.25 * total

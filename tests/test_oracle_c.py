@@ -105,3 +105,33 @@ def test_acq_results_on_the_c_rows_match_the_golden_vectors(name, fn):
     np.testing.assert_array_equal(r.codePhase, z["codePhase"])
     np.testing.assert_array_equal(r.carrFreq, z["carrFreq"])
     np.testing.assert_allclose(r.peakMetric, z["peakMetric"], rtol=1e-11)
+
+
+@pytest.mark.parametrize("signal,mode,n_epochs,iq", [("B2A", "B2A", 30, False), ("B1C", "NB", 6, False), ("B1C", "WB", 6, False),
+                                                      ("B2A", "B2A", 20, True), ("B1C", "WB", 5, True)])
+def test_tracking_epochs_in_c_against_the_numpy_oracle(signal, mode, n_epochs, iq):
+    """oracle/c/trk_oracle.c (one epoch's sample loop: code indices, carrier, the 18 correlator sums) behind the oracle's loop filters
+    against the all-NumPy oracle, closed loop: the same trajectories to rounding (different sin / cos and summation order)."""
+    from oracle import tracking as otrk
+
+    from helpers import track_case
+
+    s, x, chans = track_case(signal, mode, n_epochs, iq=iq)
+    ref, _ = otrk.tracking(otrk.RawFile(x), chans, s, mode=mode)
+    got = cfast.tracking_parallel(x, chans, s, mode=mode, threads=3)
+    for r, g in zip(ref, got):
+        assert g.status == r.status == "T" and g.PRN == r.PRN
+        np.testing.assert_array_equal(g.absoluteSample, r.absoluteSample)
+        p = np.hypot(r.I_P, r.Q_P).max()
+        fields = ["I_E", "I_P", "I_L", "Q_E", "Q_P", "Q_L", "Pilot_I_P", "Pilot_Q_P"]
+        if mode == "WB":
+            fields += ["Pilot_I_E", "Pilot_I_L", "Pilot_Q_E", "Pilot_Q_L"]
+        for f in fields:
+            np.testing.assert_allclose(getattr(g, f), getattr(r, f), rtol=0, atol=1e-9 * p, err_msg=f)
+        np.testing.assert_allclose(g.carrFreq, r.carrFreq, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(g.codeFreq, r.codeFreq, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(g.remCodePhase, r.remCodePhase, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(g.remCarrPhase, r.remCarrPhase, rtol=0, atol=1e-8)
+        cn = "B2a_CNo" if mode == "B2A" else "B1C_CNo"
+        for f in ("DataCNo", "PilotCNo", cn, "DataPLD", "PilotPLD"):
+            np.testing.assert_allclose(getattr(g, f), getattr(r, f), rtol=0, atol=1e-7, err_msg=f)

@@ -9,12 +9,14 @@ by d disagree on ceil() for some sample after about 1 / (3 N d) epochs, and from
 The reference's carrier argument trigarg(k) = (carrFreq*2*pi) .* (k ./ fs) + remCarrPhase carries a rounding noise of
 ~1e-10 rad per sample (one ulp at 1e6 rad); a correlator that forms the carrier any other way -- fp32 (d ~ 1e-9: first flip at
 epoch 142 / 1 588) or even an accurate f64 phasor recurrence (d ~ 1e-11: epoch 3 191 on one channel) -- differs from the
-reference by that noise.  The default correlator (TrkParams::prec 5) reproduces trigarg(k) bit for bit (k ./ fs by an exactly
-rounded reciprocal division, csrc/bds_strict_math.h), takes one f64 sin / cos per lane and 16 samples and reaches the other
-15 by exact angle addition -- trigarg(k + j) - trigarg(k) is an exact f64 difference, its deviation from j 2 pi f / fs a
-first-order correction of ~1e-10 rad -- and keeps the prefix sums in f64: d ~ 1e-12 or exactly 0, no flip on either fixture
-(profiles/r05_trk_prec_first.txt, r05_trk_prec_strict.txt, tools/exp/r5_trk_prec.py; prec 4, a sin / cos per sample, gives the
-same).  The fp32 form (BDS_TRK_PREC=0, 1.5x faster in wide-band mode)
+reference by that noise.  The default correlator (TrkParams::prec 4) reproduces trigarg(k) bit for bit (k ./ fs by an exactly
+rounded reciprocal division, csrc/bds_strict_math.h), takes a library-free f64 sin / cos of it per sample and keeps the prefix
+sums in f64: correlator sums 1e-13 of |P| from the oracle, d a few ulps of the code length (~1e-12 chip) or exactly 0, no flip on
+either fixture (profiles/r05_trk_prec_first.txt, r05_trk_prec_strict.txt, tools/exp/r5_trk_prec.py).  prec 5 -- one sin / cos per
+lane and 16 samples, the other 15 by angle addition with a first-order correction, 12 % faster -- gives the same on these fixtures
+and was the default until the whole of cfg4 at full rate was run against the oracle (tests/test_cfg4_gpu.py, profiles/
+r05_cfg4_full_vs_c_oracle.txt: 43 200 epoch-channels of 1e6 samples; prec 4 is 1e-13 from the oracle and loses ONE channel to a flip,
+prec 5 is 4e-10 and loses six).  The fp32 form (BDS_TRK_PREC=0, 1.5x faster in wide-band mode)
 is kept as an option and tested against the bounded flip-noise floor below."""
 import json
 import os
