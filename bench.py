@@ -195,25 +195,21 @@ def cpu_baseline(s, x, name, budget_s=15.0):
     return out
 
 
-def tracking_leg(name, local_rank, base):
-    """Second half of the hot path, reported beside the headline metric (not part of `value`):
-    closed-loop tracking of 12 channels at 99.375 MS/s on a synthetic int8 record resident in HBM
-    (BASELINE.json configs[3] shape, shortened): B1C wide-band, 10-ms epochs / B2a, 1-ms epochs.
-    The record carries the 12 satellites, so the loops LOCK: one block of whole code periods (Dopplers on the
-    fs / block grid: whole carrier cycles per block) is generated and repeated to the record's length."""
+def track_record(name, base, epochs=None):
+    """Synthetic int8 record + channels for 12-channel closed-loop tracking at the workload's sampling rate: one block of whole code
+    periods carrying the 12 satellites (Dopplers on the fs / block grid: whole carrier cycles per block), repeated to the record's
+    length -- the loops LOCK.  Returns (settings, record, channels as preRun would hand them over, mode, MACs per sample)."""
     from types import SimpleNamespace
 
-    import bds_amd
     from bds_amd import synth
 
-    # same front end as the acquisition workload (fs = 99.375 MS/s)
     if name == "b1c":
-        epochs, mode, periods = 60, "WB", 2
+        epochs, mode, periods = epochs or 60, "WB", 2
         s = base.copy(msToProcess=epochs * 10, numberOfChannels=12, pilotTRKflag=2)
         dopplers = [-1500, -1000, -750, -500, -250, -100, 100, 250, 500, 750, 1000, 1500]  # 50-Hz grid (20-ms block)
         macs = 2 + 2 * 9
     else:
-        epochs, mode, periods = 600, "B2A", 20
+        epochs, mode, periods = epochs or 600, "B2A", 20
         s = base.copy(msToProcess=epochs, numberOfChannels=12)
         # B2a/tracking.m has no code-rate aiding: its DLL only holds small Dopplers (tests/golden/make_long_tracking.py)
         dopplers = [-100, -100, -50, -50, -50, 0, 0, 50, 50, 50, 100, 100]  # 50-Hz grid (20-ms block)
@@ -232,6 +228,16 @@ def tracking_leg(name, local_rank, base):
         code_freq = s.codeFreqBasis - (cf - s.IF) / s.carrFreqBasis * s.codeFreqBasis if name == "b1c" else s.codeFreqBasis
         ch.append(SimpleNamespace(PRN=sat.prn, acquiredFreq=float(cf), codePhase=float(shift + int(np.ceil(sat.delay)) + 1),
                                   codeFreq=float(code_freq), status="T"))
+    return s, x, ch, mode, macs, epochs, spc
+
+
+def tracking_leg(name, local_rank, base):
+    """Second half of the hot path, reported beside the headline metric (not part of `value`):
+    closed-loop tracking of 12 channels at 99.375 MS/s on a synthetic int8 record resident in HBM
+    (BASELINE.json configs[3] shape, shortened): B1C wide-band, 10-ms epochs / B2a, 1-ms epochs (track_record)."""
+    import bds_amd
+
+    s, x, ch, mode, macs, epochs, spc = track_record(name, base)
     ctx = bds_amd.get_context(local_rank)
     # the fp32 carrier / fp32 prefix sums of rounds 2-4 (BDS_TRK_PREC=0: SURVEY 8d only up to its first ceil() flip,
     # tests/test_track_long_gpu.py), timed beside the default for comparison

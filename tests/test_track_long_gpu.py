@@ -93,3 +93,49 @@ def test_full_horizon_fast_correlator(ctx, name, monkeypatch):
         monkeypatch.delenv("BDS_TRK_PREC")
         ctx.reload_tuning()
     _check(z, got, n_epochs, mode, FAST_TIGHT[mode], floor=True)
+
+
+@pytest.mark.skipif(not os.environ.get("BDS_TEST_B2A_TRK_FULL"), reason="B2a tracking at the reference's own defaults (12 channels x 49 000 ms at 99.375 MS/s) "
+                    "against the oracle: a 4.9 GB record and ~5 min of host time (BDS_TEST_B2A_TRK_FULL=1; profiles/r05_b2a_trk_full_vs_c_oracle.txt)")
+def test_b2a_tracking_at_the_references_defaults_whole_horizon(ctx):
+    """B2a/initSettings.m as checked in: fs = 99.375 MS/s, msToProcess = 49 000, 12 channels -- every 1-ms epoch of every channel against
+    the float64 oracle (sample loops in C, oracle/c/trk_oracle.c).  Same assertions as tests/test_cfg4_gpu.py's whole-horizon test:
+    absoluteSample exact everywhere, SURVEY 8d up to a channel's first ceil() flip, a bounded floor after it."""
+    import bench
+    from oracle import cfast
+
+    cfast.build()
+    n_ep = int(os.environ.get("BDS_TEST_B2A_TRK_EPOCHS", "49000"))
+    base = bds_amd.init_settings_b2a()
+    assert base.samplingFreq == 99.375e6 and base.msToProcess == 49000 and base.numberOfChannels == 12
+    s, x, ch, mode, _, _, _ = bench.track_record("b2a", base, epochs=n_ep)
+    got, _ = bds_amd.tracking(x, ch, s, mode=mode)
+    ref = cfast.tracking_parallel(x, ch, s, mode=mode)
+    fields = ("I_E", "I_P", "I_L", "Q_E", "Q_P", "Q_L", "Pilot_I_P", "Pilot_Q_P")
+    n_sep = n_bad = 0
+    quiet = [0.0, 0.0, 0.0]
+    for c, (r, g) in enumerate(zip(ref, got)):
+        assert g.status == "T" and r.status == "T"
+        np.testing.assert_array_equal(g.absoluteSample, r.absoluteSample)
+        p = np.hypot(r.I_P, r.Q_P).max()
+        d_iq = np.max(np.stack([np.abs(getattr(g, f) - getattr(r, f)) for f in fields]), axis=0) / p
+        d_carr, d_code = np.abs(g.carrFreq - r.carrFreq), np.abs(g.codeFreq - r.codeFreq)
+        bad = (d_iq > 1e-4) | (d_carr > 1e-3) | (d_code > 1e-6)
+        if bad.any():
+            a = int(np.argmax(bad))
+            n_sep += 1
+            n_bad += n_ep - a
+            print(f"  channel {c} (PRN {r.PRN}): leaves 8d at epoch {a + 1}: first discrepancy {d_iq[a] * p:.1f} (= {d_iq[a]:.2e} of |P|), afterwards worst I/Q "
+                  f"{d_iq[a:].max():.2e} of |P|, carrFreq {d_carr[a:].max():.2e} Hz, codeFreq {d_code[a:].max():.2e} Hz")
+            assert d_iq[a] * p <= 4 * 127 * 2
+            assert d_iq[a:].max() <= 2e-2 and d_carr[a:].max() <= 0.5 and d_code[a:].max() <= 0.05
+            ok = slice(0, a)
+        else:
+            ok = slice(0, n_ep)
+        if d_iq[ok].size:
+            quiet = [max(quiet[0], float(d_iq[ok].max())), max(quiet[1], float(d_carr[ok].max())), max(quiet[2], float(d_code[ok].max()))]
+    total = n_ep * len(ref)
+    print(f"B2a tracking at the reference's defaults, 12 channels x {n_ep} epochs x 99.375 MS/s vs the oracle: absoluteSample exact on all {total} "
+          f"epoch-channels; {total - n_bad} inside SURVEY 8d (worst there: I/Q {quiet[0]:.2e} of |P|, carrFreq {quiet[1]:.2e} Hz, codeFreq {quiet[2]:.2e} Hz); "
+          f"{n_sep} channel(s) separate after a ceil() flip")
+    assert n_sep <= 6
