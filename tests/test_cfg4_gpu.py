@@ -112,7 +112,8 @@ def _episodes(bad):
 
 @pytest.mark.skipif(not os.environ.get("BDS_TEST_CFG4_FULL"), reason="BASELINE configs[3] at full size against the oracle: ~3 min of host time "
                     "(BDS_TEST_CFG4_FULL=1; the log of such a run is profiles/r05_cfg4_full_vs_c_oracle.txt)")
-def test_cfg4_whole_horizon_against_the_c_oracle(ctx, tmp_path):
+@pytest.mark.parametrize("mode", ["WB", "NB"])
+def test_cfg4_whole_horizon_against_the_c_oracle(ctx, tmp_path, mode):
     """BASELINE.json configs[3] literally: 12 channels x 36 000 ms at 99.375 MS/s from the 3.6 GB file, every epoch of every channel
     against the float64 oracle (sample loops in C, one thread per channel).  absoluteSample must be exact everywhere.  SURVEY 8d's
     closed-loop tolerances (I/Q 1e-4 of |P|, carrFreq 1e-3 Hz, codeFreq 1e-6 Hz) hold on every channel up to its first ceil() flip:
@@ -132,16 +133,19 @@ def test_cfg4_whole_horizon_against_the_c_oracle(ctx, tmp_path):
     cfast.build()
     base = bds_amd.init_settings_b1c(samplingFreq=99.375e6, IF=14.58e6, acqSatelliteList=list(range(1, 64)), acqCohT=10, pilotACQflag=1)
     s, ch, blocks, order, shift, n, spc = bench.cfg4_record(base, EPOCHS)
+    if mode == "NB":  # NB_tracking.m on the same record (B1C/postProcessing.m:137-143 picks the variant by pilotTRKflag)
+        s = s.copy(pilotTRKflag=1)
     path = os.path.join(os.environ.get("BDS_BENCH_TMP", str(tmp_path)), "cfg4_full.bin")
     bench.write_record(path, blocks, order, shift, n)
     try:
-        got, _ = bds_amd.tracking(path, ch, s, mode="WB")
+        got, _ = bds_amd.tracking(path, ch, s, mode=mode)
         data = np.memmap(path, dtype=np.int8, mode="r")
-        ref = cfast.tracking_parallel(data, ch, s, mode="WB")
+        ref = cfast.tracking_parallel(data, ch, s, mode=mode)
         del data
     finally:
         os.remove(path)
-    iq_fields = ("I_E", "I_P", "I_L", "Q_E", "Q_P", "Q_L", "Pilot_I_E", "Pilot_I_P", "Pilot_I_L", "Pilot_Q_E", "Pilot_Q_P", "Pilot_Q_L")
+    iq_fields = ("I_E", "I_P", "I_L", "Q_E", "Q_P", "Q_L", "Pilot_I_P", "Pilot_Q_P") + (
+        ("Pilot_I_E", "Pilot_I_L", "Pilot_Q_E", "Pilot_Q_L") if mode == "WB" else ())
     n_bad = n_eps = 0
     quiet = dict(iq=0.0, carr=0.0, code=0.0)
     for c, (r, g) in enumerate(zip(ref, got)):
@@ -165,7 +169,7 @@ def test_cfg4_whole_horizon_against_the_c_oracle(ctx, tmp_path):
         quiet["carr"] = max(quiet["carr"], float(d_carr[ok].max()))
         quiet["code"] = max(quiet["code"], float(d_code[ok].max()))
     total = EPOCHS * len(ref)
-    print(f"cfg4 whole horizon, 12 channels x {EPOCHS} epochs x 99.375 MS/s vs the oracle: absoluteSample exact on all {total} epoch-channels; "
+    print(f"cfg4 whole horizon ({mode}_tracking), 12 channels x {EPOCHS} epochs x 99.375 MS/s vs the oracle: absoluteSample exact on all {total} epoch-channels; "
           f"{total - n_bad} inside SURVEY 8d (worst there: I/Q {quiet['iq']:.2e} of |P|, carrFreq {quiet['carr']:.2e} Hz, codeFreq {quiet['code']:.2e} Hz); "
           f"{n_eps} separation(s) after a ceil() flip, {n_bad} epoch-channels after them")
     assert n_eps <= 8 and n_bad <= 0.25 * total
