@@ -112,8 +112,9 @@ def _episodes(bad):
 
 @pytest.mark.skipif(not os.environ.get("BDS_TEST_CFG4_FULL"), reason="BASELINE configs[3] at full size against the oracle: ~3 min of host time "
                     "(BDS_TEST_CFG4_FULL=1; the log of such a run is profiles/r05_cfg4_full_vs_c_oracle.txt)")
-@pytest.mark.parametrize("mode", ["WB", "NB"])
-def test_cfg4_whole_horizon_against_the_c_oracle(ctx, tmp_path, mode):
+@pytest.mark.parametrize("mode,fs,epochs,nch", [("WB", 99.375e6, EPOCHS, 12), ("NB", 99.375e6, EPOCHS, 12), ("WB", 53e6, 3700, 10)],
+                         ids=["cfg4-WB", "cfg4-NB", "b1c-defaults-WB"])
+def test_cfg4_whole_horizon_against_the_c_oracle(ctx, tmp_path, mode, fs, epochs, nch):
     """BASELINE.json configs[3] literally: 12 channels x 36 000 ms at 99.375 MS/s from the 3.6 GB file, every epoch of every channel
     against the float64 oracle (sample loops in C, one thread per channel).  absoluteSample must be exact everywhere.  SURVEY 8d's
     closed-loop tolerances (I/Q 1e-4 of |P|, carrFreq 1e-3 Hz, codeFreq 1e-6 Hz) hold on every channel up to its first ceil() flip:
@@ -131,8 +132,13 @@ def test_cfg4_whole_horizon_against_the_c_oracle(ctx, tmp_path, mode):
     from oracle import cfast
 
     cfast.build()
-    base = bds_amd.init_settings_b1c(samplingFreq=99.375e6, IF=14.58e6, acqSatelliteList=list(range(1, 64)), acqCohT=10, pilotACQflag=1)
+    # ("b1c-defaults": the reference's own checked-in B1C settings -- B1C/initSettings.m:57,62,67: fs = 53 MS/s, msToProcess = 37 000,
+    #  numberOfChannels = 10, pilotTRKflag = 2 -- on a record of the same make)
+    base = bds_amd.init_settings_b1c(samplingFreq=fs, IF=14.58e6, acqSatelliteList=list(range(1, 64)), acqCohT=10, pilotACQflag=1)
+    EPOCHS = epochs  # noqa: N806  (shadows the module constant for this run)
     s, ch, blocks, order, shift, n, spc = bench.cfg4_record(base, EPOCHS)
+    if nch != 12:
+        ch, s = ch[:nch], s.copy(numberOfChannels=nch)
     if mode == "NB":  # NB_tracking.m on the same record (B1C/postProcessing.m:137-143 picks the variant by pilotTRKflag)
         s = s.copy(pilotTRKflag=1)
     path = os.path.join(os.environ.get("BDS_BENCH_TMP", str(tmp_path)), "cfg4_full.bin")
@@ -169,7 +175,7 @@ def test_cfg4_whole_horizon_against_the_c_oracle(ctx, tmp_path, mode):
         quiet["carr"] = max(quiet["carr"], float(d_carr[ok].max()))
         quiet["code"] = max(quiet["code"], float(d_code[ok].max()))
     total = EPOCHS * len(ref)
-    print(f"cfg4 whole horizon ({mode}_tracking), 12 channels x {EPOCHS} epochs x 99.375 MS/s vs the oracle: absoluteSample exact on all {total} epoch-channels; "
+    print(f"whole horizon ({mode}_tracking), {len(ref)} channels x {EPOCHS} epochs x {fs / 1e6:g} MS/s vs the oracle: absoluteSample exact on all {total} epoch-channels; "
           f"{total - n_bad} inside SURVEY 8d (worst there: I/Q {quiet['iq']:.2e} of |P|, carrFreq {quiet['carr']:.2e} Hz, codeFreq {quiet['code']:.2e} Hz); "
           f"{n_eps} separation(s) after a ceil() flip, {n_bad} epoch-channels after them")
     assert n_eps <= 8 and n_bad <= 0.25 * total
