@@ -221,6 +221,35 @@ def test_b1c_at_the_references_own_sampling_rates_against_the_c_oracle(ctx, fs):
     assert abs(ref.carrFreq[18] - (s.IF - 1730.0)) <= 25 and abs((ref.codePhase[18] - 1) - 0.613 * spc) % spc <= 3
 
 
+@pytest.mark.parametrize("name", ["b2a", "b1c"])
+def test_resampling_branch_at_full_size_against_the_c_oracle(ctx, name):
+    """The reference's own speed-up option at the BASELINE sizes: resamplingflag = 1 on the cfg2 / cfg3 blocks (fs = 99.375 MS/s above
+    either receiver's resamplingThreshold) -- fir1(700) + filtfilt + band-pass-sampling decimation to 48.06 MS/s (B2a) / 19.62 MS/s (B1C:
+    N shrinks from 1 987 500 to 392 400), the search on the conditioned block, codePhase / carrFreq mapped back
+    (B2a/acquisition.m:54-124,339-356; B1C/acquisition.m:54-123,311-328).  Whole Doppler grids against the oracle (scipy's firwin /
+    filtfilt for the conditioner, rows from the C restatement): B2a all 63 PRNs, B1C the ten injected satellites and six absent PRNs
+    (all 63 with BDS_TEST_ALL_PRNS=1)."""
+    import os
+
+    from oracle import cfast
+
+    cfast.build()
+    s, x, sats, _ = bench.build_workload(name)
+    present = [sat.prn for sat in sats]
+    if name == "b1c" and not os.environ.get("BDS_TEST_ALL_PRNS"):
+        s = s.copy(acqSatelliteList=present + [2, 3, 30, 45, 60, 63])
+        x = x[:6 * 993750]  # (filtfilt runs over the whole longSignal: keep the oracle's share of it short)
+    s = s.copy(resamplingflag=1)
+    res = bds_amd.acquisition(x, s, verbose=False)
+    fn = oacq.acquisition_b1c if name == "b1c" else oacq.acquisition_b2a
+    ref = fn(x.astype(np.float64), s, coarse=cfast.backend(threads=_usable_cpus()))
+    np.testing.assert_array_equal(res.codePhase, ref.codePhase)
+    np.testing.assert_array_equal(res.carrFreq, ref.carrFreq)
+    np.testing.assert_allclose(res.peakMetric, ref.peakMetric, rtol=1e-6)
+    det = set(int(p) for p in np.nonzero(ref.carrFreq)[0] + 1)
+    assert det and det <= set(present)  # (the decimated block is noisier: a weak satellite may drop below the threshold -- in both)
+
+
 def test_argument_errors_are_reported(ctx):
     s = bds_amd.init_settings_b2a(acqSatelliteList=[5])
     x = np.zeros(1000, dtype=np.int8)
