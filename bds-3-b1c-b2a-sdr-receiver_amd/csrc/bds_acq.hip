@@ -1262,6 +1262,7 @@ int AcqRun::search() {
             cl.bin = d_bin + (size_t)pi0 * D;
             cl.cs = d_cs + (size_t)pi0 * D;
             cl.gc = D;
+            if (ctx->tune.list_gc > 0 && D % ctx->tune.list_gc == 0) cl.gc = ctx->tune.list_gc;  // (a chunk must stay inside one PRN's cells)
             // (a call is a handful of pairs: all of them are timed, the last, shorter one included -- cell_pair_ms and
             //  cells_per_pair are then the means a kernel trace of the call shows)
             const bool sample = (np_ == PB || n_pairs_total <= kSamples) && (pair_idx % sample_every) == 0 && nsamp < kSamples;

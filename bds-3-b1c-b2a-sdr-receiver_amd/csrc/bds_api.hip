@@ -66,6 +66,7 @@ Tuning tuning_from_env() {
     t.rows_grid = std::max(0, geti("BDS_ACQ_ROWS_GRID", 0));
     t.overlap = has("BDS_ACQ_OVERLAP");
     t.no_bwreuse = has("BDS_ACQ_NO_BWREUSE");
+    t.list_gc = std::max(0, geti("BDS_ACQ_LIST_GC", 0));
     if (const char *e = std::getenv("BDS_ACQ_KDELTA")) t.kdelta = std::max(0.0, std::min(0.9, std::atof(e)));
     t.no_selfcheck = has("BDS_ACQ_NO_SELFCHECK");
     t.test_force_fallback = has("BDS_ACQ_TEST_FORCE_FALLBACK");

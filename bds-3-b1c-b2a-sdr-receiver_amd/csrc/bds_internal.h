@@ -41,6 +41,7 @@ struct Tuning {
     double pair_gb = 0;              // BDS_ACQ_PAIR_GB (release knob): 0 = lean (one PRN's Doppler row per launch pair on big grids; small grids
                                      // batch up to 8 GiB), > 0 = as many PRNs per pair as fit so many GiB, < 0 ("auto") = 60 % of the free device memory
     int rows_grid = 0;                  // BDS_ACQ_ROWS_GRID: workgroups of the (then persistent) row pass; 0 = one per item
+    int list_gc = 0;                    // BDS_ACQ_LIST_GC: cells one row workgroup walks in a multi-PRN launch pair (a divisor of D; 0 = all D bins of its PRN)
     bool no_bwreuse = false;            // BDS_ACQ_NO_BWREUSE: the B2a second-peak pass runs its own row pass (A/B, tests)
     bool overlap = false;               // BDS_ACQ_OVERLAP: column pass of group k on a second stream beside the row pass of group k+1
     double kdelta = 0;                  // BDS_ACQ_KDELTA: test hook, sieve tolerance override (0 = per-mode default)
