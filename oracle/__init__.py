@@ -18,7 +18,12 @@ restatement instead (tests/test_oracle_*.py):
     for PRN 1-60) and the code digests of SURVEY.md Appendix E;
   * synthetic-IF round trips (injected PRN / Doppler / code delay recovered by
     acquisition, tracking loops lock with the documented I/Q conventions);
-  * agreement with the independent C++/HIP implementation behind the C ABI.
+  * agreement with the independent C++/HIP implementation behind the C ABI;
+  * agreement of two separately written restatements with each other: ``oracle/c/`` restates the hot loops -- the Doppler rows of
+    the coarse search (acq_oracle.c: own mixed-radix transform, OpenMP over the bins) and one tracking epoch's sample loop
+    (trk_oracle.c) -- in C from the same .m lines (``oracle/cfast.py``; tests/test_oracle_c.py holds them against the NumPy
+    statements they replace), which is also what makes the oracle fast enough for whole-grid / whole-horizon checks at the
+    BASELINE sizes.
 One exception is pinned by the reference itself: the packed-sample converter (oracle/unpack.py) is
 checked against the four literal look-up tables of B2a/include/unpack_cplx.m:32-35
 (tests/golden/unpack_cplx_lut.npz).
