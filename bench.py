@@ -352,6 +352,26 @@ def tracking_full_leg(local_rank, base, epochs=3600, path=None):
         res, _ = bds_amd.tracking(path, ch, s, mode="WB")
         wall = time.perf_counter() - t0
         dev_ms = ctx.timing()["total_ms"]
+        # CPU baseline of this leg: the oracle -- its sample loops in C, one thread per channel
+        # (oracle/c/trk_oracle.c; the loop filters in oracle/tracking.py) -- on the head of the same record, all 12 channels
+        cpu = None
+        try:
+            from oracle import cfast
+
+            if cfast.available():
+                n_cpu = 40
+                data = np.memmap(path, dtype=np.int8, mode="r")
+                cfast.tracking_parallel(data, ch[:1], s.copy(msToProcess=10), mode="WB")  # (code generation, library load)
+                t0 = time.perf_counter()
+                cfast.tracking_parallel(data, ch, s.copy(msToProcess=n_cpu * 10), mode="WB")
+                dt_cpu = time.perf_counter() - t0
+                del data
+                cpu = {"ms_per_epoch_12ch": dt_cpu / n_cpu * 1e3, "x_realtime_12ch": n_cpu * 0.010 / dt_cpu, "threads": 12, "kind": "port",
+                       "impl": "oracle/tracking.py with its sample loops in C (oracle/c/trk_oracle.c), one thread per channel",
+                       "sample": f"the first {n_cpu} epochs of the same record, all 12 channels, in {dt_cpu:.1f} s (code generation in Python included); "
+                                 "float64 restatement of WB_tracking.m, not MATLAB"}
+        except Exception as e:  # noqa: BLE001
+            cpu = {"error": repr(e)}
     finally:
         if own and os.path.exists(path):
             os.remove(path)
@@ -362,7 +382,7 @@ def tracking_full_leg(local_rank, base, epochs=3600, path=None):
     return {"mode": "WB", "channels": 12, "epochs": epochs, "completed": [int(r.completed) for r in res], "fs_MHz": s.samplingFreq / 1e6,
             "record_GB": n / 1e9, "wall_s": wall, "device_loop_ms": dev_ms, "x_realtime_12ch_wall": epochs * 0.010 / wall,
             "channels_locked": locked, "cno_dBHz_mean": float(np.mean(cno)), "cno_dBHz_min_max": [min(cno), max(cno)],
-            "record_write_s": t_write,
+            "record_write_s": t_write, "cpu_baseline": cpu,
             "note": "wall time of one WB_tracking call on a raw int8 file: file -> HBM window, 3 600 one-launch epochs, C/N0, results; "
                     "the file itself (synthetic: the 12 satellites at 47 dB-Hz in 20-ms blocks with 32 noise realisations in random order) is written beforehand and not timed"}
 
