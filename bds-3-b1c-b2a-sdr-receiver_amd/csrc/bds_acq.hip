@@ -501,7 +501,8 @@ static void launch_cols_wm(bds_ctx *ctx, hipStream_t sc, const Plan2D &pl, const
     want_lds(ctx, k_cols_wave_f<S, NC, MASKED, ST, NV, ILV, PK>, W::kLdsBytes);
     WColsArgs B = A;
     const int quads = A.ntiles / 32;  // per XCD and cell
-    B.qchunk = std::max(1, std::min(ctx->tune.wcols_qchunk, quads));
+    const int want = ctx->tune.wcols_qchunk > 0 ? ctx->tune.wcols_qchunk : A.G >= 1000 ? 2 : 4;  // (see Tuning::wcols_qchunk: measured at 201 and at 6432 cells per launch)
+    B.qchunk = std::max(1, std::min(want, quads));
     while (quads % B.qchunk) --B.qchunk;
     hipLaunchKernelGGL((k_cols_wave_f<S, NC, MASKED, ST, NV, ILV, PK>), dim3(A.n_items), dim3(W::NT), W::kLdsBytes, sc, B);
 }

@@ -77,7 +77,7 @@ Tuning tuning_from_env() {
     t.small_plan = geti("BDS_ACQ_SMALL", 1);
     t.host_refine = has("BDS_ACQ_HOSTREFINE");
     t.neigh = std::max(0, std::min(4, geti("BDS_ACQ_NEIGH", 0)));
-    t.wcols_qchunk = std::max(1, geti("BDS_ACQ_WCOLS_QCHUNK", 4));
+    t.wcols_qchunk = std::max(0, geti("BDS_ACQ_WCOLS_QCHUNK", 0));
     t.multi_force_rccl = has("BDS_MULTI_FORCE_RCCL");
     t.trk_nblocks = std::max(0, geti("BDS_TRK_NBLOCKS", 0));
     t.trk_chunk = std::max(0, geti("BDS_TRK_CHUNK", 0));

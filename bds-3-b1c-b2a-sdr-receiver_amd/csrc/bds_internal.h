@@ -55,7 +55,9 @@ struct Tuning {
     int neigh = 0;                   // BDS_ACQ_NEIGH: also refine the +-n bin / lag neighbours of every candidate in f64 (rounds 1-3: 1)
     int pk = 1;                      // BDS_ACQ_PK: packed-fp32 butterflies in the wave-private search kernels (bds_fft_pk.h); 0 = one fp32 instruction per real operation
     int ilv = 1;                     // BDS_ACQ_ILV: the wave-private pair of the 768 x 4096 plan keeps both components of an element side by side in the inter-pass buffer (0 = separate planes)
-    int wcols_qchunk = 4;            // BDS_ACQ_WCOLS_QCHUNK: adjacent 128-byte lines of a cell its work list keeps together (DRAM page locality; measured 1: 1.84, 2: 1.70, 4: 1.70, 8: 1.75, 16: 1.83 ms per cfg3 launch)
+    int wcols_qchunk = 0;            // BDS_ACQ_WCOLS_QCHUNK: adjacent 128-byte lines of a cell its work list keeps together (DRAM page locality; round 3, one PRN per launch:
+                                     // 1: 1.84, 2: 1.70, 4: 1.70, 8: 1.75, 16: 1.83 ms per cfg3 launch); 0 = 4 for a launch of one PRN's cells, 2 for a multi-PRN launch (round 5, 32 PRNs
+                                     // per pair, per call: 4: 189.0-190.1, 2: 187.9-188.3, 3: 187.9-188.5, 1: 188.5-188.6, 8: 191.4 ms; one PRN per pair: 4 and 2 the same, 1 +1 %)
     bool verbose = false;            // BDS_VERBOSE
     bool multi_force_rccl = false;      // BDS_MULTI_FORCE_RCCL: a single-device bds_multi still goes through RCCL (test hook)
     int trk_nblocks = 0;                // BDS_TRK_NBLOCKS: test hook, correlate workgroups per channel (0 = sized from the code rate)
