@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 5: the row pass's persistent-grid knob re-checked in the serving mode (24 576 row workgroups per launch). Hooks build.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+export BDS_LIB_PATH="$GRAFT_REPO_ROOT/bds-3-b1c-b2a-sdr-receiver_amd/libbds_mi355x_hooks.so"
+run() {
+  env "$@" timeout 300 python bench.py --workload b1c --steps 3 --warmup 1 --no-cpu-baseline --no-tracking --no-strict-f32 --no-tracking-full --no-b2a --no-cold 2>&1 | python -c "
+import sys,json
+tag=sys.argv[1]
+for l in sys.stdin:
+    if l.startswith('{'):
+        j=json.loads(l); s=j['stage_ms']; r=j['roofline']; print(tag.ljust(34), 'ms/step', round(j['ms_per_step'],2), 'frac', round(r['frac'],4), 'rows', round(r['rows_ms'],3), 'cols', round(r['cols_ms'],3), 'sha', str(j['config'].get('results_sha256'))[8:20])
+    elif 'amdgpu.ids' not in l and ('rror' in l or 'Traceback' in l): print(l.rstrip())
+" "$*"
+}
+{ for rep in 1 2; do run A=1; for g in 512 1024 4096; do run BDS_ACQ_ROWS_GRID=$g; done; done; } 2>&1 | tee gpurun_out/r05_serving_rows_grid.txt
