@@ -1233,6 +1233,7 @@ int AcqRun::search() {
             const size_t need = ((size_t)PB * D * ncomp * elem + 7) / 8;
             if (!(rc = ensure(ctx, &a.d_Bw, &a.bw_cap, std::max(need, bw_batches(a, ctx->tune)) * (size_t)pl.L))) break;
             if (PB <= 2) return rc;
+            (void)hipGetLastError();  // (the failed hipMalloc is handled here: it must not surface at the end of the search)
             PB = (PB + 1) / 2;
             a.pb_last = PB;
             n_pairs_total = (P + PB - 1) / PB, cells_per_pair = (long)PB * D;
