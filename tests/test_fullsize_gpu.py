@@ -178,23 +178,28 @@ def test_b2a_full_grid_every_prn_against_the_c_oracle(ctx):
     assert set(np.nonzero(ref.carrFreq)[0] + 1) == {sat.prn for sat in sats}
 
 
-@pytest.mark.parametrize("fs", [53e6, 30.69e6])
-def test_b1c_at_the_references_own_sampling_rates_against_the_c_oracle(ctx, fs):
+@pytest.mark.parametrize("fs,iq", [(53e6, False), (30.69e6, False), (53e6, True)], ids=["53MSps", "30.69MSps", "53MSps-IQ"])
+def test_b1c_at_the_references_own_sampling_rates_against_the_c_oracle(ctx, fs, iq):
     """The configuration a user of the reference runs first: B1C/initSettings.m as checked in -- fs = 53 MS/s (:57; N = 1 060 000 =
     2^5 5^4 53), IF = 14.58 MHz, acqSatelliteList = [19 20], 201 bins, 10 ms data + pilot -- and the rate its comment keeps beside it
     (30.69 MS/s: N = 613 800 = 2^3 3^2 5^2 11 31), at full size against the oracle on the whole grid (rows from the C restatement,
-    whose transform takes any length; the HIP path pads to its own 5-smooth two-pass length either way)."""
+    whose transform takes any length; the HIP path pads to its own 5-smooth two-pass length either way).  The third case is the same
+    configuration on a fileType-2 record (interleaved I/Q int8, B1C/postProcessing.m:92-96): complex longSignal end to end."""
     from oracle import cfast
 
     from bds_amd import synth
     from helpers import spc_of
 
     cfast.build()
-    s = bds_amd.init_settings_b1c(samplingFreq=fs)
+    s = bds_amd.init_settings_b1c(samplingFreq=fs, fileType=2 if iq else 1)
     assert s.acqSatelliteList == [19, 20] and s.IF == 1590e6 - 1575.42e6
     spc = spc_of(s)
     sats = [synth.Sat(19, -1730.0, 0.613 * spc, 0.7, 45.0), synth.Sat(35, 2210.0, 0.2 * spc, 2.0, 46.0)]  # PRN 20 absent, PRN 35 not searched
-    x = synth.make_if(s, sats, 4 * spc, seed=53)
+    x = synth.make_if(s, sats, 4 * spc, seed=53, iq_sign=-1 if iq else 0)
+    if iq:
+        from helpers import as_complex
+
+        x = as_complex(x)
     res = bds_amd.acquisition(x, s, verbose=False)
     tm = ctx.timing()
     assert tm["n_bins"] == 201 and tm["n_circ"] == 2 * spc
@@ -208,7 +213,7 @@ def test_b1c_at_the_references_own_sampling_rates_against_the_c_oracle(ctx, fs):
         rows[prn] = out
         return out[0], out[1], out[2], None
 
-    ref = oacq.acquisition_b1c(x.astype(np.float64), s, coarse=coarse)
+    ref = oacq.acquisition_b1c(x if iq else x.astype(np.float64), s, coarse=coarse)
     for i, prn in enumerate((19, 20)):
         row_max, row_arg, col_max, _ = rows[prn]
         np.testing.assert_allclose(rm[i], row_max, rtol=tol)
