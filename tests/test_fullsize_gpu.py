@@ -361,6 +361,31 @@ def test_cfg3_kernel_variants_decide_the_same(env, monkeypatch):
         assert tm["cols_kernel"] == 1
 
 
+def test_serving_mode_through_the_api(ctx):
+    """bds_acq_set_pair_budget_gb (the API form of BDS_ACQ_PAIR_GB): the same context searches cfg3's first six PRNs one PRN per launch
+    pair (default), all six in one pair ("auto"), three per pair (16 GiB), and lean again (0) -- the same bits every time."""
+    s, x, sats, _ = bench.build_workload("b1c")
+    prns = [1, 2, 3, 4, 5, 6]
+    c = bds_amd.native.Context(0)
+    try:
+        c.acq_load(s, x)
+        c.acq_prepare(s)
+        out = []
+        for budget, pairs in ((None, 6), ("auto", 1), (16, 2), (0, 6)):
+            if budget is not None:
+                c.acq_set_pair_budget(budget)
+            res = c.acq_run(s, prn_list=prns)
+            tm = c.timing()
+            assert tm["n_pairs"] == pairs and abs(tm["cells_per_pair"] - 201 * 6 / pairs) < 1e-9, (budget, tm["n_pairs"], tm["cells_per_pair"])
+            out.append(res)
+    finally:
+        c.close()
+    for res in out[1:]:
+        for u, v in zip(out[0], res):
+            assert np.array_equal(u, v)
+    assert out[0][0][0] != 0 and out[0][0][3] != 0 and out[0][0][1] == 0  # PRNs 1 and 4 are in the block, PRN 2 is not
+
+
 def test_cfg2_refinement_paths_decide_the_same(monkeypatch):
     """cfg2 with the refinement as one device chain (default: candidates, f64 sums, peak, second-peak pass, threshold and fine
     search without a host round trip) and through the host (BDS_ACQ_HOSTREFINE=1, rounds 1-4): acqResults, the f64 peaks, the
