@@ -1088,9 +1088,12 @@ int AcqRun::setup() {
     // device memory is cleared by the driver at ~33 GB/s and an allocation that needs it waits -- 150 GiB allocated again after a free:
     // 4.5 - 4.8 s (tools/probe/alloc_probe.hip, profiles/r05_alloc_probe.txt).  A first call in a fresh process costs the same in both
     // modes (bench.py `cold`: 234 vs 266 ms); a process that builds and destroys contexts, or the next process on the device, pays for
-    // the clearing.  So it is a SERVING mode, chosen by the deployment (BDS_ACQ_PAIR_GB / bds_acq_set_pair_budget_gb: GiB, or "auto"
-    // = 60 % of the device memory that is free, counting what this context already holds), not the default: the default keeps one
-    // PRN's Doppler row per pair on big grids and a right-sized buffer (cfg3: 5 GB), a footprint a host can plan with.
+    // the clearing.  So the budget is the deployment's to choose (BDS_ACQ_PAIR_GB / bds_acq_set_pair_budget_gb): the DEFAULT is
+    // 40 GiB -- 8 PRNs per pair at cfg3, 2.5 % less time per call than one PRN per pair, a footprint a host can plan with (rounds
+    // 1-5 allocated 20 GB whatever the mode) --, "auto" = 60 % of the device memory that is free (counting what this context already
+    // holds: 32 + 31 PRNs, 150 GiB, another 2.5 %) is the SERVING mode of a process that keeps the device to itself, 0 the minimal
+    // footprint (one PRN's row per pair, 5 GB at cfg3).  With the default budget a big grid is batched only when at least six PRNs
+    // fit a pair (fewer gain nothing: 4 PRNs 197.8 against 196.7 ms); an explicit budget batches from two.
     // Small grids (D <= 104: cfg2's 63 x 26 cells are 4.3 GB) batch up to 8 GiB either way.  The PRNs are dealt evenly over the
     // pairs; with room for less than two PRNs' cells a pair is one group of one PRN.
     // (BDS_ACQ_NOMULTI / BDS_ACQ_MULTI_ANY / BDS_ACQ_PBCELLS / BDS_ACQ_PBCAP_GB of the hooks build: off / on / cells per pair / budget.)
@@ -1112,7 +1115,8 @@ int AcqRun::setup() {
         const long pb_cap = (long)(budget / ((double)ncomp * (double)pl.L * (double)elem));  // cells
         const long pb_cells = tune.pbcells ? std::min<long>(tune.pbcells, pb_cap) : pb_cap;
         const long pb_max = std::min<long>(P, std::max<long>(D <= 104 ? 2 : 1, pb_cells / D));
-        if (pb_max < 2) {
+        const bool explicit_budget = tune.pbcap_gb > 0 || a.pair_gb_set || tune.pair_gb_env || tune.pbcells > 0 || tune.multi_any;
+        if (pb_max < (D <= 104 || explicit_budget ? 2 : 6)) {
             multiprn = false;
         } else {
             const long np_ = (P + pb_max - 1) / pb_max;
@@ -1263,8 +1267,24 @@ int AcqRun::search() {
             CellList cl;
             cl.bin = d_bin + (size_t)pi0 * D;
             cl.cs = d_cs + (size_t)pi0 * D;
+            // Cells one row workgroup walks: all D bins of its PRN if the launch then still has >= 32 waves of row workgroups for the
+            // chip's 512 slots (their tail is what a short launch of long workgroups loses: 8 PRNs per pair in 201-bin workgroups
+            // 197.2-197.5 ms per cfg3 call = the lean mode's 197.0, in 67-bin chunks 192.0-192.3; 32 PRNs the same either way,
+            // profiles/r05_small_pairs*.txt), else the largest divisor of D that gives them, but no chunk below 32 cells (a
+            // workgroup's set-up: code rows, 60 twiddle registers).  A chunk stays inside one PRN's cells, hence a divisor.
             cl.gc = D;
-            if (ctx->tune.list_gc > 0 && D % ctx->tune.list_gc == 0) cl.gc = ctx->tune.list_gc;  // (a chunk must stay inside one PRN's cells)
+            if (ctx->tune.list_gc > 0 && D % ctx->tune.list_gc == 0) {
+                cl.gc = ctx->tune.list_gc;
+            } else if (ctx->tune.list_gc == 0) {
+                const long want_wgs = 32L * 512;
+                for (int dv = 1; dv <= D; ++dv) {
+                    if (D % dv) continue;
+                    const int gc_ = D / dv;  // dv chunks per PRN and row
+                    if (gc_ < 32 && dv > 1) break;
+                    cl.gc = gc_;
+                    if ((long)pl.L1 * np_ * dv >= want_wgs) break;
+                }
+            }
             // (a call is a handful of pairs: all of them are timed, the last, shorter one included -- cell_pair_ms and
             //  cells_per_pair are then the means a kernel trace of the call shows)
             const bool sample = (np_ == PB || n_pairs_total <= kSamples) && (pair_idx % sample_every) == 0 && nsamp < kSamples;

@@ -32,8 +32,9 @@ int fail(bds_ctx *ctx, int code, const char *fmt, ...) {
 //                       sample; 5 = the same argument by angle addition, 12 % faster, 1e-10 instead of 1e-13 from the oracle; 0 = fp32 carrier)
 //   BDS_VERBOSE         progress / fallback messages on stderr
 //   BDS_ACQ_CLOCKPROBE  sampled workgroups time themselves with the shader clock (bds_timing::shader_clock_GHz)
-//   BDS_ACQ_PAIR_GB     serving mode of the search: several PRNs per launch pair, inter-pass buffer of so many GiB ("auto": 60 % of the
-//                       free device memory); default 0 = lean (bds_acq_set_pair_budget_gb is the same switch for a host program)
+//   BDS_ACQ_PAIR_GB     budget of the search's inter-pass buffer in GiB: a launch pair carries as many PRNs' Doppler rows as fit (default
+//                       40; "auto": 60 % of the free device memory, the serving mode; 0: minimal, one PRN per pair); bds_acq_set_pair_budget_gb
+//                       is the same switch for a host program
 // Everything else -- kernel selection, launch shapes, plan overrides, the sieve tolerance, the switches that turn the
 // completeness self-check off or force a fallback -- exists only in the TEST-HOOKS build (BDS_TEST_HOOKS=1 ./build.sh ->
 // libbds_mi355x_hooks.so, what tests/ load): a stray variable in a MATLAB session cannot change what the release library decides.
@@ -48,7 +49,7 @@ Tuning tuning_from_env() {
     t.trk_prec = geti("BDS_TRK_PREC", 4);
     t.verbose = has("BDS_VERBOSE");
     t.clockprobe = geti("BDS_ACQ_CLOCKPROBE", 0);
-    if (const char *e = std::getenv("BDS_ACQ_PAIR_GB")) t.pair_gb = (e[0] == 'a' || e[0] == 'A') ? -1.0 : std::atof(e);
+    if (const char *e = std::getenv("BDS_ACQ_PAIR_GB")) t.pair_gb = (e[0] == 'a' || e[0] == 'A') ? -1.0 : std::atof(e), t.pair_gb_env = true;
 #ifdef BDS_TEST_HOOKS
     if (const char *e = std::getenv("BDS_ACQ_FORCE_L1L2")) {
         int a = 0, b = 0;
@@ -66,7 +67,7 @@ Tuning tuning_from_env() {
     t.rows_grid = std::max(0, geti("BDS_ACQ_ROWS_GRID", 0));
     t.overlap = has("BDS_ACQ_OVERLAP");
     t.no_bwreuse = has("BDS_ACQ_NO_BWREUSE");
-    t.list_gc = std::max(0, geti("BDS_ACQ_LIST_GC", 0));
+    t.list_gc = std::max(-1, geti("BDS_ACQ_LIST_GC", 0));
     if (const char *e = std::getenv("BDS_ACQ_KDELTA")) t.kdelta = std::max(0.0, std::min(0.9, std::atof(e)));
     t.no_selfcheck = has("BDS_ACQ_NO_SELFCHECK");
     t.test_force_fallback = has("BDS_ACQ_TEST_FORCE_FALLBACK");

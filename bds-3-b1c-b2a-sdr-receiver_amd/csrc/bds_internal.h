@@ -38,10 +38,12 @@ struct Tuning {
     bool multi_any = false, nomulti = false;  // BDS_ACQ_MULTI_ANY / BDS_ACQ_NOMULTI: multi-PRN launch pairs
     int pbcells = 0;                 // BDS_ACQ_PBCELLS
     double pbcap_gb = 0;             // BDS_ACQ_PBCAP_GB (hooks): budget of the inter-pass buffer of a multi-PRN launch pair, overrides pair_gb
-    double pair_gb = 0;              // BDS_ACQ_PAIR_GB (release knob): 0 = lean (one PRN's Doppler row per launch pair on big grids; small grids
-                                     // batch up to 8 GiB), > 0 = as many PRNs per pair as fit so many GiB, < 0 ("auto") = 60 % of the free device memory
+    bool pair_gb_env = false;        // BDS_ACQ_PAIR_GB was given
+    double pair_gb = 40;             // BDS_ACQ_PAIR_GB (release knob): budget of the inter-pass buffer in GiB -- a launch pair carries as many PRNs' Doppler
+                                     // rows as fit (default 40: 8 PRNs at cfg3); 0 = minimal (one PRN's row per pair on big grids; small grids batch up
+                                     // to 8 GiB), < 0 ("auto") = 60 % of the free device memory
     int rows_grid = 0;                  // BDS_ACQ_ROWS_GRID: workgroups of the (then persistent) row pass; 0 = one per item
-    int list_gc = 0;                    // BDS_ACQ_LIST_GC: cells one row workgroup walks in a multi-PRN launch pair (a divisor of D; 0 = all D bins of its PRN)
+    int list_gc = 0;                    // BDS_ACQ_LIST_GC: cells one row workgroup walks in a multi-PRN launch pair (a divisor of D; 0 = chosen by the launch's size, -1 = all D bins of its PRN)
     bool no_bwreuse = false;            // BDS_ACQ_NO_BWREUSE: the B2a second-peak pass runs its own row pass (A/B, tests)
     bool overlap = false;               // BDS_ACQ_OVERLAP: column pass of group k on a second stream beside the row pass of group k+1
     double kdelta = 0;                  // BDS_ACQ_KDELTA: test hook, sieve tolerance override (0 = per-mode default)

@@ -466,13 +466,14 @@ def b2a_leg(local_rank, steps=5):
 
 
 def other_mode_leg(local_rank, s, x, budget, steps=3):
-    """Extra key `lean` / `serving` (never `value`): the same workload in the search mode the headline does NOT use, timed like the
+    """Extra keys `serving` / `default` / `minimal` (never `value`): the same workload in the search mode the headline does NOT use, timed like the
     headline (block resident, code spectra cached, `steps` whole bds_acq_run calls after one untimed call that allocates the buffers)."""
     import bds_amd
 
     c = bds_amd.native.Context(local_rank)
     try:
-        c.acq_set_pair_budget(budget)
+        if budget is not None:
+            c.acq_set_pair_budget(budget)
         c.acq_load(s, x)
         c.acq_prepare(s)
         t0 = time.perf_counter()
@@ -490,7 +491,8 @@ def other_mode_leg(local_rank, s, x, budget, steps=3):
     n, d, p, nc = tm["n_circ"], tm["n_bins"], tm["n_prn"], tm["n_comp"]
     pair_ms = float(np.mean([t["cell_pair_ms"] for t in tims]))
     bpp = tm["cells_per_pair"] * 8 * (1 + nc) * n
-    return {"mode": "lean (library default: one PRN's Doppler row per launch pair)" if budget == 0 else "serving (bds_acq_set_pair_budget_gb(auto))",
+    return {"mode": {None: "library default (inter-pass buffer budget 40 GiB)", 0: "minimal (bds_acq_set_pair_budget_gb(0): one PRN's Doppler row per launch pair)"}.get(
+                budget, "serving (bds_acq_set_pair_budget_gb(auto))"),
             "ms_per_step": dt * 1e3, "steps": steps, "value": float(n) * p * d / dt / 1e6, "unit": "Msamples/s",
             "stage_ms": {k: float(np.mean([t[k] for t in tims])) for k in ("total_ms", "forward_ms", "search_ms", "refine_ms")},
             "frac": bpp / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pair_ms > 0 else None, "pair_ms": pair_ms, "rows_ms": tm.get("rows_ms"),
@@ -500,7 +502,7 @@ def other_mode_leg(local_rank, s, x, budget, steps=3):
             "first_run_ms": first * 1e3, "satellites_detected": sorted(int(q) for q in np.nonzero(res[0])[0] + 1)}
 
 
-def cold_leg(local_rank, s, x, budget=0):
+def cold_leg(local_rank, s, x, budget=None):
     """`cold` measured in a FRESH PROCESS (python bench.py --cold-child ...): the HIP runtime keeps freed device memory of moderate
     size in the process, so a fresh context inside this process would get its buffers back for nothing -- a first call from a new
     MATLAB session does not.  Falls back to the in-process measurement if the child fails."""
@@ -523,7 +525,7 @@ def cold_leg(local_rank, s, x, budget=0):
     return d
 
 
-def cold_leg_here(local_rank, s, x, budget=0):
+def cold_leg_here(local_rank, s, x, budget=None):
     """Extra key `cold` (SURVEY.md 8d "also report cold"; the reference times the whole call, postProcessing.m:104-112): a
     FRESH context, wall time of each step with a device-wide synchronisation after it -- the IF block to HBM (bds_acq_load:
     H2D + block statistics), the per-PRN code generation and code-spectrum transforms (bds_acq_prepare), the first
@@ -539,7 +541,8 @@ def cold_leg_here(local_rank, s, x, budget=0):
     t0 = tick()
     c = bds_amd.native.Context(local_rank)
     try:
-        c.acq_set_pair_budget(budget)
+        if budget is not None:
+            c.acq_set_pair_budget(budget)
         t1 = tick()
         c.acq_load(s, x)
         t2 = tick()
@@ -553,7 +556,8 @@ def cold_leg_here(local_rank, s, x, budget=0):
         c.close()
     return {"create_ms": (t1 - t0) * 1e3, "load_ms": (t2 - t1) * 1e3, "prepare_ms": (t3 - t2) * 1e3, "first_run_ms": (t4 - t3) * 1e3,
             "cold_total_ms": (t4 - t1) * 1e3, "warm_run_ms": (t5 - t4) * 1e3, "block_MB": x.nbytes / 1e6,
-            "mode": "lean (library default)" if budget == 0 else "serving (bds_acq_set_pair_budget_gb(auto): first_run includes the allocation of the inter-pass buffer)",
+            "mode": "library default" if budget is None else "minimal (budget 0)" if budget == 0 else
+                    "serving (bds_acq_set_pair_budget_gb(auto): first_run includes the allocation of the inter-pass buffer)",
             "note": "fresh context; load = H2D of the int8 block + its statistics, prepare = 63 x code generation + code-spectrum "
                     "transforms (cached across calls afterwards), first_run = first bds_acq_run (buffers, plan constants); "
                     "cold_total = load + prepare + first_run; wall clock with a device synchronisation after each step"}
@@ -599,16 +603,20 @@ def main():
     ap.add_argument("--cold-child", default=None, choices=["b1c", "b2a"], help=argparse.SUPPRESS)  # internal: the cold leg in a fresh process
     ap.add_argument("--cold-budget", default="0", help=argparse.SUPPRESS)
     ap.add_argument("--cold-device", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--lean", action="store_true",
-                    help="time the library's lean default (one PRN's Doppler row per launch pair, 5 GB inter-pass buffer) as the headline "
-                         "instead of its serving mode (bds_acq_set_pair_budget_gb(auto): several PRNs per pair, buffer up to 60 %% of the free "
-                         "HBM, allocated before the timed region); the other mode is timed beside it either way (key `lean` / `serving`)")
+    ap.add_argument("--mode", default="serving", choices=["serving", "default", "minimal"],
+                    help="inter-pass buffer budget of the search the headline runs with (include/bds_mi355x.h, bds_acq_set_pair_budget_gb): "
+                         "serving = 'auto', as many PRNs' Doppler rows per launch pair as 60 %% of the free HBM hold (allocated before the timed "
+                         "region); default = the library's own default (40 GiB: 8 PRNs per pair at cfg3); minimal = 0 (one PRN per pair, 5 GB). "
+                         "The other two are timed beside the headline (keys `serving` / `default` / `minimal`)")
+    ap.add_argument("--lean", action="store_true", help="same as --mode minimal")
     args = ap.parse_args()
+    if args.lean:
+        args.mode = "minimal"
 
     if args.cold_child:  # the cold leg of another bench.py, in this fresh process
         s_, x_, _, _ = build_workload(args.cold_child)
         b = args.cold_budget
-        print(json.dumps(cold_leg_here(args.cold_device, s_, x_, "auto" if b.lower().startswith("a") else float(b))))
+        print(json.dumps(cold_leg_here(args.cold_device, s_, x_, None if b == "None" else "auto" if b.lower().startswith("a") else float(b))))
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -657,9 +665,11 @@ def main():
         g["ctx"] = bds_amd.get_context(local_rank) if k == 0 else bds_amd.native.Context(local_rank)
         # The headline is a THROUGHPUT figure of a context that is called again and again with its inputs resident: the library's
         # serving mode (include/bds_mi355x.h, bds_acq_set_pair_budget_gb / BDS_ACQ_PAIR_GB=auto) -- as many PRNs' Doppler rows per launch
-        # pair as 60 % of the free HBM hold.  A first call costs the same in both modes (`cold`, measured in fresh processes); the price
-        # is the footprint and the driver's clearing of it when the context goes.  The lean default is timed beside it (`lean`).
-        g["ctx"].acq_set_pair_budget(0 if args.lean else "auto")
+        # pair as 60 % of the free HBM hold.  A first call costs the same in every mode (`cold`, measured in fresh processes); the price
+        # is the footprint and the driver's clearing of it when the context goes.  The library default (40 GiB) and the minimal
+        # footprint (one PRN per pair) are timed beside it (`default`, `minimal`).
+        if args.mode != "default":
+            g["ctx"].acq_set_pair_budget({"serving": "auto", "minimal": 0}[args.mode])
         if g["shard"]:
             g["ctx"].acq_load(g["s"], g["x"])
             g["ctx"].acq_prepare(g["s"])
@@ -791,10 +801,11 @@ def main():
         "dtype_detail": {0: "f32 search + f64 refinement", 1: "f32 search on f16-stored spectra + f64 refinement"}[int(tm.get("half_storage", 0))],
         "data": "synthetic",
         "config": {"workload": label, "prns": p_total, "doppler_bins": n_bins, "n_circ": n_circ,
-                   "search_mode": ("lean (library default): one PRN's Doppler row per launch pair" if args.lean or tm["n_pairs"] >= p_total else
-                                   "serving (bds_acq_set_pair_budget_gb(auto) = BDS_ACQ_PAIR_GB=auto): %d launch pairs of %.0f (PRN, bin) cells on average, "
-                                   "inter-pass buffer allocated in the warm-up call (a first call in a fresh process: cold.b1c_serving); the lean default "
-                                   "is timed beside it (key `lean`)" % (int(tm["n_pairs"]), tm["cells_per_pair"])),
+                   "search_mode": {"minimal": "minimal (bds_acq_set_pair_budget_gb(0)): one PRN's Doppler row per launch pair",
+                                   "default": "library default (inter-pass buffer budget 40 GiB): %d launch pairs of %.0f (PRN, bin) cells on average" % (int(tm["n_pairs"]), tm["cells_per_pair"]),
+                                   "serving": "serving (bds_acq_set_pair_budget_gb(auto) = BDS_ACQ_PAIR_GB=auto): %d launch pairs of %.0f (PRN, bin) cells on average, "
+                                              "inter-pass buffer allocated in the warm-up call (a first call in a fresh process: cold.b1c_serving); the library default "
+                                              "(40 GiB) and the minimal footprint are timed beside it (keys `default`, `minimal`)" % (int(tm["n_pairs"]), tm["cells_per_pair"])}[args.mode],
                    "fft_len": tm["fft_len"], "components": ncomp,
                    "parallelism": f"(signal, PRN) job shard x{world}, LPT by cost; one all-reduce(SUM) of 3 x 63 f64 per signal",
                    "jobs": sum(len(set(int(p) for p in g["s"].acqSatelliteList)) for g in sigs),
@@ -849,10 +860,10 @@ def main():
                 valu["shader_clock_GHz"] = ck["shader_clock_GHz"]
                 valu["shader_clock_source"] = "measured in this run (one extra call, BDS_ACQ_CLOCKPROBE=1: sampled workgroups, s_memtime against s_memrealtime)"
                 valu["bound_ms_at_shader_clock"] = valu["bound_ms"] * valu["clock_GHz"] / ck["shader_clock_GHz"]
-                # (the clock probe runs a lean context: its pair is one PRN's cells -- compare at the same cells per pair)
+                # (the clock probe runs a context of its own, at the library's default budget -- compare at the same cells per pair)
                 valu["frac_of_issue_bound_at_shader_clock"] = (valu["bound_ms_at_shader_clock"] * ck["cells_per_pair"] / cells_per_pair / ck["pair_ms"]
                                                                if ck["pair_ms"] and cells_per_pair else None)
-                valu["shader_clock_probe_pair"] = {"pair_ms": ck["pair_ms"], "cells_per_pair": ck["cells_per_pair"], "mode": "lean context"}
+                valu["shader_clock_probe_pair"] = {"pair_ms": ck["pair_ms"], "cells_per_pair": ck["cells_per_pair"], "mode": "library default"}
         if world == 1 and len(sigs) == 1 and args.prns == 63 and not args.no_cold:
             out["cold"] = {names[0]: cold_leg(local_rank, s, x)}
             if names == ["b1c"]:
@@ -861,7 +872,9 @@ def main():
                 s2, x2, _, _ = build_workload("b2a")
                 out["cold"]["b2a"] = cold_leg(local_rank, s2, x2)
         if world == 1 and names == ["b1c"] and args.prns == 63 and not args.no_fast_path:
-            out["serving" if args.lean else "lean"] = other_mode_leg(local_rank, s, x, "auto" if args.lean else 0)
+            for m, b in (("serving", "auto"), ("default", None), ("minimal", 0)):
+                if m != args.mode:
+                    out[m] = other_mode_leg(local_rank, s, x, b)
         out["b2a"] = b2a_leg(local_rank) if world == 1 and names == ["b1c"] and not args.no_b2a and args.prns == 63 else None
         if len(sigs) > 1:
             out["config"]["satellites_detected_per_signal"] = {g["name"]: sorted(int(p) for p in np.nonzero(r[0])[0] + 1)

@@ -164,8 +164,8 @@ BDS_API void bds_destroy(bds_ctx *ctx);
  *                        faster in wide-band mode, first flip after a few hundred epochs
  *   BDS_VERBOSE          progress / fallback messages on stderr
  *   BDS_ACQ_CLOCKPROBE=1 sampled workgroups time themselves with the shader clock (bds_timing.shader_clock_GHz)
- *   BDS_ACQ_PAIR_GB=n|auto serving mode of the search: several PRNs' Doppler rows per launch pair, inter-pass buffer of n GiB
- *                        ("auto": 60 % of the free device memory); default 0 = lean.  See bds_acq_set_pair_budget_gb.
+ *   BDS_ACQ_PAIR_GB=n|auto budget of the search's inter-pass buffer in GiB: several PRNs' Doppler rows per launch pair (default 40;
+ *                        "auto": 60 % of the free device memory, the serving mode; 0: minimal).  See bds_acq_set_pair_budget_gb.
  * (plus BDS_MEX_DEVICES in the MEX gateway and BDS_LIB_PATH in the ctypes host).  Kernel-selection, launch-shape and sieve
  * switches, the RCCL path override and the aliased-device hook exist only in libbds_mi355x_hooks.so (-DBDS_TEST_HOOKS,
  * built beside the release library by build.sh; tools/README.md lists them), which is what tests/ load.
@@ -215,14 +215,18 @@ BDS_API int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s);
 BDS_API int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *prn_list, int n_prn,
                         int max_prn, double *carrFreq, double *codePhase, double *peakMetric,
                         int32_t *detected);
-/* Serving mode of the search, for a process that calls bds_acq_run again and again on one context.  By default (lean) a launch
- * pair of a big Doppler grid carries one PRN's row of bins and the inter-pass buffer is sized for that (cfg3: 5 GB): right for
- * the reference's use, ONE acquisition() per run (B1C/postProcessing.m:105-111).  With a budget of `gib` GiB (< 0: 60 % of the
- * device memory that is free) a pair carries as many PRNs' rows as fit -- cfg3 on 288 GB: 32 + 31 PRNs, a 150 GiB buffer, 3.4 %
- * less time per call (190 vs 197 ms).  The price is the footprint, and time when it changes hands: a fresh allocation is free
- * (a first call costs the same in both modes), but the driver clears freed device memory at ~33 GB/s and whoever allocates next
- * waits -- up to ~4.8 s after such a context is destroyed.  Results are the same bits in both modes.  Same switch as the
- * environment knob BDS_ACQ_PAIR_GB (number of GiB, or "auto"); takes effect at the next bds_acq_run. */
+/* Budget of the search's inter-pass buffer: a launch pair (row pass + column pass) carries as many PRNs' Doppler rows as fit
+ * `gib` GiB, and the more it carries the less a call costs -- the row workgroups of the PRNs share the signal-spectrum rows in L2
+ * and a call is a few long launches.  cfg3 (63 PRNs x 201 bins, 5 GB per PRN) on one box:
+ *     0        one PRN per pair,  5 GB     196.7 ms per call      (the minimal footprint)
+ *    40        8 PRNs per pair,  40 GB     191.6 - 192.1          (the DEFAULT)
+ *    80       16 PRNs per pair,  80 GB     189.3 - 189.8
+ *   < 0       60 % of the device memory that is free: 32 + 31 PRNs, 150 GiB   186.8 - 187.1   (the SERVING mode of a process
+ *             that keeps the device to itself; what bench.py times as its headline)
+ * The price is the footprint, and time when it changes hands: a fresh allocation is free (a first call costs the same in every
+ * mode), but the driver clears freed device memory at ~33 GB/s and whoever allocates next waits -- up to ~4.8 s after a 150-GiB
+ * context is destroyed.  Results are the same bits in every mode.  Same switch as the environment knob BDS_ACQ_PAIR_GB (number
+ * of GiB, or "auto"); takes effect at the next bds_acq_run. */
 BDS_API int bds_acq_set_pair_budget_gb(bds_ctx *ctx, double gib);
 
 /* Diagnostics of the last bds_acq_run: per searched PRN (in search order) and Doppler

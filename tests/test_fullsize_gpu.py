@@ -362,8 +362,9 @@ def test_cfg3_kernel_variants_decide_the_same(env, monkeypatch):
 
 
 def test_serving_mode_through_the_api(ctx):
-    """bds_acq_set_pair_budget_gb (the API form of BDS_ACQ_PAIR_GB): the same context searches cfg3's first six PRNs one PRN per launch
-    pair (default), all six in one pair ("auto"), three per pair (16 GiB), and lean again (0) -- the same bits every time."""
+    """bds_acq_set_pair_budget_gb (the API form of BDS_ACQ_PAIR_GB): the same context searches cfg3's first six PRNs all in one launch
+    pair (the default budget of 40 GiB holds eight PRNs' cells; "auto" likewise), three per pair (16 GiB), one PRN per pair (0: the
+    minimal footprint) -- the same bits every time."""
     s, x, sats, _ = bench.build_workload("b1c")
     prns = [1, 2, 3, 4, 5, 6]
     c = bds_amd.native.Context(0)
@@ -371,7 +372,7 @@ def test_serving_mode_through_the_api(ctx):
         c.acq_load(s, x)
         c.acq_prepare(s)
         out = []
-        for budget, pairs in ((None, 6), ("auto", 1), (16, 2), (0, 6)):
+        for budget, pairs in ((None, 1), (0, 6), ("auto", 1), (16, 2), (0, 6)):
             if budget is not None:
                 c.acq_set_pair_budget(budget)
             res = c.acq_run(s, prn_list=prns)
