@@ -21,17 +21,19 @@ elif [ "${BDS_SAN:-0}" = 1 ]; then
     EXTRA+=(-Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer -Xarch_host -fno-sanitize-recover=undefined)
     LINK+=(-fsanitize=address,undefined -shared-libsan)
 fi
+# Two libraries from one set of objects: the RELEASE library reads the documented environment knobs (csrc/bds_api.hip,
+# include/bds_mi355x.h); libbds_mi355x_hooks.so (-DBDS_TEST_HOOKS: only bds_api.hip and bds_multi.hip differ) also reads the
+# tuning / test switches and is what tests/ and tools/exp/ load (tests/conftest.py).  BDS_TEST_HOOKS=0 skips it.
+# Debug / sanitizer builds carry the hooks themselves.  (This has to stand BEFORE FLAGS is formed: for most of round 5 it stood after,
+# so the debug library had no hooks and tools/run_debug.sh stopped at the suite's "needs the test-hooks build" assertion.)
+HOOKS="${BDS_TEST_HOOKS:-1}"
+if [ "${BDS_DEBUG:-0}" = 1 ] || [ "${BDS_SAN:-0}" = 1 ]; then HOOKS=0; EXTRA+=(-DBDS_TEST_HOOKS=1); fi
 # -ffp-contract=off everywhere except the search (bds_acq.hip): the tracking NCO index
 # arithmetic must round exactly like the reference's a + k*d (two roundings), while the
 # fp32 transform butterflies want FMA contraction.
 FLAGS=(--offload-arch=gfx950 $OPT -std=c++17 -fPIC -fvisibility=hidden
        -Wall -Wno-unused-result -I"$ROOT/include" -I"$SRC" "${EXTRA[@]}")
 mkdir -p "$BLD"
-# Two libraries from one set of objects: the RELEASE library reads four documented environment knobs (csrc/bds_api.hip,
-# include/bds_mi355x.h); libbds_mi355x_hooks.so (-DBDS_TEST_HOOKS: only bds_api.hip and bds_multi.hip differ) also reads the
-# tuning / test switches and is what tests/ and tools/exp/ load (tests/conftest.py).  BDS_TEST_HOOKS=0 skips it.
-HOOKS="${BDS_TEST_HOOKS:-1}"
-[ "${BDS_DEBUG:-0}" = 1 ] || [ "${BDS_SAN:-0}" = 1 ] && HOOKS=0 && EXTRA+=(-DBDS_TEST_HOOKS=1)   # debug / sanitizer builds carry the hooks themselves
 compile() {  # source, object, extra flags...
     local f="$1" o="$2"; shift 2
     # rebuild when the source or any header is newer than the object
