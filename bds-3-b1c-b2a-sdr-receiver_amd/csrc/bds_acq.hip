@@ -248,6 +248,18 @@ static int ensure(bds_ctx *ctx, T **p, size_t *cap, size_t need) {
     return BDS_OK;
 }
 
+// The inter-pass buffer also SHRINKS (round 6): a context that ran with a larger budget (serving mode: 150 GiB) and is
+// then given a smaller one -- bds_acq_set_pair_budget_gb(ctx, 0), a lower BDS_ACQ_PAIR_GB -- returns the difference at its next
+// search instead of holding it until bds_destroy.  Called where a run knows its final need (search()); the other ensure() sites
+// only grow.  A quarter of slack (+256 MiB) is tolerated so that neighbouring settings do not reallocate back and forth.
+template <class T>
+static int ensure_fit(bds_ctx *ctx, T **p, size_t *cap, size_t need) {
+    if (*p && *cap >= need && (double)*cap * sizeof(T) > 1.25 * (double)need * sizeof(T) + 268435456.0) {
+        (void)hipFree(*p), *p = nullptr, *cap = 0;
+    }
+    return ensure(ctx, p, cap, need);
+}
+
 // (Re)derive sizes, plan and code tables when the settings that define them change.
 static int acq_configure(bds_ctx *ctx, const bds_settings &s) {
     int rc = check_settings(ctx, s);
@@ -1094,7 +1106,7 @@ int AcqRun::setup() {
     // holds: 32 + 31 PRNs, 150 GiB, another 2.5 %) is the SERVING mode of a process that keeps the device to itself, 0 the minimal
     // footprint (one PRN's row per pair, 5 GB at cfg3).  With the default budget a big grid is batched only when at least six PRNs
     // fit a pair (fewer gain nothing: 4 PRNs 197.8 against 196.7 ms); an explicit budget batches from two.
-    // Small grids (D <= 104: cfg2's 63 x 26 cells are 4.3 GB) batch up to 8 GiB either way.  The PRNs are dealt evenly over the
+    // Small grids (D <= 104: cfg2's 63 x 26 cells are 4.3 GB) batch up to the budget too (8 GiB when the budget is 0).  The PRNs are dealt evenly over the
     // pairs; with room for less than two PRNs' cells a pair is one group of one PRN.
     // (BDS_ACQ_NOMULTI / BDS_ACQ_MULTI_ANY / BDS_ACQ_PBCELLS / BDS_ACQ_PBCAP_GB of the hooks build: off / on / cells per pair / budget.)
     const double pair_gb = tune.pbcap_gb > 0 ? tune.pbcap_gb : a.pair_gb_set ? a.pair_gb : tune.pair_gb;
@@ -1230,12 +1242,13 @@ int AcqRun::search() {
     int rc;
     const long sample_every = std::max<long>(1, n_pairs_total / kSamples);
     long pair_idx = 0, group_idx = 0;
+    if (!multiprn && (rc = ensure_fit(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a, ctx->tune) * (size_t)pl.L))) return rc;  // (gives a larger budget's buffer back)
     if (multiprn) {
         // float2-sized elements the PB*D cells of one launch pair occupy; if the device cannot give that much after all (another
         // process took it since setup() asked), halve the PRNs per pair
         for (;;) {
             const size_t need = ((size_t)PB * D * ncomp * elem + 7) / 8;
-            if (!(rc = ensure(ctx, &a.d_Bw, &a.bw_cap, std::max(need, bw_batches(a, ctx->tune)) * (size_t)pl.L))) break;
+            if (!(rc = ensure_fit(ctx, &a.d_Bw, &a.bw_cap, std::max(need, bw_batches(a, ctx->tune)) * (size_t)pl.L))) break;
             if (PB <= 2) return rc;
             (void)hipGetLastError();  // (the failed hipMalloc is handled here: it must not surface at the end of the search)
             PB = (PB + 1) / 2;
@@ -1432,7 +1445,7 @@ int acq_run_once(bds_ctx *ctx, const bds_settings *s_in, const int32_t *prn_list
 }  // namespace
 }  // namespace bds
 
-/* Serving mode of the search (see AcqRun::setup): budget of the inter-pass buffer in GiB; 0 = lean, < 0 = 60 % of the free device memory */
+/* Serving mode of the search (see AcqRun::setup): budget of the inter-pass buffer in GiB; 0 = the minimal footprint (one PRN per pair), < 0 = 60 % of the free device memory; unset: Tuning::pair_gb (40) */
 extern "C" int bds_acq_set_pair_budget_gb(bds_ctx *ctx, double gib) {
     if (!ctx) return BDS_ERR_ARG;
     if (!(gib == gib)) return fail(ctx, BDS_ERR_ARG, "bds_acq_set_pair_budget_gb: not a number");
@@ -1545,9 +1558,9 @@ extern "C" int bds_acq_candidates(bds_ctx *ctx, int prn, int32_t *bin, int64_t *
 }
 
 extern "C" int bds_acq_coherent_sums(bds_ctx *ctx, const bds_settings *s_in, int prn, int64_t phase, const double *freqs, int nf, int mode,
-                                     double *out) {
+                                     double *out, int cap) {
     using namespace bds;
-    if (!ctx || !ctx->acq || !s_in || !freqs || !out || nf < 1 || nf > 4096 || mode < 0 || mode > 2 || prn < 1 || prn > BDS_MAX_PRN)
+    if (!ctx || !ctx->acq || !s_in || !freqs || !out || nf < 1 || nf > 4096 || mode < 0 || mode > 2 || prn < 1 || prn > BDS_MAX_PRN || cap < 0)
         return BDS_ERR_ARG;
     AcqState &a = *ctx->acq;
     bds_settings eff;
@@ -1556,6 +1569,10 @@ extern "C" int bds_acq_coherent_sums(bds_ctx *ctx, const bds_settings *s_in, int
     (void)hipSetDevice(ctx->device);
     const bool b1c = a.signal == BDS_SIGNAL_B1C;
     const int nc = b1c ? a.ncomp : 2;
+    {  // (re, im) pairs the call writes: nothing is written when `out` cannot hold them (round 6: the entry had no capacity argument)
+        const long need = mode == 0 ? (long)nf * a.ncomp : (long)(b1c ? 1 : s->fineNoncoh) * nc * nf;
+        if (need > cap) return fail(ctx, BDS_ERR_ARG, "bds_acq_coherent_sums: out holds %d (re, im) pairs, the call writes %ld", cap, need);
+    }
     std::vector<CorrJob> jobs;
     std::vector<double2> jout;
     int rc;

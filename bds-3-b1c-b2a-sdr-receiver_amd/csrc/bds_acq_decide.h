@@ -438,6 +438,12 @@ bool AcqRun::device_refine_ok() const {
         const size_t cap_cells = a.bw_cap / (size_t)pl.L * 8 / elem / (size_t)ncomp;
         if ((size_t)P > cap_cells) return false;
     }
+    {  // the fine-frequency pick keeps its sums in LDS: thousands of fine frequencies (acqStep / 25 large) go to the host path BEFORE
+       // anything of the device chain is enqueued (round 6, ADVICE r5: the test stood behind the whole job chain, which then ran twice)
+        const bool b1c = a.signal == BDS_SIGNAL_B1C;
+        const size_t nfine = b1c ? (size_t)m_round(s->acqStep / 25) * 2 + 1 : (size_t)m_round(s->acqStep / 25) + 1;  // B1C :267, B2a :265
+        if (sizeof(double) * ((size_t)(b1c ? ncomp : 2 * s->fineNoncoh) * nfine + nfine) > 60000) return false;
+    }
     return true;
 }
 
@@ -561,7 +567,7 @@ int AcqRun::refine_device() {
     launch_corr<kCorrFreqs>(sm, dim3((unsigned)std::min(fine_units, 1024), kCorrSlices), a.sview(), fine_nc, a.N, (const int8_t *)a.d_codes,
                             a.code_stride, 1.0 / a.fs, (const CorrJob *)a.d_jobs, a.d_jobout, (const int *)&a.d_ref_g->nfine_units, fine_units);
     const size_t pick_lds = sizeof(double) * ((size_t)(b1c ? ncomp : 2 * s->fineNoncoh) * rp.nfine + rp.nfine);
-    if (pick_lds > 60000) return kHostRefine;  // (thousands of fine frequencies: the host path has no such limit)
+    if (pick_lds > 60000) return kHostRefine;  // (cannot happen: device_refine_ok() sends such settings to the host path up front)
     hipLaunchKernelGGL(k_ref_fine_pick, dim3(P), dim3(256), pick_lds, sm, rp, a.d_ref_prn, (const double2 *)a.d_jobout, kCorrSlices);
     BDS_HIP(ctx, hipGetLastError());
 

@@ -10,7 +10,7 @@
 #endif
 
 namespace bds {
-// ---- the strict carrier (PREC 4; PREC 5, the default, needs it once per lane and pass): sin / cos of the reference's own trigarg(k), without the library calls of PREC 3.
+// ---- the strict carrier (PREC 4, the default: per sample; PREC 5 needs it once per lane and pass): sin / cos of the reference's own trigarg(k), without the library calls of PREC 3.
 // k / fs correctly rounded from the correctly rounded reciprocal (Markstein: q0 = RN(k y), r = k - q0 fs exactly by FMA,
 // q = RN(q0 + r y) = RN(k / fs) when y = RN(1 / fs) and q0 is within an ulp; checked exhaustively on the host for the
 // sample counts and rates of the tests, tests/test_abi_and_host.py, and by BDS_DASSERT in the debug build)

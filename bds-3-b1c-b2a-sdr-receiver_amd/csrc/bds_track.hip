@@ -103,6 +103,44 @@ __device__ __forceinline__ char2 tab2_at(const int8_t *__restrict__ tab, int n_u
     return reinterpret_cast<const char2 *>(tab)[j];
 }
 
+// The reference's replica index vectors are MATLAB colon vectors,
+//     tcode = (rem -+ spc)[*2] : step[*2] : ((blksize-1)*step + rem -+ spc)[*2]     (tracking.m:260-286, NB_tracking.m:271-297,
+//                                                                                      WB_tracking.m:289-317),
+// and MATLAB does not build a:d:b as a + k d throughout (MathWorks' published colonop.m, Technical Solution 1-4FLI96): with
+// n = round((b-a)/d) intervals (one less if a + n d overshoots b by more than tol = 2 eps max(|a|,|b|)) and the right end
+// c = a + n d snapped to b within tol, elements 0 .. floor(n/2) are a + k d, the elements after them c - (n-k) d -- generated from
+// the RIGHT end --, and the mid-point of an even n is (a+c)/2.  The second half differs from a + k d by 0-2 ulp of tcode, which
+// moves ceil() for a sample that sits on a chip boundary to rounding (round 6; oracle/matlab.py m_colon is the checker's copy).
+struct ColonVec {
+    double a, d, c;
+    int n, h;
+    bool even;
+};
+__device__ __forceinline__ ColonVec colon_vec(double a, double d, double b) {
+    ColonVec v;
+    const double tol = 2.0 * 2.220446049250313e-16 * fmax(fabs(a), fabs(b));
+    long n = (long)floor((b - a) / d + 0.5);  // MATLAB round() of a non-negative quotient (the tcode vectors ascend)
+    if (a + (double)n * d - b > tol) n -= 1;
+    double c = a + (double)n * d;
+    if (c - b > -tol) c = b;
+    v.a = a, v.d = d, v.c = c, v.n = (int)n, v.h = (int)(n / 2), v.even = (n & 1) == 0;
+    return v;
+}
+__device__ __forceinline__ double colon_at(const ColonVec &v, int k) {
+    const double fwd = v.a + (double)k * v.d, bwd = v.c - (double)(v.n - k) * v.d;
+    return k > v.h ? bwd : (v.even && k == v.h) ? (v.a + v.c) / 2 : fwd;
+}
+// the three replica vectors of an epoch: E, P, L
+template <int SCALE2>
+__device__ __forceinline__ void epoch_colons(double rem, double step, double spacing, long blk, ColonVec cv[3]) {
+    const double sc = SCALE2 ? 2.0 : 1.0;
+    const double last = (double)(blk - 1) * step + rem;  // (blksize-1)*codePhaseStep + remCodePhase, then -+ earlyLateSpc, then *2
+    cv[0] = colon_vec((rem - spacing) * sc, step * sc, (last - spacing) * sc);
+    cv[1] = colon_vec(rem * sc, step * sc, last * sc);
+    cv[2] = colon_vec((rem + spacing) * sc, step * sc, (last + spacing) * sc);
+    BDS_DASSERT(cv[0].n == blk - 1 && cv[1].n == blk - 1 && cv[2].n == blk - 1);  // MATLAB would stop at tcode(blksize) otherwise
+}
+
 struct EpochGeom {
     long long pos;
     long blk;
@@ -125,13 +163,10 @@ template <int MODE>
 __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data, const int8_t *__restrict__ prim_d,
                                                 const int8_t *__restrict__ prim_p, const TrkParams &p,
                                                 const EpochGeom &g, long k0_first, long k_stride, bool pilot, double *sums) {
-    constexpr double scale = MODE == BDS_TRACK_B2A ? 1.0 : 2.0;
     constexpr int UNITS = MODE == BDS_TRACK_B2A ? 1 : 2;
     const int NU = UNITS * p.code_len;
-    const double inc = g.step * scale;
-    const double st_e = (g.rem - p.spacing) * scale;  // tracking.m:260-262 / WB_tracking.m:289-291
-    const double st_l = (g.rem + p.spacing) * scale;
-    const double st_p = g.rem * scale;
+    ColonVec cv[3];  // tracking.m:260-286 / WB_tracking.m:289-317
+    epoch_colons<(MODE != BDS_TRACK_B2A)>(g.rem, g.step, p.spacing, g.blk, cv);
     const double two_pi = 6.283185307179586476925286766559;
     const double cyc0 = g.remCarr / two_pi;
     float acc[kNSums];
@@ -159,7 +194,7 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
             raw = (float)dwin[g.pos + k];
         }
         const double kd = (double)k;
-        const double te = st_e + kd * inc, tl = st_l + kd * inc, tp = st_p + kd * inc;
+        const double te = colon_at(cv[0], k), tp = colon_at(cv[1], k), tl = colon_at(cv[2], k);
         const int ie = (int)ceil(te) + 1, il = (int)ceil(tl) + 1, ip = (int)ceil(tp) + 1;
         // carrier: trigarg = (carrFreq*2*pi)*(k/fs) + remCarrPhase  (tracking.m:303-304).  A thread's
         // samples are blockDim apart, so its carrier is an f64 phasor rotated by a constant angle; it is
@@ -235,8 +270,9 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
 // The replica codes are piecewise constant: at 99.375 MS/s a BOC(1,1) half-chip lasts 48.6 samples,
 // a BOC(6,1) twelfth 8.1, a B2a chip 9.7.  With S(k) = the running sum of the carrier-wiped samples,
 //     sum_k x[k] c[idx(k)]  =  c[idx(last)] S(end)  -  sum over index steps u (c[u] - c[u-1]) S(k_u),
-// k_u = the first sample whose index reaches u.  The per-sample index of the reference,
-// ceil(fl(st + fl(k inc))) (x 6 for BOC(6,1), WB_tracking.m:298), is monotone in k, so k_u is found
+// k_u = the first sample whose index reaches u.  The per-sample index of the reference, ceil() of element k of its colon
+// vector (ColonVec above; x 6 for BOC(6,1), WB_tracking.m:298), is monotone in k -- neighbouring elements are one step apart to
+// a few ulp in both halves and across the junction --, so k_u is found
 // from a division and confirmed with the reference's own expression on k_u - 1 and k_u: every sample gets
 // exactly the index the per-sample evaluation gives it, at two exact evaluations per code unit instead
 // of one per sample and replica.
@@ -256,23 +292,21 @@ __device__ __forceinline__ void correlate_slice(const int8_t *__restrict__ data,
 #endif
 static constexpr int kCap1 = BDS_TRK_CAP1, kCap6 = BDS_TRK_CAP6;  // code / BOC(6,1) table entries of a wave's pass staged in LDS
 template <int R6>
-__device__ __forceinline__ double code_arg(double st, double inc, int k) {
-    double v = st + (double)k * inc;  // two roundings (-ffp-contract=off), as the reference's colon vector
-    if (R6) v = v * 6;
-    return v;
+__device__ __forceinline__ double code_arg(const ColonVec &v, int k) {
+    double t = colon_at(v, k);  // element k of the reference's colon vector (-ffp-contract=off: one rounding per operation)
+    if (R6) t = t * 6;
+    return t;
 }
-template <int R6>
-__device__ __forceinline__ int code_idx(double st, double inc, int k) { return (int)ceil(code_arg<R6>(st, inc, k)); }
 
 // first k in (k_lo, k_hi] with ceil(arg(k)) >= u, given ceil(arg(k_lo)) < u <= ceil(arg(k_hi))
 template <int R6>
-__device__ __forceinline__ int first_sample_of(double st, double inc, double inv_inc, int u, int k_lo, int k_hi) {
-    const double thr = (double)(u - 1);  // ceil(v) >= u  <=>  v > u - 1
+__device__ __forceinline__ int first_sample_of(const ColonVec &v, double inv_inc, int u, int k_lo, int k_hi) {
+    const double thr = (double)(u - 1);  // ceil(t) >= u  <=>  t > u - 1
     const double tgt = R6 ? thr * (1.0 / 6.0) : thr;  // a prediction only: confirmed below with the exact expression
-    int kc = (int)floor((tgt - st) * inv_inc) + 1;
+    int kc = (int)floor((tgt - v.a) * inv_inc) + 1;
     kc = max(k_lo + 1, min(kc, k_hi));
-    while (kc > k_lo + 1 && code_arg<R6>(st, inc, kc - 1) > thr) --kc;
-    while (kc < k_hi && !(code_arg<R6>(st, inc, kc) > thr)) ++kc;
+    while (kc > k_lo + 1 && code_arg<R6>(v, kc - 1) > thr) --kc;
+    while (kc < k_hi && !(code_arg<R6>(v, kc) > thr)) ++kc;
     return kc;
 }
 
@@ -340,7 +374,8 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
     int8_t *s_t6 = reinterpret_cast<int8_t *>(s_t1 + kCap1);                                    // [kCap6]
     const int NU = UNITS * p.code_len, n6 = 12 * p.code_len;
     const double inc = g.step * scale, inv_inc = 1.0 / inc;
-    const double st3[3] = {(g.rem - p.spacing) * scale, g.rem * scale, (g.rem + p.spacing) * scale};  // E, P, L
+    ColonVec cv3[3];  // E, P, L
+    epoch_colons<(MODE != BDS_TRACK_B2A)>(g.rem, g.step, p.spacing, g.blk, cv3);
     const double two_pi = 6.283185307179586476925286766559;
     const double cyc0 = g.remCarr / two_pi;
     constexpr int coeff = CPLX ? 2 : 1;
@@ -392,8 +427,8 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
         int ua1[3], ub1[3], ua6[3], ub6[3];
         {  // the twelve range ends are wave-uniform: lane 3 e + ph (+ 6 for BOC(6,1)) evaluates one, readlane spreads them
             const int ph = lane % 3, end = (lane / 3) & 1, r6 = (lane / 6) & 1;
-            const double stl = ph == 0 ? st3[0] : ph == 1 ? st3[1] : st3[2];
-            double v = stl + (double)(end ? k1 - 1 : k0) * inc;  // two roundings, as code_arg
+            const ColonVec &cl = ph == 0 ? cv3[0] : ph == 1 ? cv3[1] : cv3[2];
+            double v = colon_at(cl, end ? k1 - 1 : k0);  // as code_arg
             if (r6) v = v * 6;
             const int idx = (int)ceil(v);
 #pragma unroll
@@ -524,12 +559,12 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
             for (int r = lane; r < n0 + n1 + n2; r += 64) {
                 const int ph = r < n0 ? 0 : r < n0 + n1 ? 1 : 2;
                 const int u = (ph == 0 ? ua1[0] + r : ph == 1 ? ua1[1] + (r - n0) : ua1[2] + (r - n0 - n1)) + 1;
-                const double st = ph == 0 ? st3[0] : ph == 1 ? st3[1] : st3[2];
+                const ColonVec &cl = ph == 0 ? cv3[0] : ph == 1 ? cv3[1] : cv3[2];
                 const double thr = (double)(u - 1);
-                int kk = (int)floor((thr - st) * inv_inc) + 1;  // a prediction, confirmed with the exact expression
+                int kk = (int)floor((thr - cl.a) * inv_inc) + 1;  // a prediction, confirmed with the exact expression
                 kk = max(k0 + 1, min(kk, k1 - 1));
-                if (!(!(code_arg<0>(st, inc, kk - 1) > thr) && code_arg<0>(st, inc, kk) > thr))
-                    kk = first_sample_of<0>(st, inc, inv_inc, u, k0, k1 - 1);
+                if (!(!(code_arg<0>(cl, kk - 1) > thr) && code_arg<0>(cl, kk) > thr))
+                    kk = first_sample_of<0>(cl, inv_inc, u, k0, k1 - 1);
                 const double2 S = prefix(kk);
                 const char2 cn = at1(u + 1), co = at1(u);
                 const double dd = (double)((int)cn.x - (int)co.x), dp = (double)((int)cn.y - (int)co.y);
@@ -573,16 +608,16 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
                     uu[ph] = ua1[ph] + 1 + r;
                     val[ph] = uu[ph] <= ub1[ph];
                     const double thr = (double)(uu[ph] - 1);
-                    int kc = (int)floor((thr - st3[ph]) * inv_inc) + 1;  // a prediction, confirmed with the exact expression
+                    int kc = (int)floor((thr - cv3[ph].a) * inv_inc) + 1;  // a prediction, confirmed with the exact expression
                     kc = max(k0 + 1, min(kc, k1 - 1));
-                    const bool good = !(code_arg<0>(st3[ph], inc, kc - 1) > thr) && code_arg<0>(st3[ph], inc, kc) > thr;
+                    const bool good = !(code_arg<0>(cv3[ph], kc - 1) > thr) && code_arg<0>(cv3[ph], kc) > thr;
                     bad |= val[ph] && !good;
                     kk[ph] = val[ph] ? kc : k0 + 1;
                 }
                 if (bad) {
 #pragma unroll
                     for (int ph = 0; ph < 3; ++ph)
-                        if (val[ph]) kk[ph] = first_sample_of<0>(st3[ph], inc, inv_inc, uu[ph], k0, k1 - 1);
+                        if (val[ph]) kk[ph] = first_sample_of<0>(cv3[ph], inv_inc, uu[ph], k0, k1 - 1);
                 }
 #pragma unroll
                 for (int ph = 0; ph < 3; ++ph) {
@@ -627,16 +662,16 @@ __device__ __forceinline__ void correlate_runs(const int8_t *__restrict__ data, 
                     uu[ph] = ua6[ph] + 1 + r;
                     val[ph] = uu[ph] <= ub6[ph];
                     const double thr = (double)(uu[ph] - 1);
-                    int kc = (int)floor((thr * (1.0 / 6.0) - st3[ph]) * inv_inc) + 1;
+                    int kc = (int)floor((thr * (1.0 / 6.0) - cv3[ph].a) * inv_inc) + 1;
                     kc = max(k0 + 1, min(kc, k1 - 1));
-                    const bool good = !(code_arg<1>(st3[ph], inc, kc - 1) > thr) && code_arg<1>(st3[ph], inc, kc) > thr;
+                    const bool good = !(code_arg<1>(cv3[ph], kc - 1) > thr) && code_arg<1>(cv3[ph], kc) > thr;
                     bad |= val[ph] && !good;
                     kk[ph] = val[ph] ? kc : k0 + 1;
                 }
                 if (bad) {
 #pragma unroll
                     for (int ph = 0; ph < 3; ++ph)
-                        if (val[ph]) kk[ph] = first_sample_of<1>(st3[ph], inc, inv_inc, uu[ph], k0, k1 - 1);
+                        if (val[ph]) kk[ph] = first_sample_of<1>(cv3[ph], inv_inc, uu[ph], k0, k1 - 1);
                 }
 #pragma unroll
                 for (int ph = 0; ph < 3; ++ph) {

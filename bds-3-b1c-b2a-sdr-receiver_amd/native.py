@@ -144,7 +144,7 @@ def lib():
     L.bds_acq_candidates.restype, L.bds_acq_candidates.argtypes = i32, [vp, i32, _IP, C.POINTER(C.c_int64), i32]
     L.bds_acq_peaks.restype, L.bds_acq_peaks.argtypes = i32, [vp, i32, _DP, _DP, _IP]
     L.bds_acq_coherent_sums.restype = i32
-    L.bds_acq_coherent_sums.argtypes = [vp, SP, i32, C.c_int64, _DP, i32, i32, _DP]
+    L.bds_acq_coherent_sums.argtypes = [vp, SP, i32, C.c_int64, _DP, i32, i32, _DP, i32]
     L.bds_get_timing.restype, L.bds_get_timing.argtypes = i32, [vp, C.POINTER(Timing)]
     L.bds_track.restype = i32
     L.bds_track.argtypes = [vp, SP, C.c_char_p, i32, C.POINTER(Channel), C.POINTER(TrackOut)]
@@ -395,7 +395,7 @@ class Context:
 
     def acq_set_pair_budget(self, gib):
         """bds_acq_set_pair_budget_gb: serving mode of the search -- several PRNs' Doppler rows per launch pair, inter-pass buffer of
-        `gib` GiB ("auto" / negative: 60 % of the free device memory; 0: lean, the default).  Takes effect at the next acq_run."""
+        `gib` GiB ("auto" / negative: 60 % of the free device memory; 0: the minimal footprint, one PRN per pair; the library default is 40).  Takes effect at the next acq_run, in both directions (a larger buffer is given back)."""
         g = -1.0 if (isinstance(gib, str) and gib.lower().startswith("a")) else float(gib)
         self._lib.bds_acq_set_pair_budget_gb.argtypes = [C.c_void_p, C.c_double]
         self._check(self._lib.bds_acq_set_pair_budget_gb(self._h, g))
@@ -488,9 +488,10 @@ class Context:
         modes 1 / 2 [segments * components, nf]."""
         cs = pack_settings(settings)
         fr = np.ascontiguousarray(freqs, dtype=np.float64)
-        out = np.zeros(2 * 64 * 2 * max(len(fr), 1) + 16)
+        cap = max(int(getattr(settings, "fineNoncoh", 1) or 1), 1) * 2 * max(len(fr), 1)  # segments x components x frequencies
+        out = np.zeros(2 * cap)
         n = self._check(self._lib.bds_acq_coherent_sums(self._h, C.byref(cs), int(prn), int(phase), fr.ctypes.data_as(_DP), len(fr),
-                                                        int(mode), out.ctypes.data_as(_DP)))
+                                                        int(mode), out.ctypes.data_as(_DP), cap))
         z = out[:2 * n:2] + 1j * out[1:2 * n:2]
         return z.reshape(len(fr), -1) if mode == 0 else z.reshape(-1, len(fr))  # modes 1 / 2: rows = (segment, component)
 

@@ -603,7 +603,7 @@ def main():
     ap.add_argument("--cold-child", default=None, choices=["b1c", "b2a"], help=argparse.SUPPRESS)  # internal: the cold leg in a fresh process
     ap.add_argument("--cold-budget", default="0", help=argparse.SUPPRESS)
     ap.add_argument("--cold-device", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--mode", default="serving", choices=["serving", "default", "minimal"],
+    ap.add_argument("--mode", default="default", choices=["serving", "default", "minimal"],
                     help="inter-pass buffer budget of the search the headline runs with (include/bds_mi355x.h, bds_acq_set_pair_budget_gb): "
                          "serving = 'auto', as many PRNs' Doppler rows per launch pair as 60 %% of the free HBM hold (allocated before the timed "
                          "region); default = the library's own default (40 GiB: 8 PRNs per pair at cfg3); minimal = 0 (one PRN per pair, 5 GB). "
@@ -663,11 +663,10 @@ def main():
         g["shard"] = shards[k]
         # one context per signal: each keeps its IF block and code spectra resident in HBM across steps
         g["ctx"] = bds_amd.get_context(local_rank) if k == 0 else bds_amd.native.Context(local_rank)
-        # The headline is a THROUGHPUT figure of a context that is called again and again with its inputs resident: the library's
-        # serving mode (include/bds_mi355x.h, bds_acq_set_pair_budget_gb / BDS_ACQ_PAIR_GB=auto) -- as many PRNs' Doppler rows per launch
-        # pair as 60 % of the free HBM hold.  A first call costs the same in every mode (`cold`, measured in fresh processes); the price
-        # is the footprint and the driver's clearing of it when the context goes.  The library default (40 GiB) and the minimal
-        # footprint (one PRN per pair) are timed beside it (`default`, `minimal`).
+        # The headline is what a plain bds_acquire caller gets: the LIBRARY DEFAULT (round 6; rounds 1-5 put the opt-in serving mode
+        # here).  The serving mode (include/bds_mi355x.h, bds_acq_set_pair_budget_gb / BDS_ACQ_PAIR_GB=auto -- as many PRNs' Doppler rows
+        # per launch pair as 60 % of the free HBM hold) and the minimal footprint (one PRN per pair) are timed beside it (keys `serving`,
+        # `minimal`); a first call in a fresh process is the `cold` key.
         if args.mode != "default":
             g["ctx"].acq_set_pair_budget({"serving": "auto", "minimal": 0}[args.mode])
         if g["shard"]:

@@ -222,11 +222,13 @@ BDS_API int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *prn_
  *    40        8 PRNs per pair,  40 GB     191.6 - 192.1          (the DEFAULT)
  *    80       16 PRNs per pair,  80 GB     189.3 - 189.8
  *   < 0       60 % of the device memory that is free: 32 + 31 PRNs, 150 GiB   186.8 - 187.1   (the SERVING mode of a process
- *             that keeps the device to itself; what bench.py times as its headline)
+ *             that keeps the device to itself; bench.py times it beside its headline, which is the default: key `serving`)
  * The price is the footprint, and time when it changes hands: a fresh allocation is free (a first call costs the same in every
  * mode), but the driver clears freed device memory at ~33 GB/s and whoever allocates next waits -- up to ~4.8 s after a 150-GiB
  * context is destroyed.  Results are the same bits in every mode.  Same switch as the environment knob BDS_ACQ_PAIR_GB (number
- * of GiB, or "auto"); takes effect at the next bds_acq_run. */
+ * of GiB, or "auto"); takes effect at the next bds_acq_run -- in both directions: a context whose buffer is more than a quarter
+ * (+256 MiB) larger than the new budget needs frees it and allocates the smaller one at that run (round 6; until then only
+ * bds_destroy returned the memory). */
 BDS_API int bds_acq_set_pair_budget_gb(bds_ctx *ctx, double gib);
 
 /* Diagnostics of the last bds_acq_run: per searched PRN (in search order) and Doppler
@@ -249,7 +251,7 @@ BDS_API int bds_acq_peaks(bds_ctx *ctx, int max_prn, double *peak, double *denom
  *           out[((seg*ncomp + c)*nf + f)*2]
  *   mode 2  the same sums, one frequency per pass (what mode 1 must agree with to rounding) */
 BDS_API int bds_acq_coherent_sums(bds_ctx *ctx, const bds_settings *s, int prn, int64_t phase, const double *freqs, int nf, int mode,
-                                  double *out);
+                                  double *out, int cap); /* cap: (re, im) pairs `out` holds; BDS_ERR_ARG, nothing written, if the call needs more */
 BDS_API int bds_get_timing(bds_ctx *ctx, bds_timing *t);
 
 /* ---- multi-device acquisition -------------------------------------------

@@ -21,7 +21,7 @@ import numpy as np
 from scipy import integrate
 
 from . import codes
-from .matlab import m_round, m_var
+from .matlab import m_colon, m_round, m_var
 
 
 class RawFile:
@@ -293,8 +293,11 @@ def tracking(fid: RawFile, channel, settings, mode=None, trace=None, correlate=N
                 scale = 1.0 if b2a else 2.0
 
                 def taps(off):
-                    # (rem +- spc)[*2] : step[*2] : ...  -> start + k*inc   (:260-263, WB:289-292)
-                    t = (rem_code + off) * scale + kk * (step * scale)
+                    # (rem +- spc)[*2] : step[*2] : ((blksize-1)*step + rem +- spc)[*2]   (:260-263, NB:271-273, WB:289-292) --
+                    # a MATLAB colon vector: second half generated from the right-hand end point (oracle/matlab.py m_colon)
+                    t = m_colon((rem_code + off) * scale, step * scale, (((blk - 1) * step + rem_code) + off) * scale)
+                    if len(t) != blk:  # MATLAB itself would stop at "tcode(blksize)" / the element-wise products
+                        raise RuntimeError(f"colon vector has {len(t)} elements for blksize {blk}")
                     return t, np.ceil(t).astype(np.int64) + 1
 
                 t_e, i_e = taps(-spc_el)

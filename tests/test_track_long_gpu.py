@@ -95,8 +95,8 @@ def test_full_horizon_fast_correlator(ctx, name, monkeypatch):
     _check(z, got, n_epochs, mode, FAST_TIGHT[mode], floor=True)
 
 
-@pytest.mark.skipif(not os.environ.get("BDS_TEST_B2A_TRK_FULL"), reason="B2a tracking at the reference's own defaults (12 channels x 49 000 ms at 99.375 MS/s) "
-                    "against the oracle: a 4.9 GB record and ~5 min of host time (BDS_TEST_B2A_TRK_FULL=1; profiles/r05_b2a_trk_full_vs_c_oracle.txt)")
+@pytest.mark.skipif(bool(os.environ.get("BDS_TEST_SKIP_WHOLE_HORIZON")), reason="BDS_TEST_SKIP_WHOLE_HORIZON set (B2a tracking at the reference's own defaults, "
+                    "12 channels x 49 000 ms at 99.375 MS/s, against the oracle: a 4.9 GB record and 1-2 min of host time)")
 def test_b2a_tracking_at_the_references_defaults_whole_horizon(ctx):
     """B2a/initSettings.m as checked in: fs = 99.375 MS/s, msToProcess = 49 000, 12 channels -- every 1-ms epoch of every channel against
     the float64 oracle (sample loops in C, oracle/c/trk_oracle.c).  Same assertions as tests/test_cfg4_gpu.py's whole-horizon test:
