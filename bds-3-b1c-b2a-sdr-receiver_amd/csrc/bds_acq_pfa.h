@@ -1,0 +1,390 @@
+// N-point search pair for the B1C grid at N = 1 987 500 = 53 x 12 x 3125 (round 6; tools/proto_pfa53.py is the NumPy model).
+//
+// The reference correlates circularly over N = len10PlusXms samples (B1C/acquisition.m:135-136, 198-212).  The pair of
+// bds_acq_wrows.h / bds_acq_wcols.h transforms L = 3 145 728 = 1.583 N points per cell (zero-padded linear correlation); this
+// pair transforms N.  53, 12 and 3125 are pairwise coprime, so the N-point transform is a 3-D transform WITHOUT twiddles between
+// the dimensions (Good-Thomas): spectrum index k <-> (k1, k2, k3) = (k mod 53, k mod 12, k mod 3125), lag index
+// t = (t1 N/53 + t2 N/12 + t3 N/3125) mod N, and the Doppler bins -- acqStep N / fs = 1 at cfg3 -- are rotations of ONE signal
+// spectrum by the bin index in each dimension: fft(carr_b x)[k] = fft(carr_0 x)[k - b].
+//
+//   row pass     k_pfa_rows   workgroup = two rows (k1 = 2 mp, 2 mp + 1; one k2) x both components x a run of cells of one PRN:
+//                             spectrum product (v_dot2_f32_f16 on fp16-stored spectra, code rows held in registers across the
+//                             cells) + inverse 3125-point transform over k3 as 25 x 5 x 25 on 125 threads per row (packed fp32
+//                             butterflies, two LDS exchanges), fp16 result to the inter-pass buffer.  A row lives in one 32-lane
+//                             HALF of four waves, its partner row in the other half: the two rows' results meet through
+//                             v_permlane32_swap and leave as 16-byte pieces, 512 contiguous bytes per half-wave.
+//   column pass  k_pfa_cols   wave = 4 lags t3 x all (t1, t2) x both components: the 53-point transform over k1 on the MATRIX pipe --
+//                             the inter-pass buffer holds fp16 values, which v_mfma_f32_16x16x32_f16 multiplies exactly into fp32;
+//                             the DFT coefficients are split hi + lo in fp16 (error ~1e-7, tools/proto_pfa53.py) --, the 12-point
+//                             transform over k2 per lane on the accumulators (a lane holds all 12 k2 of one output: data is the
+//                             A operand, so the MFMA's rows are (t3, k2) and its columns the outputs), |y|^2, the sieve protocol
+//                             of bds_acq_wcols.h.
+//
+// Inter-pass buffer of a cell: [mp 27][k2 12][t3 3125][component 2][row of the pair 2] fp16 complex = 16 bytes per (mp, k2, t3);
+// a lane's A fragment (k1 = 4 mg .. 4 mg + 3 of one (k2, t3), one component) is the halves of two such pieces.
+#pragma once
+
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "bds_fft_pk.h"
+
+namespace bds {
+namespace pfa {
+
+constexpr int K1 = 53, K2 = 12, K3 = 3125;
+constexpr long NP = (long)K1 * K2 * K3;  // 1 987 500
+constexpr int MP = 27;                   // row pairs (54 rows: one zero row)
+constexpr int NB = 7;                    // output blocks of 16 (106 real outputs -> 112)
+constexpr size_t kCellElems = (size_t)MP * K2 * K3 * 4;  // 4-byte (fp16 complex) elements of a cell in the inter-pass buffer
+constexpr int kRowsThreads = 256, kColsThreads = 256;
+constexpr int kCoefFrags = NB * 4 * 2;  // B fragments (16 bytes per lane): [nb][ins][hi / lo]
+constexpr size_t kCoefBytes = (size_t)kCoefFrags * 64 * 16;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// lag of output (t1, t2, t3): the Ruritanian map
+__host__ __device__ inline long lag_of(int t1, int t2, int t3) {
+    return ((long)t1 * (NP / K1) + (long)t2 * (NP / K2) + (long)t3 * (NP / K3)) % NP;
+}
+
+// ---- 5- and 25-point inverse transforms on packed fp32 pairs -------------------------------------------------------------
+__device__ __forceinline__ void pk_radix5(v2f &x0, v2f &x1, v2f &x2, v2f &x3, v2f &x4) {
+    constexpr float c1 = 0.30901699437494745f, c2 = -0.80901699437494734f, s1 = 0.95105651629515353f, s2 = 0.58778525229247314f;
+    const v2f t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+    const v2f m1 = x0 + c1 * t1 + c2 * t2;
+    const v2f m2 = x0 + c2 * t1 + c1 * t2;
+    const v2f n1 = s1 * t3 + s2 * t4;
+    const v2f n2 = s2 * t3 - s1 * t4;
+    x0 = x0 + t1 + t2;
+    x1 = pk_addj(m1, n1);
+    x4 = pk_subj(m1, n1);
+    x2 = pk_addj(m2, n2);
+    x3 = pk_subj(m2, n2);
+}
+
+// W25^k, k = q0 p1 for q0, p1 in 1..4
+__device__ __forceinline__ v2f w25(int k) {
+    constexpr float c[17] = {1.f, 0.9685831611286311f, 0.8763066800438636f, 0.7289686274214116f, 0.5358267949789965f, 0.30901699437494745f,
+                             0.06279051952931353f, -0.1873813145857246f, -0.4257792915650727f, -0.6374239897486897f, -0.8090169943749473f,
+                             -0.9297764858882513f, -0.9921147013144778f, -0.9921147013144779f, -0.9297764858882515f, -0.8090169943749478f,
+                             -0.6374239897486895f};
+    constexpr float s[17] = {0.f, 0.2486898871648548f, 0.4817536741017153f, 0.6845471059286886f, 0.8443279255020151f, 0.9510565162951535f,
+                             0.9980267284282716f, 0.9822872507286887f, 0.9048270524660195f, 0.7705132427757893f, 0.5877852522924732f,
+                             0.36812455268467814f, 0.12533323356430454f, -0.12533323356430429f, -0.3681245526846779f, -0.5877852522924727f,
+                             -0.7705132427757894f};
+    return (v2f){c[k], s[k]};
+}
+
+// x[q0 + 5 q1] -> slot p0 + 5 p1 holds Y[5 p0 + p1] = sum_q x[q] W25^(q (5 p0 + p1))
+__device__ __forceinline__ void pk_radix25(v2f (&x)[25]) {
+#pragma unroll
+    for (int q0 = 0; q0 < 5; ++q0) pk_radix5(x[q0], x[q0 + 5], x[q0 + 10], x[q0 + 15], x[q0 + 20]);
+#pragma unroll
+    for (int q0 = 1; q0 < 5; ++q0)
+#pragma unroll
+        for (int p1 = 1; p1 < 5; ++p1) x[q0 + 5 * p1] = pk_cmul_k(x[q0 + 5 * p1], w25(q0 * p1));
+#pragma unroll
+    for (int p1 = 0; p1 < 5; ++p1) pk_radix5(x[5 * p1], x[5 * p1 + 1], x[5 * p1 + 2], x[5 * p1 + 3], x[5 * p1 + 4]);
+}
+__host__ __device__ constexpr int slot25_index(int s) { return 5 * (s % 5) + s / 5; }  // output index held by slot s
+
+__device__ __forceinline__ v2f unit(int num, int den) {  // exp(+2 pi j num / den), num reduced by the caller
+    float sn, cs;
+    sincospif(2.0f * (float)num / (float)den, &sn, &cs);
+    return (v2f){cs, sn};
+}
+
+// ---- row pass ----------------------------------------------------------------------------------------------------------------
+struct RowsArgs {
+    const uint32_t *Xs;  // signal spectrum of bin 0, CRT layout, every row doubled: [53][12][6250] fp16 complex (re lo, im hi)
+    const uint32_t *Cs;  // conjugated, scaled code spectra: [prn slot][component][53][12][3125]
+    uint32_t *Bw;        // inter-pass buffer [cell][27][12][3125][2][2]
+    const int *bin;      // per cell: Doppler bin (= rotation)
+    const long *cs;      // per cell: element offset of the PRN's spectra in Cs
+    int ncells;          // cells of the launch
+    int gc;              // cells a workgroup walks (all of one PRN)
+    int ncomp;           // 2 (data + pilot) or 1
+};
+
+template <int NC>
+__global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
+    extern __shared__ __align__(16) unsigned char pfa_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5;
+    const int j = wave * 32 + (lane & 31);  // thread of the row: 0..127, 125 of them work
+    const bool live = j < 125;
+    const int jj = live ? j : 124;
+    const int rp = blockIdx.x % (MP * K2), chunk = blockIdx.x / (MP * K2);
+    const int mp = rp / K2, k2 = rp % K2;
+    const int k1 = 2 * mp + half;
+    const bool row_ok = k1 < K1;
+    const int k1c = row_ok ? k1 : K1 - 1;
+    float2 *region = reinterpret_cast<float2 *>(pfa_lds) + (size_t)half * 3136;  // 3125 elements per row (+ pad)
+    const int c0 = chunk * A.gc, c1 = min(A.ncells, c0 + A.gc);
+    if (c0 >= c1) return;
+
+    // code rows of this workgroup's PRN (zero for the pad row: its outputs are zeros)
+    uint32_t cv[NC][25];
+    {
+        const uint32_t *crow = A.Cs + A.cs[c0] + ((size_t)k1c * K2 + k2) * K3;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 25; ++q) cv[c][q] = row_ok ? crow[(size_t)c * K1 * K2 * K3 + jj + 125 * q] : 0u;
+    }
+    // stage twiddles: W3125^(j p) after stage 1, W125^(i u) after stage 2 (thread t = i + 25 pg)
+    // (W3125^(j p), p = 5 p0 + p1, as the product of two factors from 4 + 4 registers: all 24 of them held per thread -- 48 registers --
+    //  spill 43 dwords at two waves per SIMD; the 16 extra complex products are 5 % of the row pass's vector instructions)
+    v2f tw1a[5], tw1b[5], tw2[5];
+#pragma unroll
+    for (int p = 1; p < 5; ++p) tw1a[p] = unit((jj * p) % K3, K3), tw1b[p] = unit((jj * 5 * p) % K3, K3);
+    const int si = jj % 25, spg = jj / 25;
+#pragma unroll
+    for (int u = 1; u < 5; ++u) tw2[u] = unit((si * u) % 125, 125);
+
+    for (int cell = c0; cell < c1; ++cell) {
+        const int s = A.bin[cell];
+        const int k1s = ((k1c - s) % K1 + K1) % K1, k2s = ((k2 - s) % K2 + K2) % K2, o3 = (K3 - s % K3) % K3;
+        const uint32_t *xrow = A.Xs + ((size_t)k1s * K2 + k2s) * (2 * K3) + o3 + jj;
+        uint32_t xn[25];
+#pragma unroll
+        for (int q = 0; q < 25; ++q) xn[q] = xrow[125 * q];
+        uint32_t outp[NC][25];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            v2f x[25];
+#pragma unroll
+            for (int q = 0; q < 25; ++q) {  // X conj(C): (xr, -xi).(cr', ci') and (xi, xr).(cr', ci') with C' = conj(C) stored
+                const uint32_t xs = __builtin_amdgcn_alignbit(xn[q], xn[q], 16), xc = xn[q] ^ 0x80000000u;
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 hc = __builtin_bit_cast(h2, cv[c][q]);
+                x[q] = (v2f){__builtin_amdgcn_fdot2(__builtin_bit_cast(h2, xc), hc, 0.f, false),
+                             __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, xs), hc, 0.f, false)};
+            }
+            // stage 1: 25 points over q (k3 = j + 125 q) -> p, twiddle W3125^(j p), a[j][p] at 25 j + p
+            pk_radix25(x);
+            if (c > 0) __syncthreads();  // the previous component's stage-3 reads of the region are done
+            if (live) {
+#pragma unroll
+                for (int sl = 0; sl < 25; ++sl) {
+                    const int p = slot25_index(sl);  // slot p0 + 5 p1 holds output 5 p0 + p1
+                    v2f v = x[sl];
+                    if (sl / 5) v = pk_cmul(v, tw1a[sl / 5]);
+                    if (sl % 5) v = pk_cmul(v, tw1b[sl % 5]);
+                    region[25 * j + p] = to_f2(v);
+                }
+            }
+            __syncthreads();
+            // stage 2: thread (i, pg): for c5 = 0..4: 5 points over r of a[i + 25 r][5 pg + c5] -> u, twiddle W125^(i u), in place
+            if (live) {
+#pragma unroll
+                for (int c5 = 0; c5 < 5; ++c5) {
+                    v2f z[5];
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) z[r] = to_v2f(region[25 * (si + 25 * r) + 5 * spg + c5]);
+                    pk_radix5(z[0], z[1], z[2], z[3], z[4]);
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        const v2f v = u ? pk_cmul(z[u], tw2[u]) : z[u];
+                        region[25 * (si + 25 * u) + 5 * spg + c5] = to_f2(v);
+                    }
+                }
+            }
+            __syncthreads();
+            // stage 3: thread t' = p + 25 u: 25 points over i of b[p][i][u] at 25 (i + 25 u) + p -> t'': X[t' + 125 t'']
+            {
+                const int p3 = jj % 25, u3 = jj / 25;
+#pragma unroll
+                for (int i = 0; i < 25; ++i) x[i] = to_v2f(region[25 * (i + 25 * u3) + p3]);
+            }
+            pk_radix25(x);
+#pragma unroll
+            for (int sl = 0; sl < 25; ++sl) {
+                const int tq = slot25_index(sl);
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                outp[c][tq] = __builtin_bit_cast(uint32_t, __builtin_convertvector(x[sl], h2));  // v_cvt_pk_f16_f32: round to nearest even
+            }
+        }
+        // the two rows of the pair meet: after the swap half 0 holds (row 0, row 1) of t'' = e, half 1 of t'' = e + 1
+        uint32_t *dst = A.Bw + (size_t)cell * kCellElems + ((size_t)mp * K2 + k2) * K3 * 4;
+#pragma unroll
+        for (int e = 0; e < 25; e += 2) {
+            uint32_t P[2], Q[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t pe = c < NC ? outp[c < NC ? c : 0][e] : 0u, qo = (c < NC && e + 1 < 25) ? outp[c < NC ? c : 0][e + 1 < 25 ? e + 1 : e] : 0u;
+                // v_permlane32_swap: lanes 32-63 of the first <-> lanes 0-31 of the second
+                const auto r = __builtin_amdgcn_permlane32_swap(pe, qo, false, false);
+                P[c] = r[0], Q[c] = r[1];
+            }
+            const int tq = e + half;
+            if (live && tq < 25) {
+                const int t3 = j + 125 * tq;
+                *reinterpret_cast<uint4 *>(dst + (size_t)t3 * 4) = make_uint4(P[0], Q[0], P[1], Q[1]);
+            }
+        }
+        __syncthreads();  // region free for the next cell
+    }
+}
+
+// ---- column pass -------------------------------------------------------------------------------------------------------------
+// B operand of the 53-point stage in fragment order: frag[(nb * 4 + ins) * 2 + part][lane] = 8 halves
+//   coef[kappa = 32 ins + 8 (lane >> 4) + e][o = 16 nb + (lane & 15)],  kappa = 2 k1 + ri_in, o = 2 t1 + ri_out,
+//   y_re = sum c x_re - s x_im, y_im = sum s x_re + c x_im, c + j s = exp(+2 pi j k1 t1 / 53); part 0 = fp16(coef), part 1 = fp16(coef - hi)
+inline void make_coef_frags(uint16_t *out /* kCoefBytes / 2 halves */) {
+    auto f2h = [](float f) { return __half_as_ushort(__float2half_rn(f)); };
+    auto h2f = [](uint16_t h) { return __half2float(__ushort_as_half(h)); };
+    for (int nb = 0; nb < NB; ++nb)
+        for (int ins = 0; ins < 4; ++ins)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int kap = 32 * ins + 8 * (lane >> 4) + e, o = 16 * nb + (lane & 15);
+                    const int k1 = kap >> 1, ri = kap & 1, t1 = o >> 1, ro = o & 1;
+                    double v = 0.0;
+                    if (k1 < K1 && t1 < K1) {
+                        const double ang = 2.0 * M_PI * (double)((k1 * t1) % K1) / K1;
+                        const double c = cos(ang), s = sin(ang);
+                        v = ro == 0 ? (ri == 0 ? c : -s) : (ri == 0 ? s : c);
+                    }
+                    const uint16_t hi = f2h((float)v);
+                    const uint16_t lo = f2h((float)(v - (double)h2f(hi)));
+                    out[((((size_t)nb * 4 + ins) * 2 + 0) * 64 + lane) * 8 + e] = hi;
+                    out[((((size_t)nb * 4 + ins) * 2 + 1) * 64 + lane) * 8 + e] = lo;
+                }
+}
+
+struct ColsArgs {
+    const uint32_t *Bw;      // inter-pass buffer
+    const uint4 *coef;       // make_coef_frags
+    int ncells;
+    float w0sq_plus_w1sq;    // w_d^2 + w_p^2
+    unsigned *cellbound;     // per cell: max of the Cauchy-Schwarz bound (float bits; probe output)
+    float *dbg;              // optional: |y_d|^2, |y_p|^2 of one (cell, t3 group): [2][53][12][4]
+    int dbg_cell, dbg_group;
+};
+
+// real 12-point transform F[t] = sum_k v[k] exp(+2 pi j k t / 12) of a real sequence: P = re F (t = 0..6), Q = im F (t = 1..5)
+__device__ __forceinline__ void real_dft6(float a0, float a1, float a2, float a3, float a4, float a5, float (&re)[4], float (&im)[4]) {
+    constexpr float h3 = 0.86602540378443865f;
+    const float s0 = a0 + a3, d0 = a0 - a3, s1 = a1 + a4, d1 = a1 - a4, s2 = a2 + a5, d2 = a2 - a5;
+    const float s12 = s1 + s2, d12 = d1 - d2;
+    re[0] = s0 + s12, im[0] = 0.f;
+    re[2] = fmaf(-0.5f, s12, s0), im[2] = h3 * (s1 - s2);
+    re[1] = fmaf(0.5f, d12, d0), im[1] = h3 * (d1 + d2);
+    re[3] = d0 - d12, im[3] = 0.f;
+}
+__device__ __forceinline__ void real_dft12(const float (&v)[12], float (&P)[7], float (&Q)[7]) {
+    float er[4], ei[4], orr[4], oi[4];
+    real_dft6(v[0], v[2], v[4], v[6], v[8], v[10], er, ei);
+    real_dft6(v[1], v[3], v[5], v[7], v[9], v[11], orr, oi);
+    constexpr float c1 = 0.86602540378443865f, s1 = 0.5f;  // W12 = exp(j pi / 6)
+    // F[t] = E[t mod 6] + W12^t O[t mod 6];  E[6 - t] = conj E[t]
+    P[0] = er[0] + orr[0], Q[0] = 0.f;
+    P[6] = er[0] - orr[0], Q[6] = 0.f;
+    P[3] = er[3], Q[3] = orr[3];  // W12^3 = j, E[3], O[3] real
+    // t = 1: W = (c1, s1)
+    P[1] = er[1] + c1 * orr[1] - s1 * oi[1], Q[1] = ei[1] + c1 * oi[1] + s1 * orr[1];
+    // t = 5: E[5] = conj E[1], O[5] = conj O[1], W^5 = (-c1, s1)
+    P[5] = er[1] - c1 * orr[1] + s1 * oi[1], Q[5] = -ei[1] + c1 * oi[1] + s1 * orr[1];
+    // t = 2: W^2 = (s1, c1)
+    P[2] = er[2] + s1 * orr[2] - c1 * oi[2], Q[2] = ei[2] + s1 * oi[2] + c1 * orr[2];
+    // t = 4: E[4] = conj E[2], O[4] = conj O[2], W^4 = (-s1, c1)
+    P[4] = er[2] - s1 * orr[2] + c1 * oi[2], Q[4] = -ei[2] + s1 * oi[2] + c1 * orr[2];
+}
+
+template <int NC, bool DBG>
+__global__ __launch_bounds__(kColsThreads) void k_pfa_cols(ColsArgs A) {
+    extern __shared__ __align__(16) unsigned char pfa_lds[];
+    uint4 *s_coef = reinterpret_cast<uint4 *>(pfa_lds);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < kCoefFrags * 64; i += kColsThreads) s_coef[i] = A.coef[i];
+    __syncthreads();
+    const int ai = lane & 15, g = ai >> 2, r = ai & 3, ks = lane >> 4;
+    const float sgn = (lane & 1) ? 1.f : -1.f;
+    constexpr int kBlocks = (K3 + 15) / 16;  // 196 blocks of 16 lags t3 per cell
+    for (long item = blockIdx.x; item < (long)A.ncells * kBlocks; item += gridDim.x) {
+        const int cell = (int)(item / kBlocks), blk = (int)(item % kBlocks);
+        const int t0 = 16 * blk + 4 * wave;
+        if (t0 >= K3) continue;
+        const int t3 = min(t0 + g, K3 - 1);
+        const uint32_t *base = A.Bw + (size_t)cell * kCellElems;
+        // ---- A fragments: [component][quad][ins], k1 = 4 mg .. 4 mg + 3 with mg = 4 ins + ks, of (k2 = 4 quad + r, t3)
+        uint4 fa[2][3][4];
+#pragma unroll
+        for (int quad = 0; quad < 3; ++quad)
+#pragma unroll
+            for (int ins = 0; ins < 4; ++ins) {
+                const int mg = 4 * ins + ks;
+                uint4 l0 = make_uint4(0, 0, 0, 0), l1 = l0;
+                const size_t off = ((size_t)(4 * quad + r) * K3 + t3) * 4;
+                if (2 * mg < MP) l0 = *reinterpret_cast<const uint4 *>(base + (size_t)(2 * mg) * K2 * K3 * 4 + off);
+                if (2 * mg + 1 < MP) l1 = *reinterpret_cast<const uint4 *>(base + (size_t)(2 * mg + 1) * K2 * K3 * 4 + off);
+                fa[0][quad][ins] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                fa[1][quad][ins] = make_uint4(l0.z, l0.w, l1.z, l1.w);
+            }
+        float best = 0.f;
+        for (int nb = 0; nb < NB; ++nb) {
+            uint4 fb[4][2];
+#pragma unroll
+            for (int ins = 0; ins < 4; ++ins)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) fb[ins][part] = s_coef[((nb * 4 + ins) * 2 + part) * 64 + lane];
+            float m2[2][12];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                f4 acc[3];
+#pragma unroll
+                for (int quad = 0; quad < 3; ++quad) acc[quad] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ins = 0; ins < 4; ++ins)
+#pragma unroll
+                    for (int part = 0; part < 2; ++part)
+#pragma unroll
+                        for (int quad = 0; quad < 3; ++quad)
+                            acc[quad] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, fa[c][quad][ins]), __builtin_bit_cast(h8, fb[ins][part]),
+                                                                               acc[quad], 0, 0, 0);
+                // lane (G = lane >> 4, o = lane & 15): acc[quad][rr] = row 4 G + rr <-> (t3 = t0 + G, k2 = 4 quad + rr) of output 16 nb + o
+                float v[12], P[7], Q[7];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) v[k] = acc[k >> 2][k & 3];
+                real_dft12(v, P, Q);
+                // the lane pair (o even: re part of z, o odd: im part): y[t] = A[t] + j B[t] -> even lane: re y = P - Q', odd lane: im y = P + Q'
+                float rr[12];
+                rr[0] = P[0], rr[6] = P[6];
+#pragma unroll
+                for (int t = 1; t < 6; ++t) {
+                    const float qp = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, Q[t]), 0xB1, 0xf, 0xf, true));
+                    rr[t] = fmaf(sgn, qp, P[t]);
+                    rr[12 - t] = fmaf(-sgn, qp, P[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 12; ++t) {
+                    const float sq = rr[t] * rr[t];
+                    const float sp = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sq), 0xB1, 0xf, 0xf, true));
+                    m2[c][t] = sq + sp;
+                }
+            }
+            const int o = 16 * nb + (lane & 15), t1 = o >> 1;
+            const bool real_out = t1 < K1 && t0 + (lane >> 4) < K3;
+            if (real_out) {
+#pragma unroll
+                for (int t = 0; t < 12; ++t) best = fmaxf(best, NC == 2 ? m2[0][t] + m2[1][t] : m2[0][t]);
+            }
+            if (DBG && cell == A.dbg_cell && t0 / 4 == A.dbg_group && t1 < K1 && !(lane & 1)) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int t = 0; t < 12; ++t) A.dbg[((c * K1 + t1) * 12 + t) * 4 + (lane >> 4)] = m2[c][t];
+            }
+        }
+        // Cauchy-Schwarz bound of the wave: (w_d |y_d| + w_p |y_p|)^2 <= (w_d^2 + w_p^2)(|y_d|^2 + |y_p|^2)
+        best *= A.w0sq_plus_w1sq;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
+        if (lane == 0 && __float_as_uint(best) > A.cellbound[cell]) atomicMax(&A.cellbound[cell], __float_as_uint(best));
+    }
+}
+
+}  // namespace pfa
+}  // namespace bds

@@ -1,0 +1,200 @@
+// Probe of the N-point search pair (csrc/bds_acq_pfa.h): correctness of the row pass (k_pfa_rows) and of the column
+// pass (k_pfa_cols: 53-point stage on the matrix pipe) against direct float64 evaluation, then their time per 201 cells at cfg3 sizes.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-slp-vectorize -I bds-3-b1c-b2a-sdr-receiver_amd/csrc
+//         tools/probe/pfa_pair.hip -o gpurun_out/pfa_pair && gpurun_out/pfa_pair [prns] [reps]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "bds_acq_pfa.h"
+
+using namespace bds::pfa;
+typedef std::complex<double> cd;
+
+#define CK(x)                                                                                         \
+    do {                                                                                              \
+        hipError_t e_ = (x);                                                                          \
+        if (e_ != hipSuccess) {                                                                       \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));        \
+            exit(2);                                                                                  \
+        }                                                                                             \
+    } while (0)
+
+static uint16_t f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }
+static float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+static uint32_t pack(float re, float im) { return (uint32_t)f2h(re) | ((uint32_t)f2h(im) << 16); }
+static cd unpack(uint32_t u) { return cd(h2f((uint16_t)(u & 0xffff)), h2f((uint16_t)(u >> 16))); }
+
+int main(int argc, char **argv) {
+    const int prns = argc > 1 ? atoi(argv[1]) : 4, reps = argc > 2 ? atoi(argv[2]) : 3, D = 201;
+    const int nslots = std::max(prns, 2);
+    std::mt19937_64 rng(7);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    // spectra in natural order (fp16-exact values), then the CRT layouts the kernels read
+    std::vector<uint32_t> Xnat(NP), Cnat((size_t)nslots * 2 * NP);
+    for (long k = 0; k < NP; ++k) Xnat[k] = pack(8.f * nd(rng), 8.f * nd(rng));
+    for (size_t i = 0; i < Cnat.size(); ++i) Cnat[i] = pack(0.125f * nd(rng), 0.125f * nd(rng));
+    std::vector<uint32_t> Xs((size_t)K1 * K2 * 2 * K3), Cs(Cnat.size());
+    for (long k = 0; k < NP; ++k) {
+        const int k1 = k % K1, k2 = k % K2, k3 = k % K3;
+        Xs[((size_t)k1 * K2 + k2) * 2 * K3 + k3] = Xnat[k];
+        Xs[((size_t)k1 * K2 + k2) * 2 * K3 + K3 + k3] = Xnat[k];
+        for (int sc = 0; sc < nslots * 2; ++sc) Cs[(size_t)sc * NP + ((size_t)k1 * K2 + k2) * K3 + k3] = Cnat[(size_t)sc * NP + k];
+    }
+    // cells of the correctness run
+    const int tb[6] = {0, 1, 5, 57, 100, 200}, tslot[6] = {0, 0, 0, 1, 1, 1};
+    const int ncell_t = 6;
+    const int ncells = prns * D;
+    std::vector<int> h_bin(std::max(ncells, ncell_t));
+    std::vector<long> h_cs(std::max(ncells, ncell_t));
+    uint32_t *d_Xs, *d_Cs, *d_Bw;
+    int *d_bin;
+    long *d_cs;
+    uint4 *d_coef;
+    unsigned *d_bound;
+    float *d_dbg;
+    CK(hipMalloc(&d_Xs, Xs.size() * 4));
+    CK(hipMalloc(&d_Cs, Cs.size() * 4));
+    CK(hipMalloc(&d_Bw, (size_t)std::max(ncells, ncell_t) * kCellElems * 4));
+    CK(hipMalloc(&d_bin, h_bin.size() * sizeof(int)));
+    CK(hipMalloc(&d_cs, h_cs.size() * sizeof(long)));
+    CK(hipMalloc(&d_coef, kCoefBytes));
+    CK(hipMalloc(&d_bound, h_bin.size() * sizeof(unsigned)));
+    CK(hipMalloc(&d_dbg, sizeof(float) * 2 * K1 * 12 * 4));
+    CK(hipMemcpy(d_Xs, Xs.data(), Xs.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_Cs, Cs.data(), Cs.size() * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<uint16_t> cf(kCoefBytes / 2);
+        make_coef_frags(cf.data());
+        CK(hipMemcpy(d_coef, cf.data(), kCoefBytes, hipMemcpyHostToDevice));
+    }
+    const size_t rows_lds = 2 * 3136 * sizeof(float2);
+    CK(hipFuncSetAttribute((const void *)k_pfa_cols<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoefBytes));
+    CK(hipFuncSetAttribute((const void *)k_pfa_cols<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoefBytes));
+
+    // ---------------- correctness: each test cell is its own one-cell chunk (gc = 1: the PRN slot changes from cell to cell)
+    for (int i = 0; i < ncell_t; ++i) h_bin[i] = tb[i], h_cs[i] = (long)tslot[i] * 2 * NP;
+    CK(hipMemcpy(d_bin, h_bin.data(), ncell_t * sizeof(int), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_cs, h_cs.data(), ncell_t * sizeof(long), hipMemcpyHostToDevice));
+    CK(hipMemset(d_Bw, 0xff, (size_t)ncell_t * kCellElems * 4));  // NaN pattern: every element must be written
+    RowsArgs ra{d_Xs, d_Cs, d_Bw, d_bin, d_cs, ncell_t, 1, 2};
+    hipLaunchKernelGGL(k_pfa_rows<2>, dim3(MP * K2 * ncell_t), dim3(kRowsThreads), rows_lds, 0, ra);
+    CK(hipDeviceSynchronize());
+    std::vector<uint32_t> Bw((size_t)ncell_t * kCellElems);
+    CK(hipMemcpy(Bw.data(), d_Bw, Bw.size() * 4, hipMemcpyDeviceToHost));
+    auto Ycrt = [&](int cell, int comp, int k1, int k2, int k3) {  // product spectrum of a cell at CRT coordinates
+        const int s = tb[cell];
+        const int a = ((k1 - s) % K1 + K1) % K1, b = ((k2 - s) % K2 + K2) % K2, c = ((k3 - s) % K3 + K3) % K3;
+        return unpack(Xs[((size_t)a * K2 + b) * 2 * K3 + c]) * unpack(Cs[((size_t)tslot[cell] * 2 + comp) * NP + ((size_t)k1 * K2 + k2) * K3 + k3]);
+    };
+    double worst_rows = 0, rms_rows = 0;
+    long nchk = 0;
+    std::uniform_int_distribution<int> u1(0, K1), u2(0, K2 - 1), u3(0, K3 - 1);
+    for (int cell = 0; cell < ncell_t; ++cell)
+        for (int trial = 0; trial < 40; ++trial) {
+            const int k1 = trial == 0 ? 53 : trial == 1 ? 52 : u1(rng) % 54, k2 = u2(rng), t3 = trial < 4 ? (trial & 1 ? K3 - 1 : 0) : u3(rng);
+            for (int comp = 0; comp < 2; ++comp) {
+                cd ref = 0;
+                if (k1 < K1)
+                    for (int k3 = 0; k3 < K3; ++k3) ref += Ycrt(cell, comp, k1, k2, k3) * std::polar(1.0, 2 * M_PI * (double)(((long)k3 * t3) % K3) / K3);
+                const cd got = unpack(Bw[(size_t)cell * kCellElems + ((((size_t)(k1 / 2) * K2 + k2) * K3 + t3) * 2 + comp) * 2 + (k1 & 1)]);
+                worst_rows = std::max(worst_rows, std::abs(got - ref));
+                rms_rows += std::norm(ref);
+                ++nchk;
+            }
+        }
+    rms_rows = std::sqrt(rms_rows / nchk);
+    printf("row pass: %ld sampled outputs of %d cells: worst |error| %.3g against an rms output of %.3g (%.2e; fp16 rounding is 4.9e-4 of a value)\n", nchk, ncell_t,
+           worst_rows, rms_rows, worst_rows / rms_rows);
+    size_t nan_left = 0;
+    for (size_t i = 0; i < Bw.size(); ++i) nan_left += Bw[i] == 0xffffffffu;
+    printf("          elements of the inter-pass buffer never written: %zu of %zu\n", nan_left, Bw.size());
+
+    // column pass on the GPU's own buffer, one (cell, t3 group) at a time in debug mode
+    double worst_cols = 0, worst_e2e = 0, big = 0;
+    for (int cell : {0, 3, 5})
+        for (int grp : {0, 311, 781}) {
+            CK(hipMemset(d_bound, 0, ncell_t * sizeof(unsigned)));
+            CK(hipMemset(d_dbg, 0, sizeof(float) * 2 * K1 * 12 * 4));
+            ColsArgs ca{d_Bw, d_coef, ncell_t, 1.0f, d_bound, d_dbg, cell, grp};
+            hipLaunchKernelGGL((k_pfa_cols<2, true>), dim3(512), dim3(kColsThreads), kCoefBytes, 0, ca);
+            CK(hipDeviceSynchronize());
+            std::vector<float> dbg(2 * K1 * 12 * 4);
+            CK(hipMemcpy(dbg.data(), d_dbg, dbg.size() * 4, hipMemcpyDeviceToHost));
+            for (int comp = 0; comp < 2; ++comp)
+                for (int g = 0; g < 4; ++g) {
+                    const int t3 = 4 * grp + g;
+                    if (t3 >= K3) continue;
+                    for (int t1 : {0, 1, 17, 52})
+                        for (int t2 : {0, 1, 5, 6, 7, 11}) {
+                            cd y = 0;
+                            for (int k1 = 0; k1 < K1; ++k1)
+                                for (int k2 = 0; k2 < K2; ++k2)
+                                    y += unpack(Bw[(size_t)cell * kCellElems + ((((size_t)(k1 / 2) * K2 + k2) * K3 + t3) * 2 + comp) * 2 + (k1 & 1)]) *
+                                         std::polar(1.0, 2 * M_PI * ((double)((k1 * t1) % K1) / K1 + (double)((k2 * t2) % K2) / K2));
+                            const double got = dbg[((comp * K1 + t1) * 12 + t2) * 4 + g];
+                            worst_cols = std::max(worst_cols, std::abs(got - std::norm(y)));
+                            big = std::max(big, std::norm(y));
+                        }
+                }
+            // end to end for two lags of this group: y[t] = sum_k Y[k] exp(+2 pi j k t / N) in natural order
+            for (int pick = 0; pick < 2; ++pick) {
+                const int t1 = pick ? 52 : 17, t2 = pick ? 11 : 5, g = pick ? 0 : 1, t3 = 4 * grp + g;
+                if (t3 >= K3) continue;
+                const long t = lag_of(t1, t2, t3);
+                const int s = tb[cell];
+                for (int comp = 0; comp < 2; ++comp) {
+                    cd y = 0;
+                    for (long k = 0; k < NP; ++k) {
+                        const long ks = ((k - s) % NP + NP) % NP;
+                        const __int128 ph = ((__int128)k * t) % NP;
+                        y += unpack(Xnat[ks]) * unpack(Cnat[((size_t)tslot[cell] * 2 + comp) * NP + k]) * std::polar(1.0, 2 * M_PI * (double)(long)ph / NP);
+                    }
+                    const double got = dbg[((comp * K1 + t1) * 12 + t2) * 4 + g];
+                    worst_e2e = std::max(worst_e2e, std::abs(std::sqrt(got) - std::abs(y)) / std::abs(y));
+                }
+            }
+        }
+    printf("column pass: worst error of |y|^2 against a float64 53 x 12 transform of the SAME buffer: %.3g of the largest (%.3g)\n", worst_cols / big, big);
+    printf("pair, end to end: worst relative error of |y| against the N-point sum in natural order (index maps, rotation, fp16 storage): %.2e\n", worst_e2e);
+
+    // ---------------- timing at cfg3 sizes: prns x 201 cells, row workgroups walk all 201 bins of their PRN
+    for (int p = 0; p < prns; ++p)
+        for (int b = 0; b < D; ++b) h_bin[p * D + b] = b, h_cs[p * D + b] = (long)(p % nslots) * 2 * NP;
+    CK(hipMemcpy(d_bin, h_bin.data(), ncells * sizeof(int), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_cs, h_cs.data(), ncells * sizeof(long), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1, e2;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventCreate(&e2));
+    for (int gc : {201, 67}) {
+        RowsArgs rt{d_Xs, d_Cs, d_Bw, d_bin, d_cs, ncells, gc, 2};
+        const int chunks = (ncells + gc - 1) / gc;
+        for (int cgrid : {2048, 4096}) {
+            float best_r = 1e9f, best_c = 1e9f;
+            for (int rep = 0; rep < reps; ++rep) {
+                CK(hipMemset(d_bound, 0, ncells * sizeof(unsigned)));
+                ColsArgs ct{d_Bw, d_coef, ncells, 1.0f, d_bound, nullptr, -1, -1};
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_pfa_rows<2>, dim3(MP * K2 * chunks), dim3(kRowsThreads), rows_lds, 0, rt);
+                CK(hipEventRecord(e1));
+                hipLaunchKernelGGL((k_pfa_cols<2, false>), dim3(cgrid), dim3(kColsThreads), kCoefBytes, 0, ct);
+                CK(hipEventRecord(e2));
+                CK(hipDeviceSynchronize());
+                float mr, mc;
+                CK(hipEventElapsedTime(&mr, e0, e1));
+                CK(hipEventElapsedTime(&mc, e1, e2));
+                best_r = std::min(best_r, mr), best_c = std::min(best_c, mc);
+            }
+            printf("timing: %d PRNs x %d bins, %d-cell row workgroups, column grid %d: rows %.3f ms + columns %.3f ms per 201 cells = %.3f ms  (L-point pair of round 5: 3.0 - 3.1 ms)\n",
+                   prns, D, gc, cgrid, best_r / prns, best_c / prns, (best_r + best_c) / prns);
+        }
+    }
+    return 0;
+}
