@@ -33,6 +33,7 @@
 #include "bds_acq_wcols.h"
 #include "bds_acq_refine.h"
 #include "bds_acq_wrows.h"
+#include "bds_acq_pfa.h"
 #include "bds_internal.h"
 
 namespace bds {
@@ -189,6 +190,9 @@ struct AcqState {
     double sum_sq_ext = 0;     // sum x^2 over it: X_rms^2 (Parseval)
     long sums_N = 0, sums_next = 0;  // sizes the two sums above were computed for
     float sX = 1.f, sC = 1.f, sB = 1.f;  // power-of-two storage scales
+    // N-point plan (bds_acq_pfa.h, round 6): the cached code spectra are in its layout (53 x 12 x 3125, CRT order), the search runs its pair
+    bool cs_pfa = false;
+    uint4 *d_pfa_coef = nullptr;  // B fragments of the 53-point stage (pfa::make_coef_frags)
     long sigpower_X = 0;       // X the cached B1C normaliser was computed for (0: none; reset by bds_acq_load)
     double sigpower = 0;       // sqrt(var(sig(1:X)) * X), B1C/acquisition.m:150
 };
@@ -196,7 +200,7 @@ struct AcqState {
 void acq_state_free(AcqState *a) {
     if (!a) return;
     plan_free(a->plan);
-    for (void *p : {(void *)a->d_sig, (void *)a->d_prim, (void *)a->d_Cs, (void *)a->d_Xs, (void *)a->d_Bw,
+    for (void *p : {(void *)a->d_sig, (void *)a->d_prim, (void *)a->d_Cs, (void *)a->d_Xs, (void *)a->d_Bw, (void *)a->d_pfa_coef,
                     (void *)a->d_recs, (void *)a->d_rowmax, (void *)a->d_rowarg, (void *)a->d_jobs, (void *)a->d_codes,
                     (void *)a->d_jobout, (void *)a->d_sig64, (void *)a->d_ffa, (void *)a->d_ffb, (void *)a->d_fir, (void *)a->d_cells, (void *)a->d_mcells,
                     (void *)a->d_extra, (void *)a->d_extra_count, (void *)a->d_cellmax, (void *)a->d_lb, (void *)a->d_ref_zero,
@@ -771,6 +775,18 @@ extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s_in, const int8_t
     return BDS_OK;
 }
 
+// Does the N-point pair (bds_acq_pfa.h) apply to a run with these settings?  B1C with both components on N = 53 x 12 x 3125 samples
+// (99.375 MS/s, acqCohT = 10), fp16 storage, no resampling, and whole spectrum bins per Doppler step: acqStep N / fs an integer
+// (B1C/acquisition.m:194-198: frqBins(b) = IF - band + acqStep (b - 1), so fft(carr_b x)[k] = fft(carr_1 x)[k - (b - 1) acqStep N / fs]).
+// Everything else -- and every fallback of a run (fp32 storage, run-time-plan kernels) -- takes the L-point pair.
+static int pfa_shift(const bds_ctx *ctx, const AcqState &a, const bds_settings &s) {
+    if (!ctx->tune.pfa || !a.half || a.no_fast_search || a.signal != BDS_SIGNAL_B1C || a.ncomp != 2 || a.N != pfa::NP || a.rs.on) return 0;
+    const double sh = s.acqStep * (double)a.N / s.samplingFreq;
+    const long D = (long)m_round(s.acqSearchBand * 2 / s.acqStep) + 1;
+    if (!(sh >= 1.0) || sh != std::floor(sh) || sh * (double)D >= (double)a.N) return 0;
+    return (int)sh;
+}
+
 extern "C" int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s_in) {
     if (!ctx || !s_in) return BDS_ERR_ARG;
     if (int rc0 = check_settings(ctx, *s_in)) return rc0;  // (the resampling band edges are only visible here)
@@ -784,6 +800,18 @@ extern "C" int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s_in) {
     Plan2D &pl = a.plan;
     pick_group(a, *s);
     if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a, ctx->tune) * (size_t)pl.L))) return rc;
+    {   // layout of the cached code spectra: the N-point plan's or the L-point plan's; a change drops the cache
+        const bool want = pfa_shift(ctx, a, *s) > 0;
+        if (want != a.cs_pfa) a.cs_slot.clear();
+        a.cs_pfa = want;
+        if (a.half) a.sC = (float)std::exp2(std::floor(std::log2(32768.0 * (double)(want ? a.N : pl.L) / (double)a.X)));
+        if (want && !a.d_pfa_coef) {
+            std::vector<uint16_t> cf(pfa::kCoefBytes / 2);
+            pfa::make_coef_frags(cf.data());
+            BDS_HIP(ctx, hipMalloc((void **)&a.d_pfa_coef, pfa::kCoefBytes));
+            BDS_HIP(ctx, hipMemcpy(a.d_pfa_coef, cf.data(), pfa::kCoefBytes, hipMemcpyHostToDevice));
+        }
+    }
     std::vector<int> todo;
     for (int i = 0; i < s->n_acq; ++i)
         if (!a.cs_slot.count(s->acqSatelliteList[i]) &&
@@ -811,7 +839,11 @@ extern "C" int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s_in) {
         // half storage: the same byte buffer holds 4-byte elements, so offsets count in those
         float2 *cs_dst = a.half ? (float2 *)((__half2 *)a.d_Cs + (size_t)slot * a.ncomp * pl.L)
                                 : a.d_Cs + (size_t)slot * a.ncomp * pl.L;
-        if ((rc = forward(ctx, a, ld, a.ncomp, cs_dst, pl.L, 1, (float)((double)a.sC / (double)pl.L)))) return rc;
+        if (a.cs_pfa) {  // conj(fft(code)) / N in the CRT layout, [slot][component][53][12][3125] (the slots keep the L-point stride)
+            pfa::forward(st(ctx), ld, a.ncomp, a.d_Bw, (uint32_t *)cs_dst, pfa::NP, 1, (float)((double)a.sC / (double)a.N), 0);
+            BDS_HIP(ctx, hipGetLastError());
+        } else if ((rc = forward(ctx, a, ld, a.ncomp, cs_dst, pl.L, 1, (float)((double)a.sC / (double)pl.L))))
+            return rc;
         a.cs_slot[prn] = slot;
     }
     BDS_HIP(ctx, hipStreamSynchronize(st(ctx)));
@@ -953,6 +985,8 @@ struct AcqRun {
     double f0 = 0, kDelta = 0;
     float w0 = 1.f, w1 = 1.f;
     bool fsearch = false, wcols = false, multiprn = false, overlap = false;
+    int pfa = 0;               // > 0: the N-point pair runs (bds_acq_pfa.h); the value = spectrum bins per Doppler step
+    size_t cell_elems = 0;     // fp16-complex-sized elements of one cell in the inter-pass buffer (both components)
     bool dev_refined = false;  // the refinement ran as the device chain
     size_t elem = 8;  // bytes of one stored complex value
     int PB = 1;
@@ -1010,8 +1044,11 @@ int AcqRun::setup() {
     ncomp = a.ncomp;
     pick_group(a, *s);
     G = a.group;
+    pfa = a.cs_pfa ? pfa_shift(ctx, a, *s) : 0;  // (bds_acq_prepare laid the code spectra out for it with these very settings)
+    if (a.cs_pfa && !pfa) return fail(ctx, BDS_ERR_HIP, "internal: code spectra in the N-point layout for a run that cannot use them");
     if ((rc = ensure(ctx, &a.d_Bw, &a.bw_cap, bw_batches(a, ctx->tune) * (size_t)pl.L))) return rc;
-    if ((rc = ensure(ctx, &a.d_Xs, &a.xs_cap, (size_t)D * pl.L))) return rc;
+    // (N-point pair: ONE signal spectrum, every row stored twice -- 2 N fp16 complex = N float2-sized elements)
+    if ((rc = ensure(ctx, &a.d_Xs, &a.xs_cap, pfa ? (size_t)pfa::NP : (size_t)D * pl.L))) return rc;
 
     BDS_HIP(ctx, evp.make(&ev0));
     BDS_HIP(ctx, evp.make(&ev1));
@@ -1031,7 +1068,10 @@ int AcqRun::setup() {
         // |X[k]| <= sum|x|  -> keep the stored spectrum below 2^15
         a.sX = (float)std::exp2(std::floor(std::log2(32768.0 / std::max(1.0, a.sum_abs_ext))));
         // inter-pass values: rms = X_rms * C_rms / L * sqrt(L2) (Parseval); allow 64 x rms
-        const double b_rms = std::sqrt(a.sum_sq_ext) * std::sqrt((double)a.X) / (double)pl.L * std::sqrt((double)pl.L2);
+        // (N-point pair: transform length N, rows of 3125 points; its row pass has no output scale -- sB rides on the stored signal
+        //  spectrum, whose rms stays ~0.2 whatever the block: forward_all)
+        const double b_rms = pfa ? std::sqrt(a.sum_sq_ext) * std::sqrt((double)a.X) / (double)a.N * std::sqrt((double)pfa::K3)
+                                 : std::sqrt(a.sum_sq_ext) * std::sqrt((double)a.X) / (double)pl.L * std::sqrt((double)pl.L2);
         a.sB = (float)std::exp2(std::floor(std::log2(32768.0 / (64.0 * std::max(1e-30, b_rms) * a.sX * a.sC))));
     }
 
@@ -1046,7 +1086,7 @@ int AcqRun::setup() {
         w0 *= inv;
         w1 *= inv;
     }
-    fsearch = (pl.fast || (pl.small && a.half)) && !a.no_fast_search;  // fp32-arithmetic specialised kernels (default)
+    fsearch = (pl.fast || (pl.small && a.half) || pfa) && !a.no_fast_search;  // fp32-arithmetic specialised kernels (default)
     // sieve tolerance: every lag within kDelta of a PRN's maximum is re-evaluated in f64.  fp32 storage (with the fp32 carrier / twiddle
     // rotations of the forward pass, round 4) errs by 5.3e-7 of the PRN maximum at worst against the f64 oracle (tools/sieve_error.py,
     // profiles/r05_sieve_error_small.txt: 19x inside its kDelta / 2 = 1e-5; checked at run time like the fp16 mode).  fp16 storage: three roundings lie between the exact value and the sieve's (signal spectrum, code spectrum,
@@ -1066,7 +1106,7 @@ int AcqRun::setup() {
     // bounds instead of per-tile records
     // (the 256-point plans keep the tile kernel unless forced with BDS_ACQ_WCOLS=1: a workgroup's share of such a tile is
     //  8 points per lane and the per-workgroup constants and barriers dominate -- measured at cfg2 2.18 vs 1.39 ms per launch)
-    wcols = fsearch && (pl.small || (tune.wcols != 0 && (pl.L1 != 256 || tune.wcols > 0)));
+    wcols = fsearch && (pfa || pl.small || (tune.wcols != 0 && (pl.L1 != 256 || tune.wcols > 0)));
     so = SieveOut{nullptr, a.d_extra, a.d_extra_count, kExtraCap, 0, (float)(1.0 - kDelta)};
     if (wcols) {
         if ((rc = ensure(ctx, &a.d_cellmax, &a.cellmax_cap, (size_t)std::max(P, 1) * D))) return rc;
@@ -1089,6 +1129,7 @@ int AcqRun::setup() {
         so.recs = a.d_recs;
     }
     elem = a.half ? 4 : 8;
+    cell_elems = pfa ? pfa::kCellElems : (size_t)ncomp * pl.L;  // stored complex values of one cell in the inter-pass buffer
     // One launch pair carries the whole Doppler rows of SEVERAL PRNs through a cell list: the grids fill the chip, a row workgroup
     // walks all the bins of one PRN (its code rows and twiddles set up once per D cells), the row workgroups of different PRNs
     // read the same spectrum rows at about the same time, and a call is a few long launches instead of many short ones.
@@ -1112,7 +1153,7 @@ int AcqRun::setup() {
     const double pair_gb = tune.pbcap_gb > 0 ? tune.pbcap_gb : a.pair_gb_set ? a.pair_gb : tune.pair_gb;
     multiprn = fsearch && P > 1 && !tune.nomulti && (D <= 104 || tune.multi_any || pair_gb != 0);
     PB = 1;
-    const double pb_key[6] = {(double)P, (double)D, (double)pl.L, (double)elem, (double)ncomp, pair_gb + (tune.pbcells ? 1e6 * tune.pbcells : 0)};
+    const double pb_key[6] = {(double)P, (double)D, (double)cell_elems, (double)elem, (double)ncomp, pair_gb + (tune.pbcells ? 1e6 * tune.pbcells : 0)};
     const bool pb_known = multiprn && a.pb_last > 0 && !memcmp(pb_key, a.pb_key, sizeof(pb_key));
     if (pb_known) {
         PB = a.pb_last;
@@ -1124,7 +1165,7 @@ int AcqRun::setup() {
             if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)16 << 30;
             budget = 0.6 * ((double)fr + (double)a.bw_cap * sizeof(float2));
         }
-        const long pb_cap = (long)(budget / ((double)ncomp * (double)pl.L * (double)elem));  // cells
+        const long pb_cap = (long)(budget / ((double)cell_elems * (double)elem));  // cells
         const long pb_cells = tune.pbcells ? std::min<long>(tune.pbcells, pb_cap) : pb_cap;
         const long pb_max = std::min<long>(P, std::max<long>(D <= 104 ? 2 : 1, pb_cells / D));
         const bool explicit_budget = tune.pbcap_gb > 0 || a.pair_gb_set || tune.pair_gb_env || tune.pbcells > 0 || tune.multi_any;
@@ -1142,6 +1183,7 @@ int AcqRun::setup() {
     n_pairs_total = (long)P * ((D + G - 1) / G);
     cells_per_pair = G;
     if (multiprn) n_pairs_total = (P + PB - 1) / PB, cells_per_pair = (long)PB * D;
+    if (pfa && !multiprn) multiprn = true, PB = 1, n_pairs_total = P, cells_per_pair = D;  // the N-point pair always runs on cell lists
     // Overlapped passes (BDS_ACQ_OVERLAP=1, fp32-arithmetic kernels): group k's column pass runs on a second stream beside
     // group k+1's row pass, the two working in different halves of the inter-pass buffer.
     overlap = fsearch && tune.overlap && !multiprn;
@@ -1156,6 +1198,13 @@ int AcqRun::setup() {
 
 int AcqRun::forward_all() {
     Plan2D &pl = a.plan;
+    if (pfa) {  // ONE transform: the spectrum of bin 0; bin b is its rotation by b * pfa bins (bds_acq_pfa.h)
+        SignalLoader ld{a.sview(), a.N, a.n_ext, f0, s->acqStep, 1.0 / a.fs, 0};
+        pfa::forward(stream(), ld, 1, a.d_Bw, (uint32_t *)a.d_Xs, 0, 0, a.sX * a.sB, 1);
+        BDS_HIP(ctx, hipGetLastError());
+        BDS_HIP(ctx, hipEventRecord(ev1, stream()));
+        return BDS_OK;
+    }
     const int chunk = (int)bw_batches(a, ctx->tune);
     for (int b0 = 0; b0 < D; b0 += chunk) {
         const int nb = std::min(chunk, D - b0);
@@ -1223,6 +1272,21 @@ void AcqRun::launch_list(int ncells, Rec *recs, const CellList &cl, int cell0, h
     so1.mid = mid;
     if (mid) mids = true;
     const int hi1 = cl.rng ? -1 : (int)a.N - 1, lo2 = cl.rng ? 0 : 1, hi2 = cl.rng ? -1 : 0;
+    if (pfa) {  // the N-point pair (bds_acq_pfa.h): every lag of the N is searched, the cells come as a list
+        const int gc = std::max(1, cl.gc), chunks = (ncells + gc - 1) / gc;
+        const size_t rows_lds = 2 * 3136 * sizeof(float2);
+        want_lds(ctx, pfa::k_pfa_cols<2, false>, pfa::kCoefBytes);
+        pfa::RowsArgs ra{(const uint32_t *)a.d_Xs, (const uint32_t *)a.d_Cs, (uint32_t *)a.d_Bw, cl.bin, cl.cs, ncells, gc, pfa};
+        hipLaunchKernelGGL(pfa::k_pfa_rows<2>, dim3((unsigned)(pfa::MP * pfa::K2 * chunks)), dim3(pfa::kRowsThreads), rows_lds, s_main, ra);
+        if (mid) (void)hipEventRecord(mid, s_main);
+        const int qch = ctx->tune.pfa_qchunk > 0 ? ctx->tune.pfa_qchunk : 4;
+        const long items = (long)((196 + qch - 1) / qch) * qch * ncells;
+        const unsigned cgrid = (unsigned)std::min<long>(items, ctx->tune.pfa_cgrid > 0 ? ctx->tune.pfa_cgrid : 4096);
+        pfa::ColsArgs ca{(const uint32_t *)a.d_Bw, a.d_pfa_coef, ncells, w0, w1, so1.cellmax, so1.lb, so1.lb_div, so1.extra, so1.extra_count,
+                         so1.extra_cap, cell0, so1.keep, qch, nullptr, nullptr, -1, -1};
+        hipLaunchKernelGGL((pfa::k_pfa_cols<2, false>), dim3(cgrid), dim3(pfa::kColsThreads), pfa::kCoefBytes, s_main, ca);
+        return;
+    }
     if (a.half) {
         if (ncomp == 2)
             launch_fast_f<2, __half2>(ctx, s_main, pl, a.d_Xs, ncells, 0, a.d_Cs, a.d_Bw, a.sB, w0, w1, 0, hi1, lo2, hi2, so1, cl);
@@ -1247,8 +1311,8 @@ int AcqRun::search() {
         // float2-sized elements the PB*D cells of one launch pair occupy; if the device cannot give that much after all (another
         // process took it since setup() asked), halve the PRNs per pair
         for (;;) {
-            const size_t need = ((size_t)PB * D * ncomp * elem + 7) / 8;
-            if (!(rc = ensure_fit(ctx, &a.d_Bw, &a.bw_cap, std::max(need, bw_batches(a, ctx->tune)) * (size_t)pl.L))) break;
+            const size_t need = ((size_t)PB * D * cell_elems * elem + 7) / 8;
+            if (!(rc = ensure_fit(ctx, &a.d_Bw, &a.bw_cap, std::max(need, bw_batches(a, ctx->tune) * (size_t)pl.L)))) break;
             if (PB <= 2) return rc;
             (void)hipGetLastError();  // (the failed hipMalloc is handled here: it must not surface at the end of the search)
             PB = (PB + 1) / 2;
@@ -1295,7 +1359,7 @@ int AcqRun::search() {
                     const int gc_ = D / dv;  // dv chunks per PRN and row
                     if (gc_ < 32 && dv > 1) break;
                     cl.gc = gc_;
-                    if ((long)pl.L1 * np_ * dv >= want_wgs) break;
+                    if ((long)(pfa ? pfa::MP * pfa::K2 : pl.L1) * np_ * dv >= want_wgs) break;
                 }
             }
             // (a call is a handful of pairs: all of them are timed, the last, shorter one included -- cell_pair_ms and
@@ -1380,19 +1444,19 @@ int AcqRun::finish() {
     t.cell_pair_ms = nsamp ? acc / nsamp : (n_pairs_total ? t.search_ms / (double)n_pairs_total : 0);
     t.cells_per_pair = samp_cells > 0 && nsamp ? samp_cells / nsamp : (double)cells_per_pair;
     t.n_pairs = n_pairs_total;
-    t.fft_len = pl.L;
+    t.fft_len = pfa ? pfa::NP : pl.L;
     t.n_circ = a.N;
     t.n_bins = D;
     t.n_prn = P;
     t.n_comp = ncomp;
     t.half_storage = a.half ? 1 : 0;  // 0 fp32; 1 fp16 storage (fp32 arithmetic either way)
-    t.plan_l1 = pl.L1;
-    t.plan_l2 = pl.L2;
+    t.plan_l1 = pfa ? pfa::K1 * pfa::K2 : pl.L1;
+    t.plan_l2 = pfa ? pfa::K3 : pl.L2;
     t.refine_path = dev_refined ? 1 : 0;
     {
         const bool wrows_on = fsearch && a.half && pl.L2 == 4096 && (tune.wrows != 0 || pl.small);
-        t.rows_kernel = !fsearch ? 0 : wrows_on ? 2 : 1;
-        t.cols_kernel = !fsearch ? 0 : pl.small ? 3 : wcols ? 2 : 1;
+        t.rows_kernel = !fsearch ? 0 : pfa ? 3 : wrows_on ? 2 : 1;
+        t.cols_kernel = !fsearch ? 0 : pfa ? 4 : pl.small ? 3 : wcols ? 2 : 1;
         const bool ilv_on = wrows_on && wcols && ncomp == 2 && ((pl.L1 == 768 && tune.ilv != 0) || pl.small);
         t.kernel_flags = (ilv_on ? 1 : 0) | (wrows_on && tune.pk != 0 ? 2 : 0);
     }

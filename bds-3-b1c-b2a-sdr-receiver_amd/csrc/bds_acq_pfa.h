@@ -27,7 +27,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
-#include "bds_fft_pk.h"
+#include "bds_acq_wcols.h"  // Extra, wc_pack, wave_max_f32; bds_fft_pk.h
 
 namespace bds {
 namespace pfa {
@@ -105,7 +105,7 @@ struct RowsArgs {
     const long *cs;      // per cell: element offset of the PRN's spectra in Cs
     int ncells;          // cells of the launch
     int gc;              // cells a workgroup walks (all of one PRN)
-    int ncomp;           // 2 (data + pilot) or 1
+    int shift;           // spectrum bins per Doppler bin (acqStep N / fs)
 };
 
 template <int NC>
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
     for (int u = 1; u < 5; ++u) tw2[u] = unit((si * u) % 125, 125);
 
     for (int cell = c0; cell < c1; ++cell) {
-        const int s = A.bin[cell];
+        const int s = A.bin[cell] * A.shift;
         const int k1s = ((k1c - s) % K1 + K1) % K1, k2s = ((k2 - s) % K2 + K2) % K2, o3 = (K3 - s % K3) % K3;
         const uint32_t *xrow = A.Xs + ((size_t)k1s * K2 + k2s) * (2 * K3) + o3 + jj;
         uint32_t xn[25];
@@ -255,12 +255,21 @@ inline void make_coef_frags(uint16_t *out /* kCoefBytes / 2 halves */) {
 }
 
 struct ColsArgs {
-    const uint32_t *Bw;      // inter-pass buffer
-    const uint4 *coef;       // make_coef_frags
-    int ncells;
-    float w0sq_plus_w1sq;    // w_d^2 + w_p^2
-    unsigned *cellbound;     // per cell: max of the Cauchy-Schwarz bound (float bits; probe output)
-    float *dbg;              // optional: |y_d|^2, |y_p|^2 of one (cell, t3 group): [2][53][12][4]
+    const uint32_t *Bw;           // inter-pass buffer of the launch's cells
+    const uint4 *coef;            // make_coef_frags
+    int ncells;                   // cells of the launch
+    float w0, w1;                 // magnitude weights (storage scales undone)
+    unsigned long long *cellmax;  // [run-wide cell]: (value bits << 32) | ~lag, by atomic max      -- the protocol of bds_acq_wcols.h --
+    float *lb;                    // [(run-wide cell) / lb_div]: running lower bound of that PRN's sieve maximum
+    int lb_div;
+    Extra *extra;                 // candidate list
+    int *extra_count;
+    int extra_cap;
+    int cell0;                    // run-wide index of cell 0 of this launch
+    float keep;                   // 1 - tolerance of the sieve
+    int qchunk;                   // blocks of 16 lags of a cell that follow each other in the work list
+    unsigned long long *stats;    // optional (probe): [0] wave items, [1] of them through the exact pass, [2] through the exhaustive pass
+    float *dbg;                   // optional: |y_d|^2, |y_p|^2 of one (cell, t3 group): [2][53][12][4]
     int dbg_cell, dbg_group;
 };
 
@@ -283,18 +292,14 @@ __device__ __forceinline__ void real_dft12(const float (&v)[12], float (&P)[7], 
     P[0] = er[0] + orr[0], Q[0] = 0.f;
     P[6] = er[0] - orr[0], Q[6] = 0.f;
     P[3] = er[3], Q[3] = orr[3];  // W12^3 = j, E[3], O[3] real
-    // t = 1: W = (c1, s1)
     P[1] = er[1] + c1 * orr[1] - s1 * oi[1], Q[1] = ei[1] + c1 * oi[1] + s1 * orr[1];
-    // t = 5: E[5] = conj E[1], O[5] = conj O[1], W^5 = (-c1, s1)
-    P[5] = er[1] - c1 * orr[1] + s1 * oi[1], Q[5] = -ei[1] + c1 * oi[1] + s1 * orr[1];
-    // t = 2: W^2 = (s1, c1)
-    P[2] = er[2] + s1 * orr[2] - c1 * oi[2], Q[2] = ei[2] + s1 * oi[2] + c1 * orr[2];
-    // t = 4: E[4] = conj E[2], O[4] = conj O[2], W^4 = (-s1, c1)
-    P[4] = er[2] - s1 * orr[2] + c1 * oi[2], Q[4] = -ei[2] + s1 * oi[2] + c1 * orr[2];
+    P[5] = er[1] - c1 * orr[1] + s1 * oi[1], Q[5] = -ei[1] + c1 * oi[1] + s1 * orr[1];  // E[5] = conj E[1], O[5] = conj O[1], W^5 = (-c1, s1)
+    P[2] = er[2] + s1 * orr[2] - c1 * oi[2], Q[2] = ei[2] + s1 * oi[2] + c1 * orr[2];   // W^2 = (s1, c1)
+    P[4] = er[2] - s1 * orr[2] + c1 * oi[2], Q[4] = -ei[2] + s1 * oi[2] + c1 * orr[2];  // W^4 = (-s1, c1)
 }
 
 template <int NC, bool DBG>
-__global__ __launch_bounds__(kColsThreads) void k_pfa_cols(ColsArgs A) {
+__global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
     extern __shared__ __align__(16) unsigned char pfa_lds[];
     uint4 *s_coef = reinterpret_cast<uint4 *>(pfa_lds);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -303,12 +308,19 @@ __global__ __launch_bounds__(kColsThreads) void k_pfa_cols(ColsArgs A) {
     const int ai = lane & 15, g = ai >> 2, r = ai & 3, ks = lane >> 4;
     const float sgn = (lane & 1) ? 1.f : -1.f;
     constexpr int kBlocks = (K3 + 15) / 16;  // 196 blocks of 16 lags t3 per cell
-    for (long item = blockIdx.x; item < (long)A.ncells * kBlocks; item += gridDim.x) {
-        const int cell = (int)(item / kBlocks), blk = (int)(item % kBlocks);
+    const int qch = A.qchunk > 0 ? A.qchunk : 4, nq = (kBlocks + qch - 1) / qch;
+    const long n_items = (long)nq * A.ncells * qch;
+    // work list: qch adjacent blocks of one cell (1 KB of every buffer row), then the same blocks of the NEXT cell: the workgroups
+    // that run together work on different cells, so a cell's running maximum is settled by its first few waves
+    for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int b = (int)(item % qch), cl = (int)((item / qch) % A.ncells), q = (int)(item / ((long)qch * A.ncells));
+        const int blk = q * qch + b;
         const int t0 = 16 * blk + 4 * wave;
-        if (t0 >= K3) continue;
+        if (blk >= kBlocks || t0 >= K3) continue;
+        const int cell = A.cell0 + cl;
+        float *const lbp = A.lb + cell / A.lb_div;
         const int t3 = min(t0 + g, K3 - 1);
-        const uint32_t *base = A.Bw + (size_t)cell * kCellElems;
+        const uint32_t *base = A.Bw + (size_t)cl * kCellElems;
         // ---- A fragments: [component][quad][ins], k1 = 4 mg .. 4 mg + 3 with mg = 4 ins + ks, of (k2 = 4 quad + r, t3)
         uint4 fa[2][3][4];
 #pragma unroll
@@ -323,14 +335,16 @@ __global__ __launch_bounds__(kColsThreads) void k_pfa_cols(ColsArgs A) {
                 fa[0][quad][ins] = make_uint4(l0.x, l0.y, l1.x, l1.y);
                 fa[1][quad][ins] = make_uint4(l0.z, l0.w, l1.z, l1.w);
             }
-        float best = 0.f;
-        for (int nb = 0; nb < NB; ++nb) {
+        // the cell's maximum so far and the PRN's running bound; stale values are lower values: a redundant visit of the exact pass
+        const float lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+        // |y|^2 of output block nb: m2[c][t2] for the lane's (t1, t3); both lanes of a pair hold all twelve
+        auto block = [&](int nb, float (&m2)[2][12]) {
             uint4 fb[4][2];
 #pragma unroll
             for (int ins = 0; ins < 4; ++ins)
 #pragma unroll
                 for (int part = 0; part < 2; ++part) fb[ins][part] = s_coef[((nb * 4 + ins) * 2 + part) * 64 + lane];
-            float m2[2][12];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 f4 acc[3];
@@ -365,9 +379,14 @@ __global__ __launch_bounds__(kColsThreads) void k_pfa_cols(ColsArgs A) {
                     m2[c][t] = sq + sp;
                 }
             }
-            const int o = 16 * nb + (lane & 15), t1 = o >> 1;
-            const bool real_out = t1 < K1 && t0 + (lane >> 4) < K3;
-            if (real_out) {
+        };
+        const int t3o = t0 + (lane >> 4);  // the lag t3 of this lane's outputs
+        float best = 0.f;
+        for (int nb = 0; nb < NB; ++nb) {
+            float m2[2][12];
+            block(nb, m2);
+            const int t1 = (16 * nb + (lane & 15)) >> 1;
+            if (t1 < K1 && t3o < K3) {
 #pragma unroll
                 for (int t = 0; t < 12; ++t) best = fmaxf(best, NC == 2 ? m2[0][t] + m2[1][t] : m2[0][t]);
             }
@@ -378,12 +397,229 @@ __global__ __launch_bounds__(kColsThreads) void k_pfa_cols(ColsArgs A) {
                     for (int t = 0; t < 12; ++t) A.dbg[((c * K1 + t1) * 12 + t) * 4 + (lane >> 4)] = m2[c][t];
             }
         }
-        // Cauchy-Schwarz bound of the wave: (w_d |y_d| + w_p |y_p|)^2 <= (w_d^2 + w_p^2)(|y_d|^2 + |y_p|^2)
-        best *= A.w0sq_plus_w1sq;
+        if (A.stats && lane == 0) atomicAdd(A.stats, 1ull);
+        // Cauchy-Schwarz: (w_d |y_d| + w_p |y_p|)^2 <= (w_d^2 + w_p^2)(|y_d|^2 + |y_p|^2).  If even that bound, over all of the wave's
+        // outputs, stays below both the cell's maximum so far and the sieve threshold of the PRN's running bound, the wave has nothing
+        // to report (bds_acq_wcols.h).  Otherwise the exact values: the outputs are recomputed (they were never all in registers) --
+        const float wsum2 = NC > 1 ? A.w0 * A.w0 + A.w1 * A.w1 : A.w0 * A.w0;
+        const float bw = wave_max_f32(best) * wsum2 * 1.00001f;
+        const float curv = __uint_as_float(cur), lim = fminf(curv, lbv * A.keep);
+        if (!(bw < lim * lim)) {  // (wave-uniform; also taken while the bounds are unset or not finite)
+            if (A.stats && lane == 0) atomicAdd(A.stats + 1, 1ull);
+            // -- each output owned by ONE lane of its pair (even lane: t2 = 0..5, odd lane: t2 = 6..11); a lane keeps its two largest
+            // values with their lags (first lag on ties, like max()).  Two qualifying values in one lane's 42 outputs are the rare case of
+            // the rare case: then a third pass lists exhaustively.
+            const int th = (lane & 1) * 6;
+            float top1 = -1.f, top2 = -1.f;
+            int lag1 = 0x7fffffff, lag2 = 0x7fffffff;
+            for (int nb = 0; nb < NB; ++nb) {
+                float m2[2][12];
+                block(nb, m2);
+                const int t1 = (16 * nb + (lane & 15)) >> 1;
+                if (t1 < K1 && t3o < K3) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
-        if (lane == 0 && __float_as_uint(best) > A.cellbound[cell]) atomicMax(&A.cellbound[cell], __float_as_uint(best));
+                    for (int t = 0; t < 12; ++t) {
+                        if ((t >= 6) != (th == 6)) continue;
+                        float a = A.w0 * __builtin_amdgcn_sqrtf(m2[0][t]);  // raw v_sqrt_f32 (1 ulp): the value only feeds the sieve
+                        if (NC > 1) a += A.w1 * __builtin_amdgcn_sqrtf(m2[NC - 1][t]);
+                        const int lag = (int)lag_of(t1, t, t3o);
+                        if (a > top1 || (a == top1 && lag < lag1)) {
+                            top2 = top1, lag2 = lag1, top1 = a, lag1 = lag;
+                        } else if (a > top2 || (a == top2 && lag < lag2)) {
+                            top2 = a, lag2 = lag;
+                        }
+                    }
+                }
+            }
+            const float Mw = wave_max_f32(top1);
+            if (Mw >= 0.f) {
+                const float thr = fmaxf(Mw, lbv) * A.keep;
+                const bool newmax = __float_as_uint(Mw) >= cur;  // this wave holds (a tie of) the cell's maximum so far
+                const unsigned long long hit1 = __builtin_amdgcn_ballot_w64(top1 >= thr), hit2 = __builtin_amdgcn_ballot_w64(top2 >= thr);
+                if (newmax || hit1) {
+                    if (!hit2) {
+                        const int total = __builtin_popcountll(hit1);
+                        if (total > 0) {  // one reservation per wave on the list's counter
+                            int base_i = 0;
+                            if (lane == 0) base_i = atomicAdd(A.extra_count, total);
+                            base_i = __builtin_amdgcn_readfirstlane(base_i);
+                            if (top1 >= thr) {
+                                const int idx = base_i + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit1, 0u));
+                                if (idx < A.extra_cap) {
+                                    Extra ex;
+                                    ex.v = top1, ex.lag = lag1, ex.cell = cell;
+                                    A.extra[idx] = ex;
+                                }
+                            }
+                        }
+                    } else {
+                        if (A.stats && lane == 0) atomicAdd(A.stats + 2, 1ull);
+                        for (int nb = 0; nb < NB; ++nb) {
+                            float m2[2][12];
+                            block(nb, m2);
+                            const int t1 = (16 * nb + (lane & 15)) >> 1;
+                            const bool mine = t1 < K1 && t3o < K3;
+#pragma unroll
+                            for (int t = 0; t < 12; ++t) {
+                                float a = -1.f;
+                                if (mine && ((t >= 6) == (th == 6))) {
+                                    a = A.w0 * __builtin_amdgcn_sqrtf(m2[0][t]);
+                                    if (NC > 1) a += A.w1 * __builtin_amdgcn_sqrtf(m2[NC - 1][t]);
+                                }
+                                const unsigned long long mask = __builtin_amdgcn_ballot_w64(a >= thr);
+                                if (mask) {  // (wave-uniform)
+                                    int base_i = 0;
+                                    if (lane == 0) base_i = atomicAdd(A.extra_count, __builtin_popcountll(mask));
+                                    base_i = __builtin_amdgcn_readfirstlane(base_i);
+                                    if (a >= thr) {
+                                        const int idx = base_i + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                                        if (idx < A.extra_cap) {
+                                            Extra ex;
+                                            ex.v = a, ex.lag = (int)lag_of(t1, t, t3o), ex.cell = cell;
+                                            A.extra[idx] = ex;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (newmax) {
+                        int bestlag = top1 == Mw ? lag1 : 0x7fffffff;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) bestlag = min(bestlag, __shfl_xor(bestlag, o));
+                        if (lane == 0) {
+                            atomicMax(A.cellmax + cell, wc_pack(Mw, bestlag));
+                            if (Mw > lbv) atomicMax(reinterpret_cast<unsigned *>(lbp), __float_as_uint(Mw));
+                        }
+                    }
+                }
+            }
+        }
     }
+}
+
+// ---- forward transforms: the spectra of the signal (one per call) and of the codes (cached), in the CRT layout ---------------------
+// X[k1, k2, k3] = sum x[n] W_N^(-n k) with n = (n1 N/53 + n2 N/12 + n3 N/3125) mod N: rows over n3 (k_pfa_fwd_rows, the row pass's
+// stages run on conjugates), then 53 points over n1 and 12 over n2 as plain sums (fp32; 1e8 complex products per transform).
+template <class Loader>
+__global__ __launch_bounds__(128) void k_pfa_fwd_rows(Loader ld, float2 *T /* [batch][636][3125] */) {
+    __shared__ float2 region[K3 + 11];
+    const int row = blockIdx.x, batch = blockIdx.y, j = threadIdx.x;
+    const bool live = j < 125;
+    const int jj = live ? j : 124;
+    const long base = ((long)(row / K2) * (NP / K1) + (long)(row % K2) * (NP / K2)) % NP;
+    v2f x[25];
+#pragma unroll
+    for (int q = 0; q < 25; ++q) {
+        const float2 v = ld(batch, (base + (long)(jj + 125 * q) * (NP / K3)) % NP);
+        x[q] = (v2f){v.x, -v.y};  // forward transform = conj(inverse transform of the conjugate)
+    }
+    pk_radix25(x);
+    if (live) {
+#pragma unroll
+        for (int sl = 0; sl < 25; ++sl) {
+            const int p = slot25_index(sl);
+            region[25 * j + p] = to_f2(p ? pk_cmul(x[sl], unit((jj * p) % K3, K3)) : x[sl]);
+        }
+    }
+    __syncthreads();
+    const int si = jj % 25, spg = jj / 25;
+    if (live) {
+#pragma unroll
+        for (int c5 = 0; c5 < 5; ++c5) {
+            v2f z[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) z[r] = to_v2f(region[25 * (si + 25 * r) + 5 * spg + c5]);
+            pk_radix5(z[0], z[1], z[2], z[3], z[4]);
+#pragma unroll
+            for (int u = 0; u < 5; ++u) region[25 * (si + 25 * u) + 5 * spg + c5] = to_f2(u ? pk_cmul(z[u], unit((si * u) % 125, 125)) : z[u]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 25; ++i) x[i] = to_v2f(region[25 * (i + 25 * (jj / 25)) + jj % 25]);
+    pk_radix25(x);
+    if (live) {
+        float2 *o = T + ((size_t)batch * K1 * K2 + row) * K3;
+#pragma unroll
+        for (int sl = 0; sl < 25; ++sl) o[j + 125 * slot25_index(sl)] = make_float2(x[sl].x, -x[sl].y);
+    }
+}
+
+// U[batch][k1][n2][k3] = sum_n1 T[batch][n1][n2][k3] W53^(-n1 k1)
+__global__ __launch_bounds__(256) void k_pfa_fwd_53(const float2 *T, float2 *U) {
+    __shared__ float2 w[K1];
+    if (threadIdx.x < K1) {
+        float sn, cs;
+        sincospif(-2.0f * (float)threadIdx.x / (float)K1, &sn, &cs);
+        w[threadIdx.x] = make_float2(cs, sn);
+    }
+    __syncthreads();
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (n2, k3)
+    const int batch = blockIdx.y;
+    if (e >= (long)K2 * K3) return;
+    const float2 *t = T + (size_t)batch * NP + e;
+    float2 *u = U + (size_t)batch * NP + e;
+    float2 x[K1];
+#pragma unroll
+    for (int n1 = 0; n1 < K1; ++n1) x[n1] = t[(size_t)n1 * K2 * K3];
+    for (int k1 = 0; k1 < K1; ++k1) {
+        float ar = 0.f, ai = 0.f;
+        int idx = 0;
+#pragma unroll
+        for (int n1 = 0; n1 < K1; ++n1) {
+            const float2 ww = w[idx];
+            ar = fmaf(x[n1].x, ww.x, fmaf(-x[n1].y, ww.y, ar));
+            ai = fmaf(x[n1].x, ww.y, fmaf(x[n1].y, ww.x, ai));
+            idx += k1;
+            idx -= idx >= K1 ? K1 : 0;
+        }
+        u[(size_t)k1 * K2 * K3] = make_float2(ar, ai);
+    }
+}
+
+// 12 points over n2, then the stored form: value * scale (conjugated for the code spectra) as fp16 complex;
+// doubled = 1: signal spectrum, rows [k1][k2][2 x 3125]; 0: code spectra [batch][k1][k2][3125] from dst
+__global__ __launch_bounds__(256) void k_pfa_fwd_12(const float2 *U, uint32_t *dst, long dst_batch_stride, int conj_flag, float scale, int doubled) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (k1, k3)
+    const int batch = blockIdx.y;
+    if (e >= (long)K1 * K3) return;
+    const int k1 = (int)(e / K3), k3 = (int)(e % K3);
+    const float2 *u = U + (size_t)batch * NP + (size_t)k1 * K2 * K3 + k3;
+    float2 x[K2];
+#pragma unroll
+    for (int n2 = 0; n2 < K2; ++n2) x[n2] = u[(size_t)n2 * K3];
+    constexpr float c[12] = {1.f, 0.86602540378443865f, 0.5f, 0.f, -0.5f, -0.86602540378443865f, -1.f, -0.86602540378443865f, -0.5f, 0.f, 0.5f, 0.86602540378443865f};
+    constexpr float sn[12] = {0.f, 0.5f, 0.86602540378443865f, 1.f, 0.86602540378443865f, 0.5f, 0.f, -0.5f, -0.86602540378443865f, -1.f, -0.86602540378443865f, -0.5f};
+    uint32_t *d = dst + (size_t)batch * dst_batch_stride;
+#pragma unroll
+    for (int k2 = 0; k2 < K2; ++k2) {
+        float ar = 0.f, ai = 0.f;
+#pragma unroll
+        for (int n2 = 0; n2 < K2; ++n2) {  // W12^(-n2 k2) = (c, -sn)[(n2 k2) mod 12]
+            const float wr = c[(n2 * k2) % 12], wi = -sn[(n2 * k2) % 12];
+            ar = fmaf(x[n2].x, wr, fmaf(-x[n2].y, wi, ar));
+            ai = fmaf(x[n2].x, wi, fmaf(x[n2].y, wr, ai));
+        }
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const v2f val = (v2f){ar * scale, (conj_flag ? -ai : ai) * scale};
+        const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(val, h2));
+        if (doubled) {
+            d[((size_t)k1 * K2 + k2) * (2 * K3) + k3] = pk;
+            d[((size_t)k1 * K2 + k2) * (2 * K3) + K3 + k3] = pk;
+        } else {
+            d[((size_t)k1 * K2 + k2) * K3 + k3] = pk;
+        }
+    }
+}
+
+// nb transforms: tmp holds 2 x nb x NP float2
+template <class Loader>
+inline void forward(hipStream_t st, Loader ld, int nb, float2 *tmp, uint32_t *dst, long dst_batch_stride, int conj_flag, float scale, int doubled) {
+    float2 *T = tmp, *U = tmp + (size_t)nb * NP;
+    hipLaunchKernelGGL(k_pfa_fwd_rows<Loader>, dim3(K1 * K2, nb), dim3(128), 0, st, ld, T);
+    hipLaunchKernelGGL(k_pfa_fwd_53, dim3((K2 * K3 + 255) / 256, nb), dim3(256), 0, st, (const float2 *)T, U);
+    hipLaunchKernelGGL(k_pfa_fwd_12, dim3((K1 * K3 + 255) / 256, nb), dim3(256), 0, st, (const float2 *)U, dst, dst_batch_stride, conj_flag, scale, doubled);
 }
 
 }  // namespace pfa

@@ -76,6 +76,9 @@ Tuning tuning_from_env() {
     t.ilv = geti("BDS_ACQ_ILV", 1);
     t.pk = geti("BDS_ACQ_PK", 1);
     t.small_plan = geti("BDS_ACQ_SMALL", 1);
+    t.pfa = geti("BDS_ACQ_PFA", 1);
+    t.pfa_qchunk = std::max(0, geti("BDS_ACQ_PFA_QCHUNK", 0));
+    t.pfa_cgrid = std::max(0, geti("BDS_ACQ_PFA_CGRID", 0));
     t.host_refine = has("BDS_ACQ_HOSTREFINE");
     t.neigh = std::max(0, std::min(4, geti("BDS_ACQ_NEIGH", 0)));
     t.wcols_qchunk = std::max(0, geti("BDS_ACQ_WCOLS_QCHUNK", 0));

@@ -52,6 +52,10 @@ struct Tuning {
     int wcols = -1;                  // BDS_ACQ_WCOLS: wave-private column pass (bds_acq_wcols.h); -1 = default on, 0 = the round-2 tile kernel
     int clockprobe = 0;              // BDS_ACQ_CLOCKPROBE: sampled workgroups of the wave-private search kernels time themselves (bds_timing::shader_clock_GHz)
     int wrows = -1;                  // BDS_ACQ_WROWS: wave-private 4096-point row pass (bds_acq_wrows.h); -1 = default on, 0 = k_rows_inv_f
+    int pfa = 1;                     // BDS_ACQ_PFA (hooks): the N-point search pair of bds_acq_pfa.h where it applies (B1C, N = 53 x 12 x 3125, fp16 storage,
+                                     // whole bins per acqStep); 0 = the L-point pair of rounds 3-5 everywhere
+    int pfa_qchunk = 0;              // BDS_ACQ_PFA_QCHUNK (hooks): blocks of 16 lags of a cell that follow each other in the N-point column pass's work list
+    int pfa_cgrid = 0;               // BDS_ACQ_PFA_CGRID (hooks): workgroups of the N-point column pass
     int small_plan = 1;              // BDS_ACQ_SMALL: small two-component searches on the 80 x 4096 plan (bds_acq_scols.h); 0 = 256 x 1280 as in rounds 1-3
     bool host_refine = false;        // BDS_ACQ_HOSTREFINE: refinement through the host (lists downloaded, jobs built there: rounds 1-4) instead of the device chain
     int neigh = 0;                   // BDS_ACQ_NEIGH: also refine the +-n bin / lag neighbours of every candidate in f64 (rounds 1-3: 1)

@@ -422,8 +422,8 @@ def strict_f32_leg(local_rank, s, x, n_cells_samples, ncomp, n_circ):
             "note": "fp32 storage AND arithmetic end to end (one extra call); the headline stores spectra and the inter-pass buffer as fp16 complex"}
 
 
-ROWS_KERNEL = {0: "k_rows_inv (run-time plan)", 1: "k_rows_inv_f", 2: "k_rows_wave_f"}
-COLS_KERNEL = {0: "k_cols_inv_max (run-time plan)", 1: "k_cols_inv_max_f (tile)", 2: "k_cols_wave_f", 3: "k_cols_small_f"}
+ROWS_KERNEL = {0: "k_rows_inv (run-time plan)", 1: "k_rows_inv_f", 2: "k_rows_wave_f", 3: "k_pfa_rows"}
+COLS_KERNEL = {0: "k_cols_inv_max (run-time plan)", 1: "k_cols_inv_max_f (tile)", 2: "k_cols_wave_f", 3: "k_cols_small_f", 4: "k_pfa_cols"}
 
 
 def kernel_label(tm):

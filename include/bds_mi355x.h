@@ -141,8 +141,8 @@ typedef struct bds_timing {
     double shader_clock_GHz; /* engine clock the search kernels ran at (sampled workgroups time themselves with the shader
                                 clock against the reference clock); 0 unless BDS_ACQ_CLOCKPROBE=1              */
     int32_t plan_l1, plan_l2; /* two-pass factorisation of fft_len: column length x row length                          */
-    int32_t rows_kernel;    /* row pass of the search: 0 run-time plan (k_rows_inv), 1 k_rows_inv_f, 2 k_rows_wave_f      */
-    int32_t cols_kernel;    /* column pass: 0 run-time plan (k_cols_inv_max), 1 tile kernel k_cols_inv_max_f, 2 k_cols_wave_f, 3 k_cols_small_f */
+    int32_t rows_kernel;    /* row pass of the search: 0 run-time plan (k_rows_inv), 1 k_rows_inv_f, 2 k_rows_wave_f, 3 k_pfa_rows (N-point pair) */
+    int32_t cols_kernel;    /* column pass: 0 run-time plan (k_cols_inv_max), 1 tile kernel k_cols_inv_max_f, 2 k_cols_wave_f, 3 k_cols_small_f, 4 k_pfa_cols */
     int32_t kernel_flags;   /* bit 0: components interleaved in the inter-pass buffer; bit 1: packed-fp32 butterflies     */
     int32_t refine_path;     /* 1: candidates -> f64 sums -> peak / second peak / fine search as one device chain with a single download (csrc/bds_acq_refine.h); 0: through the host */
 } bds_timing;

@@ -9,6 +9,7 @@
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -31,7 +32,62 @@ static float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
 static uint32_t pack(float re, float im) { return (uint32_t)f2h(re) | ((uint32_t)f2h(im) << 16); }
 static cd unpack(uint32_t u) { return cd(h2f((uint16_t)(u & 0xffff)), h2f((uint16_t)(u >> 16))); }
 
+struct ArrayLoader {  // the forward kernels' input: x[n] of transform `batch`
+    const float2 *x;
+    __device__ __forceinline__ float2 operator()(int batch, long n) const { return x[(size_t)batch * NP + n]; }
+};
+
+static void check_forward() {
+    std::mt19937_64 rng(11);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    const int nb = 2;
+    std::vector<float2> x((size_t)nb * NP);
+    for (auto &v : x) v = make_float2(std::round(20.f * nd(rng)), std::round(3.f * nd(rng)));
+    float2 *d_x, *d_tmp;
+    uint32_t *d_sig, *d_code;
+    CK(hipMalloc(&d_x, x.size() * sizeof(float2)));
+    CK(hipMalloc(&d_tmp, (size_t)2 * nb * NP * sizeof(float2)));
+    CK(hipMalloc(&d_sig, (size_t)2 * NP * 4));
+    CK(hipMalloc(&d_code, (size_t)nb * NP * 4));
+    CK(hipMemcpy(d_x, x.data(), x.size() * sizeof(float2), hipMemcpyHostToDevice));
+    const float sc = 1.0f / 65536.f;
+    forward(0, ArrayLoader{d_x}, 1, d_tmp, d_sig, 0, 0, sc, 1);
+    forward(0, ArrayLoader{d_x}, nb, d_tmp, d_code, NP, 1, sc, 0);
+    CK(hipDeviceSynchronize());
+    std::vector<uint32_t> sig((size_t)2 * NP), code((size_t)nb * NP);
+    CK(hipMemcpy(sig.data(), d_sig, sig.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(code.data(), d_code, code.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0, rms = 0;
+    int n = 0;
+    std::uniform_int_distribution<long> uk(0, NP - 1);
+    for (int trial = 0; trial < 12; ++trial) {
+        const long k = trial == 0 ? 0 : trial == 1 ? NP - 1 : uk(rng);
+        const int k1 = k % K1, k2 = k % K2, k3 = k % K3;
+        for (int b = 0; b < nb; ++b) {
+            cd ref = 0;
+            for (long m = 0; m < NP; ++m) {
+                const __int128 ph = ((__int128)m * k) % NP;
+                ref += cd(x[(size_t)b * NP + m].x, x[(size_t)b * NP + m].y) * std::polar(1.0, -2 * M_PI * (double)(long)ph / NP);
+            }
+            ref *= sc;
+            const cd gc = unpack(code[(size_t)b * NP + ((size_t)k1 * K2 + k2) * K3 + k3]);
+            worst = std::max(worst, std::abs(gc - std::conj(ref)));
+            if (b == 0) {
+                const cd g0 = unpack(sig[((size_t)k1 * K2 + k2) * 2 * K3 + k3]), g1 = unpack(sig[((size_t)k1 * K2 + k2) * 2 * K3 + K3 + k3]);
+                worst = std::max(worst, std::max(std::abs(g0 - ref), std::abs(g1 - ref)));
+            }
+            rms += std::norm(ref), ++n;
+        }
+    }
+    printf("forward transforms (CRT layout, fp16 storage): worst |error| %.3g against an rms value of %.3g (%.2e)\n", worst, std::sqrt(rms / n), worst / std::sqrt(rms / n));
+    CK(hipFree(d_x));
+    CK(hipFree(d_tmp));
+    CK(hipFree(d_sig));
+    CK(hipFree(d_code));
+}
+
 int main(int argc, char **argv) {
+    check_forward();
     const int prns = argc > 1 ? atoi(argv[1]) : 4, reps = argc > 2 ? atoi(argv[2]) : 3, D = 201;
     const int nslots = std::max(prns, 2);
     std::mt19937_64 rng(7);
@@ -57,15 +113,22 @@ int main(int argc, char **argv) {
     int *d_bin;
     long *d_cs;
     uint4 *d_coef;
-    unsigned *d_bound;
-    float *d_dbg;
+    unsigned long long *d_cellmax, *d_stats;
+    float *d_lb, *d_dbg;
+    bds::Extra *d_extra;
+    int *d_extra_count;
+    const int extra_cap = 1 << 22;
     CK(hipMalloc(&d_Xs, Xs.size() * 4));
     CK(hipMalloc(&d_Cs, Cs.size() * 4));
     CK(hipMalloc(&d_Bw, (size_t)std::max(ncells, ncell_t) * kCellElems * 4));
     CK(hipMalloc(&d_bin, h_bin.size() * sizeof(int)));
     CK(hipMalloc(&d_cs, h_cs.size() * sizeof(long)));
     CK(hipMalloc(&d_coef, kCoefBytes));
-    CK(hipMalloc(&d_bound, h_bin.size() * sizeof(unsigned)));
+    CK(hipMalloc(&d_cellmax, h_bin.size() * sizeof(unsigned long long)));
+    CK(hipMalloc(&d_lb, h_bin.size() * sizeof(float)));
+    CK(hipMalloc(&d_stats, 4 * sizeof(unsigned long long)));
+    CK(hipMalloc(&d_extra, sizeof(bds::Extra) * extra_cap));
+    CK(hipMalloc(&d_extra_count, sizeof(int)));
     CK(hipMalloc(&d_dbg, sizeof(float) * 2 * K1 * 12 * 4));
     CK(hipMemcpy(d_Xs, Xs.data(), Xs.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_Cs, Cs.data(), Cs.size() * 4, hipMemcpyHostToDevice));
@@ -83,7 +146,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(d_bin, h_bin.data(), ncell_t * sizeof(int), hipMemcpyHostToDevice));
     CK(hipMemcpy(d_cs, h_cs.data(), ncell_t * sizeof(long), hipMemcpyHostToDevice));
     CK(hipMemset(d_Bw, 0xff, (size_t)ncell_t * kCellElems * 4));  // NaN pattern: every element must be written
-    RowsArgs ra{d_Xs, d_Cs, d_Bw, d_bin, d_cs, ncell_t, 1, 2};
+    RowsArgs ra{d_Xs, d_Cs, d_Bw, d_bin, d_cs, ncell_t, 1, 1};
     hipLaunchKernelGGL(k_pfa_rows<2>, dim3(MP * K2 * ncell_t), dim3(kRowsThreads), rows_lds, 0, ra);
     CK(hipDeviceSynchronize());
     std::vector<uint32_t> Bw((size_t)ncell_t * kCellElems);
@@ -120,9 +183,11 @@ int main(int argc, char **argv) {
     double worst_cols = 0, worst_e2e = 0, big = 0;
     for (int cell : {0, 3, 5})
         for (int grp : {0, 311, 781}) {
-            CK(hipMemset(d_bound, 0, ncell_t * sizeof(unsigned)));
+            CK(hipMemset(d_cellmax, 0, ncell_t * sizeof(unsigned long long)));
+            CK(hipMemset(d_lb, 0, ncell_t * sizeof(float)));
+            CK(hipMemset(d_extra_count, 0, sizeof(int)));
             CK(hipMemset(d_dbg, 0, sizeof(float) * 2 * K1 * 12 * 4));
-            ColsArgs ca{d_Bw, d_coef, ncell_t, 1.0f, d_bound, d_dbg, cell, grp};
+            ColsArgs ca{d_Bw, d_coef, ncell_t, 0.52440442f, 0.85146932f, d_cellmax, d_lb, 1, d_extra, d_extra_count, extra_cap, 0, 0.996f, 4, nullptr, d_dbg, cell, grp};
             hipLaunchKernelGGL((k_pfa_cols<2, true>), dim3(512), dim3(kColsThreads), kCoefBytes, 0, ca);
             CK(hipDeviceSynchronize());
             std::vector<float> dbg(2 * K1 * 12 * 4);
@@ -161,6 +226,61 @@ int main(int argc, char **argv) {
                 }
             }
         }
+    {   // the sieve's outputs of the last of those launches against a float64 evaluation of two whole cells from the same buffer
+        std::vector<unsigned long long> cm(ncell_t);
+        int n_ex = 0;
+        CK(hipMemcpy(cm.data(), d_cellmax, ncell_t * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&n_ex, d_extra_count, sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<bds::Extra> ex(std::min(n_ex, extra_cap));
+        CK(hipMemcpy(ex.data(), d_extra, ex.size() * sizeof(bds::Extra), hipMemcpyDeviceToHost));
+        const double w0 = 0.52440442, w1 = 0.85146932, keep = 0.996;
+        std::vector<cd> W53(K1), W12(K2);
+        for (int i = 0; i < K1; ++i) W53[i] = std::polar(1.0, 2 * M_PI * i / K1);
+        for (int i = 0; i < K2; ++i) W12[i] = std::polar(1.0, 2 * M_PI * i / K2);
+        for (int cell : {1, 4}) {
+            std::vector<double> val(NP);
+            double M = -1;
+            long argM = -1;
+            std::vector<cd> z((size_t)2 * K1 * K2), u((size_t)2 * K1 * K2);
+            for (int t3 = 0; t3 < K3; ++t3) {
+                for (int comp = 0; comp < 2; ++comp)
+                    for (int k1 = 0; k1 < K1; ++k1)
+                        for (int k2 = 0; k2 < K2; ++k2)
+                            z[((size_t)comp * K1 + k1) * K2 + k2] = unpack(Bw[(size_t)cell * kCellElems + ((((size_t)(k1 / 2) * K2 + k2) * K3 + t3) * 2 + comp) * 2 + (k1 & 1)]);
+                for (int comp = 0; comp < 2; ++comp)  // 53 points over k1
+                    for (int t1 = 0; t1 < K1; ++t1)
+                        for (int k2 = 0; k2 < K2; ++k2) {
+                            cd a = 0;
+                            for (int k1 = 0; k1 < K1; ++k1) a += z[((size_t)comp * K1 + k1) * K2 + k2] * W53[(k1 * t1) % K1];
+                            u[((size_t)comp * K1 + t1) * K2 + k2] = a;
+                        }
+                for (int t1 = 0; t1 < K1; ++t1)
+                    for (int t2 = 0; t2 < K2; ++t2) {
+                        cd yd = 0, yp = 0;
+                        for (int k2 = 0; k2 < K2; ++k2) yd += u[((size_t)0 * K1 + t1) * K2 + k2] * W12[(k2 * t2) % K2], yp += u[((size_t)1 * K1 + t1) * K2 + k2] * W12[(k2 * t2) % K2];
+                        const double v = w0 * std::abs(yd) + w1 * std::abs(yp);
+                        const long t = lag_of(t1, t2, t3);
+                        val[t] = v;
+                        if (v > M || (v == M && t < argM)) M = v, argM = t;
+                    }
+            }
+            float gv;
+            { const unsigned gb = (unsigned)(cm[cell] >> 32); memcpy(&gv, &gb, 4); }
+            const long glag = (long)(~(unsigned)(cm[cell] & 0xffffffffu));
+            long want = 0, found = 0;
+            for (long t = 0; t < NP; ++t)
+                if (val[t] >= M * (keep + 2e-6)) {  // (the kernel's fp32 values are ~1e-6 from these)
+                    ++want;
+                    for (const auto &e : ex)
+                        if (e.cell == cell && e.lag == t) {
+                            ++found;
+                            break;
+                        }
+                }
+            printf("sieve protocol, cell %d: maximum %.6g at lag %ld (float64 of the same buffer: %.6g at %ld; value error %.1e); %ld lags within the tolerance of it, %ld of them on the list (%d entries in all)\n",
+                   cell, gv, glag, M, argM, std::fabs(gv - M) / M, want, found, n_ex);
+        }
+    }
     printf("column pass: worst error of |y|^2 against a float64 53 x 12 transform of the SAME buffer: %.3g of the largest (%.3g)\n", worst_cols / big, big);
     printf("pair, end to end: worst relative error of |y| against the N-point sum in natural order (index maps, rotation, fp16 storage): %.2e\n", worst_e2e);
 
@@ -174,13 +294,18 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&e1));
     CK(hipEventCreate(&e2));
     for (int gc : {201, 67}) {
-        RowsArgs rt{d_Xs, d_Cs, d_Bw, d_bin, d_cs, ncells, gc, 2};
+        RowsArgs rt{d_Xs, d_Cs, d_Bw, d_bin, d_cs, ncells, gc, 1};
         const int chunks = (ncells + gc - 1) / gc;
-        for (int cgrid : {2048, 4096}) {
+        for (int cgrid : {2048, 4096})
+        for (int qch : {4, 196}) {
             float best_r = 1e9f, best_c = 1e9f;
-            for (int rep = 0; rep < reps; ++rep) {
-                CK(hipMemset(d_bound, 0, ncells * sizeof(unsigned)));
-                ColsArgs ct{d_Bw, d_coef, ncells, 1.0f, d_bound, nullptr, -1, -1};
+            for (int rep = 0; rep <= reps; ++rep) {  // the last repetition counts the passes (one atomic per wave item: not timed)
+                const bool counting = rep == reps;
+                CK(hipMemset(d_cellmax, 0, ncells * sizeof(unsigned long long)));
+                CK(hipMemset(d_lb, 0, ncells * sizeof(float)));
+                CK(hipMemset(d_extra_count, 0, sizeof(int)));
+                CK(hipMemset(d_stats, 0, 4 * sizeof(unsigned long long)));
+                ColsArgs ct{d_Bw, d_coef, ncells, 0.52440442f, 0.85146932f, d_cellmax, d_lb, D, d_extra, d_extra_count, extra_cap, 0, 0.996f, qch, counting ? d_stats : nullptr, nullptr, -1, -1};
                 CK(hipEventRecord(e0));
                 hipLaunchKernelGGL(k_pfa_rows<2>, dim3(MP * K2 * chunks), dim3(kRowsThreads), rows_lds, 0, rt);
                 CK(hipEventRecord(e1));
@@ -190,10 +315,15 @@ int main(int argc, char **argv) {
                 float mr, mc;
                 CK(hipEventElapsedTime(&mr, e0, e1));
                 CK(hipEventElapsedTime(&mc, e1, e2));
-                best_r = std::min(best_r, mr), best_c = std::min(best_c, mc);
+                if (!counting) best_r = std::min(best_r, mr), best_c = std::min(best_c, mc);
             }
-            printf("timing: %d PRNs x %d bins, %d-cell row workgroups, column grid %d: rows %.3f ms + columns %.3f ms per 201 cells = %.3f ms  (L-point pair of round 5: 3.0 - 3.1 ms)\n",
-                   prns, D, gc, cgrid, best_r / prns, best_c / prns, (best_r + best_c) / prns);
+            unsigned long long st[4];
+            int n_ex = 0;
+            CK(hipMemcpy(st, d_stats, sizeof(st), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(&n_ex, d_extra_count, sizeof(int), hipMemcpyDeviceToHost));
+            printf("timing: %d PRNs x %d bins, %d-cell row workgroups, column grid %d, %d-block chunks: rows %.3f ms + columns %.3f ms per 201 cells = %.3f ms  (L-point pair of round 5: 3.0 - 3.1 ms); "
+                   "%llu wave items, %llu through the exact pass (%.2f %%), %llu exhaustive, %d list entries\n",
+                   prns, D, gc, cgrid, qch, best_r / prns, best_c / prns, (best_r + best_c) / prns, st[0], st[1], 100.0 * st[1] / std::max(1ull, st[0]), st[2], n_ex);
         }
     }
     return 0;
