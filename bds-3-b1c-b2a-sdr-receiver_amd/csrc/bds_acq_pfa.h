@@ -29,6 +29,12 @@
 
 #include "bds_acq_wcols.h"  // Extra, wc_pack, wave_max_f32; bds_fft_pk.h
 
+#ifdef PFA_EXP_R_NOBAR
+#define PFA_RSYNC() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define PFA_RSYNC() __syncthreads()
+#endif
+
 namespace bds {
 namespace pfa {
 
@@ -148,8 +154,13 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
         const int k1s = ((k1c - s) % K1 + K1) % K1, k2s = ((k2 - s) % K2 + K2) % K2, o3 = (K3 - s % K3) % K3;
         const uint32_t *xrow = A.Xs + ((size_t)k1s * K2 + k2s) * (2 * K3) + o3 + jj;
         uint32_t xn[25];
+#ifdef PFA_EXP_R_NOLOAD
+#pragma unroll
+        for (int q = 0; q < 25; ++q) xn[q] = 0x3c003800u + q + cell + (uint32_t)(size_t)xrow;
+#else
 #pragma unroll
         for (int q = 0; q < 25; ++q) xn[q] = xrow[125 * q];
+#endif
         uint32_t outp[NC][25];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
             }
             // stage 1: 25 points over q (k3 = j + 125 q) -> p, twiddle W3125^(j p), a[j][p] at 25 j + p
             pk_radix25(x);
-            if (c > 0) __syncthreads();  // the previous component's stage-3 reads of the region are done
+            if (c > 0) PFA_RSYNC();  // the previous component's stage-3 reads of the region are done
             if (live) {
 #pragma unroll
                 for (int sl = 0; sl < 25; ++sl) {
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
                     region[25 * j + p] = to_f2(v);
                 }
             }
-            __syncthreads();
+            PFA_RSYNC();
             // stage 2: thread (i, pg): for c5 = 0..4: 5 points over r of a[i + 25 r][5 pg + c5] -> u, twiddle W125^(i u), in place
             if (live) {
 #pragma unroll
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
                     }
                 }
             }
-            __syncthreads();
+            PFA_RSYNC();
             // stage 3: thread t' = p + 25 u: 25 points over i of b[p][i][u] at 25 (i + 25 u) + p -> t'': X[t' + 125 t'']
             {
                 const int p3 = jj % 25, u3 = jj / 25;
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
                 *reinterpret_cast<uint4 *>(dst + (size_t)t3 * 4) = make_uint4(P[0], Q[0], P[1], Q[1]);
             }
         }
-        __syncthreads();  // region free for the next cell
+        PFA_RSYNC();  // region free for the next cell
     }
 }
 
@@ -350,6 +361,10 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                 f4 acc[3];
 #pragma unroll
                 for (int quad = 0; quad < 3; ++quad) acc[quad] = (f4){0.f, 0.f, 0.f, 0.f};
+#ifdef PFA_EXP_C_NOMFMA  // (timing experiments, tools/exp/r6_pfa_parts.sh: results INVALID)
+#pragma unroll
+                for (int quad = 0; quad < 3; ++quad) acc[quad] = (f4){__uint_as_float(fa[c][quad][0].x), __uint_as_float(fb[1][0].y), __uint_as_float(fa[c][quad][2].z), __uint_as_float(fb[3][1].w)};
+#else
 #pragma unroll
                 for (int ins = 0; ins < 4; ++ins)
 #pragma unroll
@@ -358,6 +373,12 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                         for (int quad = 0; quad < 3; ++quad)
                             acc[quad] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, fa[c][quad][ins]), __builtin_bit_cast(h8, fb[ins][part]),
                                                                                acc[quad], 0, 0, 0);
+#endif
+#ifdef PFA_EXP_C_NOEPI
+#pragma unroll
+                for (int t = 0; t < 12; ++t) m2[c][t] = acc[t >> 2][t & 3];
+                continue;
+#endif
                 // lane (G = lane >> 4, o = lane & 15): acc[quad][rr] = row 4 G + rr <-> (t3 = t0 + G, k2 = 4 quad + rr) of output 16 nb + o
                 float v[12], P[7], Q[7];
 #pragma unroll
@@ -445,7 +466,7 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                             base_i = __builtin_amdgcn_readfirstlane(base_i);
                             if (top1 >= thr) {
                                 const int idx = base_i + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit1, 0u));
-                                if (idx < A.extra_cap) {
+                                if ((unsigned)idx < (unsigned)A.extra_cap) {  // (unsigned: a counter run over 2^31 must not index backwards)
                                     Extra ex;
                                     ex.v = top1, ex.lag = lag1, ex.cell = cell;
                                     A.extra[idx] = ex;
@@ -473,7 +494,7 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                                     base_i = __builtin_amdgcn_readfirstlane(base_i);
                                     if (a >= thr) {
                                         const int idx = base_i + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                                        if (idx < A.extra_cap) {
+                                        if ((unsigned)idx < (unsigned)A.extra_cap) {  // (unsigned: a counter run over 2^31 must not index backwards)
                                             Extra ex;
                                             ex.v = a, ex.lag = (int)lag_of(t1, t, t3o), ex.cell = cell;
                                             A.extra[idx] = ex;

@@ -74,7 +74,7 @@ def test_joint_workload_at_full_size_is_bit_equal_to_the_single_signal_runs():
     b1c = run_bench(["--workload", "b1c"] + FAST)
     # (the default B1C run also times cfg2 -- extra key `b2a` -- and labels its kernels from the plan)
     assert b1c["b2a"]["ms_per_step"] > 0 and b1c["b2a"]["satellites_detected"] == b1c["b2a"]["satellites_injected"]
-    assert "k_cols_small_f<80>" in b1c["b2a"]["kernel"] and "k_cols_wave_f<768>" in b1c["roofline"]["kernel"]
+    assert "k_cols_small_f<80>" in b1c["b2a"]["kernel"] and "k_pfa_cols<636>" in b1c["roofline"]["kernel"]
     for k in ("frac_strict_f32", "frac_at_stored_bytes", "traffic_source"):
         assert k in b1c["roofline"], k
     b2a = run_bench(["--workload", "b2a"] + FAST)

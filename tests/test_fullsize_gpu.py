@@ -314,11 +314,19 @@ def test_b1c_wideband_tracking_full_rate(ctx):
         np.testing.assert_allclose(g.codeFreq, r.codeFreq, rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("env", [{"BDS_ACQ_PK": "0"}, {"BDS_ACQ_PK": "2"}, {"BDS_ACQ_ILV": "0"}, {"BDS_ACQ_PK": "0", "BDS_ACQ_ILV": "0"},
-                                 {"BDS_ACQ_NEIGH": "1"}, {"BDS_ACQ_WROWS": "0"}, {"BDS_ACQ_WCOLS": "0"}, {"BDS_ACQ_HOSTREFINE": "1"},
-                                 {"BDS_ACQ_PAIR_GB": "auto"}, {"BDS_ACQ_PAIR_GB": "11"}, {"BDS_ACQ_PAIR_GB": "auto", "BDS_ACQ_WCOLS": "0"}])
+_L = {"BDS_ACQ_PFA": "0"}  # the L-point pair of rounds 3-5 (768 x 4096) instead of the N-point pair (round 6: the default at cfg3)
+
+
+@pytest.mark.parametrize("env", [_L, {**_L, "BDS_ACQ_PK": "0"}, {**_L, "BDS_ACQ_PK": "2"}, {**_L, "BDS_ACQ_ILV": "0"}, {**_L, "BDS_ACQ_PK": "0", "BDS_ACQ_ILV": "0"},
+                                 {**_L, "BDS_ACQ_NEIGH": "1"}, {**_L, "BDS_ACQ_WROWS": "0"}, {**_L, "BDS_ACQ_WCOLS": "0"}, {**_L, "BDS_ACQ_HOSTREFINE": "1"},
+                                 {**_L, "BDS_ACQ_PAIR_GB": "auto"}, {**_L, "BDS_ACQ_PAIR_GB": "11"}, {**_L, "BDS_ACQ_PAIR_GB": "auto", "BDS_ACQ_WCOLS": "0"},
+                                 {"BDS_ACQ_HOSTREFINE": "1"}, {"BDS_ACQ_NEIGH": "1"}, {"BDS_ACQ_PAIR_GB": "auto"}, {"BDS_ACQ_PAIR_GB": "11"},
+                                 {"BDS_ACQ_PFA_QCHUNK": "196"}, {"BDS_ACQ_PFA_CGRID": "1024"}])
 def test_cfg3_kernel_variants_decide_the_same(env, monkeypatch):
-    """The switches of the round-4 search kernels at the cfg3 plan (768 x 4096): plain-fp32 instead of packed butterflies (both
+    """The default at cfg3 is the N-point pair (csrc/bds_acq_pfa.h, round 6); BDS_ACQ_PFA=0 selects the L-point pair of rounds 3-5, whose
+    own switches follow.  The N-point pair's variants: the refinement through the host, the +-1 neighbours, the serving mode / 11 GiB,
+    a cell-major work list of its column pass, a quarter of its grid.
+    The switches of the round-4 search kernels at the cfg3 plan (768 x 4096): plain-fp32 instead of packed butterflies (both
     passes / column pass only), component planes instead of interleaved components, the +-1 neighbours of rounds 1-3 refined
     as well, the round-2 row / column kernels, the refinement through the host (rounds 1-4) instead of the device chain of
     round 5 (csrc/bds_acq_refine.h), the serving mode of the search (BDS_ACQ_PAIR_GB, a release knob: all four PRNs' Doppler rows in
@@ -346,6 +354,10 @@ def test_cfg3_kernel_variants_decide_the_same(env, monkeypatch):
         assert np.array_equal(u, v)
     np.testing.assert_allclose(g1, g0, rtol=2e-3)
     assert flags0 == 3  # default: interleaved components + packed butterflies
+    if "BDS_ACQ_PFA" in env:
+        assert tm["fft_len"] == 3145728 and tm["rows_kernel"] in (1, 2) and tm["cols_kernel"] in (1, 2)
+    else:
+        assert (tm["rows_kernel"], tm["cols_kernel"], tm["fft_len"]) == (3, 4, 1987500)
     if "BDS_ACQ_PAIR_GB" in env:
         assert tm["n_pairs"] == (1 if env["BDS_ACQ_PAIR_GB"] == "auto" else 2) and tm["cells_per_pair"] == 201 * 4 / tm["n_pairs"]
     else:
