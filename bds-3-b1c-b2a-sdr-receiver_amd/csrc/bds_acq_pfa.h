@@ -27,7 +27,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
-#include "bds_acq_wcols.h"  // Extra, wc_pack, wave_max_f32; bds_fft_pk.h
+#include "bds_acq_wcols.h"  // Extra, wc_pack, wave_max_f32; bds_fft_pk.h, bds_lds.h
 
 #ifdef PFA_EXP_R_NOBAR
 #define PFA_RSYNC() __builtin_amdgcn_s_waitcnt(0)
@@ -102,6 +102,33 @@ __device__ __forceinline__ v2f unit(int num, int den) {  // exp(+2 pi j num / de
     return (v2f){cs, sn};
 }
 
+// LDS reads of the row pass as single ds_read_b64 (bds_lds.h: the ds_read2_b64 the compiler fuses two reads into is served in groups of
+// 16 lanes at half the rate): y[k] = *(a + BASE + k STEP), byte offsets, one wait per batch
+template <int BASE, int STEP>
+__device__ __forceinline__ void lds_read5(v2f (&y)[5], unsigned a) {
+    asm volatile(
+        "ds_read_b64 %0, %5 offset:%6\n ds_read_b64 %1, %5 offset:%6+%7\n ds_read_b64 %2, %5 offset:%6+2*%7\n ds_read_b64 %3, %5 offset:%6+3*%7\n"
+        "ds_read_b64 %4, %5 offset:%6+4*%7\n s_waitcnt lgkmcnt(0)"
+        : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(y[4])
+        : "v"(a), "n"(BASE), "n"(STEP)
+        : "memory");
+}
+template <int STEP>
+__device__ __forceinline__ void lds_read25(v2f (&y)[25], unsigned a) {
+    asm volatile(
+        "ds_read_b64 %0, %25\n ds_read_b64 %1, %25 offset:%26\n ds_read_b64 %2, %25 offset:2*%26\n ds_read_b64 %3, %25 offset:3*%26\n ds_read_b64 %4, %25 offset:4*%26\n"
+        "ds_read_b64 %5, %25 offset:5*%26\n ds_read_b64 %6, %25 offset:6*%26\n ds_read_b64 %7, %25 offset:7*%26\n ds_read_b64 %8, %25 offset:8*%26\n ds_read_b64 %9, %25 offset:9*%26\n"
+        "ds_read_b64 %10, %25 offset:10*%26\n ds_read_b64 %11, %25 offset:11*%26\n ds_read_b64 %12, %25 offset:12*%26\n ds_read_b64 %13, %25 offset:13*%26\n ds_read_b64 %14, %25 offset:14*%26\n"
+        "ds_read_b64 %15, %25 offset:15*%26\n ds_read_b64 %16, %25 offset:16*%26\n ds_read_b64 %17, %25 offset:17*%26\n ds_read_b64 %18, %25 offset:18*%26\n ds_read_b64 %19, %25 offset:19*%26\n"
+        "ds_read_b64 %20, %25 offset:20*%26\n ds_read_b64 %21, %25 offset:21*%26\n ds_read_b64 %22, %25 offset:22*%26\n ds_read_b64 %23, %25 offset:23*%26\n ds_read_b64 %24, %25 offset:24*%26\n"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(y[4]), "=&v"(y[5]), "=&v"(y[6]), "=&v"(y[7]), "=&v"(y[8]), "=&v"(y[9]), "=&v"(y[10]), "=&v"(y[11]),
+          "=&v"(y[12]), "=&v"(y[13]), "=&v"(y[14]), "=&v"(y[15]), "=&v"(y[16]), "=&v"(y[17]), "=&v"(y[18]), "=&v"(y[19]), "=&v"(y[20]), "=&v"(y[21]), "=&v"(y[22]),
+          "=&v"(y[23]), "=&v"(y[24])
+        : "v"(a), "n"(STEP)
+        : "memory");
+}
+
 // ---- row pass ----------------------------------------------------------------------------------------------------------------
 struct RowsArgs {
     const uint32_t *Xs;  // signal spectrum of bin 0, CRT layout, every row doubled: [53][12][6250] fp16 complex (re lo, im hi)
@@ -145,7 +172,11 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
     v2f tw1a[5], tw1b[5], tw2[5];
 #pragma unroll
     for (int p = 1; p < 5; ++p) tw1a[p] = unit((jj * p) % K3, K3), tw1b[p] = unit((jj * 5 * p) % K3, K3);
-    const int si = jj % 25, spg = jj / 25;
+    // stage-2 thread t = 5 i + pg: its five reads / in-place writes sit at 25 (i + 25 r) + 5 pg + c = 5 t + (625 r + c) -- stride 5 over
+    // the lanes, conflict-free in the 32-lane halves of a ds_read_b64 and the 16-lane groups of a ds_write_b64 (t = i + 25 pg, the
+    // first version, was 2-way in every half-wave: SQ_LDS_BANK_CONFLICT 28 % of the LDS cycles, profiles/r06_b1c_pmc_first.txt)
+    const int si = jj / 5, spg = jj % 5;
+    const unsigned region_b = lds_offset(region);
 #pragma unroll
     for (int u = 1; u < 5; ++u) tw2[u] = unit((si * u) % 125, 125);
 
@@ -192,8 +223,8 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
 #pragma unroll
                 for (int c5 = 0; c5 < 5; ++c5) {
                     v2f z[5];
-#pragma unroll
-                    for (int r = 0; r < 5; ++r) z[r] = to_v2f(region[25 * (si + 25 * r) + 5 * spg + c5]);
+                    // a[i + 25 r][5 pg + c5], r = 0..4: 625 elements apart
+                    lds_read5<0, 625 * 8>(z, region_b + (unsigned)(25 * si + 5 * spg + c5) * 8u);
                     pk_radix5(z[0], z[1], z[2], z[3], z[4]);
 #pragma unroll
                     for (int u = 0; u < 5; ++u) {
@@ -204,11 +235,7 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
             }
             PFA_RSYNC();
             // stage 3: thread t' = p + 25 u: 25 points over i of b[p][i][u] at 25 (i + 25 u) + p -> t'': X[t' + 125 t'']
-            {
-                const int p3 = jj % 25, u3 = jj / 25;
-#pragma unroll
-                for (int i = 0; i < 25; ++i) x[i] = to_v2f(region[25 * (i + 25 * u3) + p3]);
-            }
+            lds_read25<25 * 8>(x, region_b + (unsigned)(625 * (jj / 25) + jj % 25) * 8u);  // b[p][i][u] at 25 (i + 25 u) + p, i = 0..24
             pk_radix25(x);
 #pragma unroll
             for (int sl = 0; sl < 25; ++sl) {

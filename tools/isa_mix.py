@@ -32,7 +32,7 @@ def mix(body, lo, hi):
         c[l.split()[0]] += 1
     valu = {2: 0, 4: 0, 8: 0}
     for op, n in c.items():
-        if op.startswith("v_") and not op.startswith("v_readlane") and not op.startswith("v_readfirstlane"):
+        if op.startswith("v_") and not op.startswith(("v_readlane", "v_readfirstlane", "v_mfma", "v_accvgpr")):
             k = 8 if op.startswith(CYC8) else 4 if op.startswith(CYC4) else 2
             valu[k] += n
     ds_r = sum(n * (2 if "read2" in op else 1) for op, n in c.items() if op.startswith("ds_read"))
@@ -54,12 +54,41 @@ def report(name, body, lo, hi, items_note):
           f"round-3 additive figure {cyc_lds} (8 / 24);   {vm} global/buffer memory instructions")
     top = sorted(((n, op) for op, n in c.items() if op.startswith(("v_", "ds_"))), reverse=True)[:14]
     print("   " + ", ".join(f"{op} {n}" for n, op in top))
+    n_mfma = sum(n for op, n in c.items() if op.startswith("v_mfma"))
+    if n_mfma:
+        print(f"   MFMA {n_mfma} x v_mfma_f32_16x16x32_f16 (16 matrix-pipe cycles each, 4 passes): {16 * n_mfma} cycles of the SIMD's matrix pipe")
     return dict(valu_insts=n_valu, valu_cycles=cyc_valu, cycles_per_inst=cyc_valu / n_valu, lds_cycles=cyc_lds, lds_marginal_cycles=cyc_lds_marg,
-                lds_unit_cu_cycles=cyc_lds_unit, lds_reads=ds_r, lds_writes=ds_w, vmem_insts=vm, class_counts={str(k): v for k, v in valu.items()})
+                lds_unit_cu_cycles=cyc_lds_unit, lds_reads=ds_r, lds_writes=ds_w, vmem_insts=vm, class_counts={str(k): v for k, v in valu.items()},
+                mfma_insts=n_mfma, mfma_cycles=16 * n_mfma)
+
+
+def main_pfa(lines, outp):
+    """the N-point pair (csrc/bds_acq_pfa.h, round 6):  python tools/isa_mix.py acq.s profiles/r06_isa_mix.json pfa"""
+    out = {}
+    # column pass: ONE OUTPUT BLOCK of a wave item (the loop over nb: 16 real outputs = 8 lags t1, x 4 lags t3 x 12 lags t2 x 2 components;
+    # seven of them per wave item, whose 24 buffer loads stand in front of the loop)
+    b = kernel_body(lines, "k_pfa_colsILi2ELb0EE")
+    first_mfma = next(i for i, l in enumerate(b) if "v_mfma" in l)
+    hdr = [i for i, l in enumerate(b) if l.startswith(".LBB") and "Loop" in l and i < first_mfma]
+    lo = max(hdr)
+    # (ds_read_b128 counted as two b64 reads)
+    hi = next(i for i, l in enumerate(b) if i > first_mfma and "v_readlane_b32" in l)
+    body = [l.replace("ds_read_b128", "ds_read2_b64") for l in b]
+    out["cols"] = report("k_pfa_cols<2, false>", body, lo, hi, "one output block of a wave item (7 per item): 8 x 4 x 12 lags x 2 components = 12 point-components per lane, bound pass")
+    b = kernel_body(lines, "k_pfa_rowsILi2EE")
+    bar = [i for i, l in enumerate(b) if "s_barrier" in l]
+    hdr = [(i, l.split(":")[0]) for i, l in enumerate(b) if l.startswith(".LBB") and "Loop" in l and i < bar[0]]
+    lo, lab = max(hdr)
+    hi2 = max(i for i, l in enumerate(b) if "s_cbranch" in l and l.split()[-1] == lab)
+    out["rows"] = report("k_pfa_rows<2>", b, lo, hi2, "one cell of a row pair, 2 components: 2 x 25 point-components per lane (125 of 128 lanes of a row at work)")
+    if outp:
+        json.dump(out, open(outp, "w"), indent=1)
 
 
 def main():
     lines = open(sys.argv[1]).read().split("\n")
+    if len(sys.argv) > 3 and sys.argv[3] == "pfa":
+        return main_pfa(lines, sys.argv[2])
     out = {}
     # column pass: one tile (both components) per workgroup; everything up to the wave maximum is the hot part
     b = kernel_body(lines, "k_cols_wave_fILi768ELi2ELb0E7__half2Li6ELb1ELb1EE")

@@ -16,7 +16,7 @@ blocks = {b.split("\n")[0]: b for b in re.split(r"^== ", txt, flags=re.M) if b.s
 
 def counters(prefix):
     if prefix == "k_rows_":  # the row pass of the search: wave-private kernel when the plan has one, k_rows_inv_f otherwise
-        prefix = "k_rows_wave_f" if any(n.startswith("k_rows_wave_f") for n in blocks) else "k_rows_inv_f"
+        prefix = "k_pfa_rows" if any(n.startswith("k_pfa_rows") for n in blocks) else "k_rows_wave_f" if any(n.startswith("k_rows_wave_f") for n in blocks) else "k_rows_inv_f"
     for name, b in blocks.items():
         if name.startswith(prefix):
             d = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+([\d.]+)", b, re.M)}
@@ -26,14 +26,20 @@ def counters(prefix):
 
 rn, r = counters("k_rows_")
 cn, c = counters(sys.argv[5] if len(sys.argv) > 5 else "k_cols_wave_f")
-total = 1024.0 * (2 * r["FETCH_SIZE"] + r["WRITE_SIZE"] + 2 * c["FETCH_SIZE"] + c["WRITE_SIZE"])
+# FETCH_SIZE correction per kernel (MI355X_MICROARCH.md, HBM: "x 2 for wide coalesced streaming reads ... other access widths are
+# uncalibrated: calibrate on a known byte count in your own access pattern").  argv[7] = factor of the column pass: the N-point
+# pair's column pass (k_pfa_cols) requests 64-byte pieces and reads every byte of the inter-pass buffer exactly once -- 16.2 MB per
+# cell by construction --: its raw FETCH_SIZE is 1.10 x that (= TCC_MISS x 64 B), doubled it would be 8.3 TB/s with the matrix
+# instructions compiled out (profiles/r06_pfa53_parts.txt): more than the chip's peak.  Factor 1 there.
+cf = float(sys.argv[7]) if len(sys.argv) > 7 else 2.0
+total = 1024.0 * (2 * r["FETCH_SIZE"] + r["WRITE_SIZE"] + cf * c["FETCH_SIZE"] + c["WRITE_SIZE"])
 out = {"workload": workload, "cells_per_pair": cells, "round": (sys.argv[6] if len(sys.argv) > 6 else "round 4"), "bytes_per_pair": total,
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_run.sh), avg per dispatch of {rn} + {cn} "
-                 f"(one dispatch pair = {cells} (PRN, bin) cells); FETCH_SIZE doubled per the gfx950 correction "
-                 f"(MI355X_MICROARCH.md, HBM); see {keep}",
+                 f"(one dispatch pair = {cells} (PRN, bin) cells); FETCH_SIZE x 2 (row pass) / x {cf:g} (column pass) per the gfx950 correction and its "
+                 f"calibration rule (MI355X_MICROARCH.md, HBM; tools/make_traffic.py); see {keep}",
        "rows": {"FETCH_SIZE_KiB": r["FETCH_SIZE"], "WRITE_SIZE_KiB": r["WRITE_SIZE"], "duration_us": r["~duration_ns"] / 1e3},
        "cols": {"FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"], "duration_us": c["~duration_ns"] / 1e3},
-       "per_cell_MB": total / cells / 1e6}
+       "cols_fetch_factor": cf, "per_cell_MB": total / cells / 1e6}
 json.dump(out, open(f"profiles/traffic_{workload}.json", "w"), indent=1)
 
 shutil.copy(src, keep)

@@ -33,7 +33,8 @@ def counters(prefix):
 CUS, SIMDS, CLOCK = 256, 256 * 4, 2.4  # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
 kern = {}
 tot = dict(valu=0.0, marg=0.0, unit=0.0, add=0.0, insts=0.0)
-for key, prefix in (("rows", "k_rows_wave_f"), ("cols", "k_cols_wave_f")):
+PFA = len(sys.argv) > 6 and sys.argv[6] == "pfa"  # the N-point pair of round 6 (csrc/bds_acq_pfa.h)
+for key, prefix in ((("rows", "k_pfa_rows"), ("cols", "k_pfa_cols")) if PFA else (("rows", "k_rows_wave_f"), ("cols", "k_cols_wave_f"))):
     name, c = counters(prefix)
     m = mix[key]
     items = c["SQ_INSTS_VALU"] / m["valu_insts"]  # hot-loop items (wave-tiles / wave-cells) of one dispatch
@@ -48,7 +49,8 @@ for key, prefix in (("rows", "k_rows_wave_f"), ("cols", "k_cols_wave_f")):
                  "static_pipe_cycles_per_valu_inst": m["cycles_per_inst"], "valu_insts_per_item": m["valu_insts"],
                  "lds_reads_per_item": m["lds_reads"], "lds_writes_per_item": m["lds_writes"],
                  "valu_pipe_cycles_per_simd": valu_cyc, "lds_marginal_issue_cycles_per_simd": marg, "lds_unit_cycles_per_cu": unit,
-                 "bound_ms": max(valu_cyc + marg, unit) / (CLOCK * 1e6), "additive_r3_bound_ms": (valu_cyc + add) / (CLOCK * 1e6),
+                 "mfma_insts_per_item": m.get("mfma_insts", 0), "matrix_pipe_cycles_per_simd": items * m.get("mfma_cycles", 0) / SIMDS,
+                 "bound_ms": max(valu_cyc + marg, unit, items * m.get("mfma_cycles", 0) / SIMDS) / (CLOCK * 1e6), "additive_r3_bound_ms": (valu_cyc + add) / (CLOCK * 1e6),
                  "measured_ms": c["~duration_ns"] / 1e6,
                  "valu_busy": valu_cyc / elapsed if elapsed else None,
                  "shader_clock_GHz_under_pmc": elapsed / c["~duration_ns"] if elapsed else None,
@@ -66,7 +68,7 @@ out = {"workload": workload, "cells_per_pair": cells, "round": rnd, "insts_per_p
        "clock_GHz": CLOCK,
        "bound_ms": sum(k["bound_ms"] for k in kern.values()),
        "additive_r3_bound_ms": sum(k["additive_r3_bound_ms"] for k in kern.values()),
-       "model": "per kernel max(vector pipe cycles + marginal LDS issue cost, LDS-unit time) / 2.4 GHz (tools/probe/coissue.hip); "
+       "model": "per kernel max(vector pipe cycles + marginal LDS issue cost, LDS-unit time, matrix-pipe cycles) / 2.4 GHz (tools/probe/coissue.hip); "
                 "additive_r3_bound_ms = the round-3 sum with 8 / 24 SIMD-cycles per LDS read / write",
        "power": {"measured_W": 1325, "cap_W": 1400, "sclk_MHz": 1996,
                  "note": "rocm-smi sample while the cfg3 search ran (tools/exp/r4_power.sh): the chip sits at its power cap, so the "

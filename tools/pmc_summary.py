@@ -12,7 +12,7 @@ for path in sys.argv[1:]:
     q = ("select kernel_name, counter_name, sum(value), count(distinct dispatch_id), avg(duration) "
          "from counters_collection group by kernel_name, counter_name")
     for k, cn, v, n, dur in db.execute(q):
-        k = k.split("(")[0].replace("void bds::", "").replace("bds::", "")
+        k = k.split("(")[0].replace("void bds::", "").replace("bds::", "").replace("pfa::", "")
         acc[k][cn] = [v / max(n, 1), n]
         acc[k]["~duration_ns"] = [dur, n]
 for k in sorted(acc):
