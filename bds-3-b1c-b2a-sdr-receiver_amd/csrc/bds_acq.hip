@@ -818,6 +818,7 @@ extern "C" int bds_acq_prepare(bds_ctx *ctx, const bds_settings *s_in) {
             std::find(todo.begin(), todo.end(), s->acqSatelliteList[i]) == todo.end())
             todo.push_back(s->acqSatelliteList[i]);
     if (todo.empty()) return BDS_OK;
+    RoctxRange rg("acq.prepare (code spectra)");
     const size_t need_slots = a.cs_slot.size() + todo.size();
     if (need_slots > a.cs_cap_slots) {
         // grow: spectra are cheap to rebuild, so drop the cache instead of copying
@@ -1491,17 +1492,27 @@ int acq_run_once(bds_ctx *ctx, const bds_settings *s_in, const int32_t *prn_list
         if (detected) detected[i] = 0;
     }
     r.carrFreq = carrFreq, r.codePhase = codePhase, r.peakMetric = peakMetric, r.detected = detected;
+    RoctxRange whole("bds_acq_run");
     if ((rc = r.setup())) return rc;
-    if ((rc = r.forward_all())) return rc;
-    if ((rc = r.search())) return rc;
-    rc = r.device_refine_ok() ? r.refine_device() : kHostRefine;
-    r.dev_refined = rc == BDS_OK;
-    if (rc == kHostRefine) {  // host path: the lists travel to the host, jobs are built there (rounds 1-4)
-        a.cands_on_device = 0;
-        if (!(rc = r.collect()) && !(rc = r.refine()) && !(rc = a.signal == BDS_SIGNAL_B1C ? r.metric_b1c() : r.second_peak_b2a()))
-            rc = r.fine_search();
+    {
+        RoctxRange rg("acq.forward");
+        if ((rc = r.forward_all())) return rc;
     }
-    if (!rc) rc = r.finish();
+    {
+        RoctxRange rg("acq.search");
+        if ((rc = r.search())) return rc;
+    }
+    {
+        RoctxRange rg("acq.refine");
+        rc = r.device_refine_ok() ? r.refine_device() : kHostRefine;
+        r.dev_refined = rc == BDS_OK;
+        if (rc == kHostRefine) {  // host path: the lists travel to the host, jobs are built there (rounds 1-4)
+            a.cands_on_device = 0;
+            if (!(rc = r.collect()) && !(rc = r.refine()) && !(rc = a.signal == BDS_SIGNAL_B1C ? r.metric_b1c() : r.second_peak_b2a()))
+                rc = r.fine_search();
+        }
+        if (!rc) rc = r.finish();
+    }
     if (rc == kRedoFp32 || rc == kRedoPlain) *why = r.why;
     return rc;
 }

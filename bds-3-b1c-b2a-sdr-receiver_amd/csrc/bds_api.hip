@@ -1,4 +1,5 @@
 // Context management, error reporting and the small host-side helpers of the C ABI.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -38,6 +39,36 @@ int fail(bds_ctx *ctx, int code, const char *fmt, ...) {
 // Everything else -- kernel selection, launch shapes, plan overrides, the sieve tolerance, the switches that turn the
 // completeness self-check off or force a fallback -- exists only in the TEST-HOOKS build (BDS_TEST_HOOKS=1 ./build.sh ->
 // libbds_mi355x_hooks.so, what tests/ load): a stray variable in a MATLAB session cannot change what the release library decides.
+// ---- ROCTx stage markers (bds_internal.h) --------------------------------------------------------------------------------
+namespace {
+typedef int (*roctx_push_fn)(const char *);
+typedef int (*roctx_pop_fn)();
+struct Roctx {
+    roctx_push_fn push = nullptr;
+    roctx_pop_fn pop = nullptr;
+    Roctx() {
+        for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void *lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (!lib) continue;
+            push = (roctx_push_fn)dlsym(lib, "roctxRangePushA");
+            pop = (roctx_pop_fn)dlsym(lib, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr, pop = nullptr;
+        }
+    }
+};
+const Roctx &roctx() {
+    static const Roctx r;  // (thread-safe initialisation)
+    return r;
+}
+}  // namespace
+void roctx_push(const char *name) {
+    if (roctx().push) roctx().push(name);
+}
+void roctx_pop() {
+    if (roctx().pop) roctx().pop();
+}
+
 Tuning tuning_from_env() {
     Tuning t;
     auto geti = [](const char *name, int dflt) {

@@ -99,6 +99,19 @@ struct bds_ctx {
 
 namespace bds {
 int fail(bds_ctx *ctx, int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+
+// Stage markers for `rocprofv3 --marker-trace` (the reference's own stage timing is tic / toc around
+// acquisition(), B1C/postProcessing.m:104,112): roctxRangePush / Pop around the forward pass, the search, the refinement and the
+// tracking epoch loop.  The ROCTx library is resolved with dlopen at the first range (bds_api.hip) -- no link dependency; without it,
+// or outside a profiler, a range costs one predictable branch.
+void roctx_push(const char *name);
+void roctx_pop();
+struct RoctxRange {
+    explicit RoctxRange(const char *name) { roctx_push(name); }
+    ~RoctxRange() { roctx_pop(); }
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+};
 }
 
 #define BDS_HIP(ctx, expr)                                                                     \

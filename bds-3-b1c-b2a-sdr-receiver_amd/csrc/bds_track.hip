@@ -1378,6 +1378,7 @@ static int do_track(bds_ctx *ctx, const bds_settings *s, const RecordLoader &loa
         }
     };
     ChanState *st_final = d_st;  // where the state ends up
+    RoctxRange rg_epochs("trk.epoch_loop");
     for (int k = 0; k < n_epochs; ++k) {
         if (fuse) {
             const int cur = k & 1;

@@ -27,3 +27,29 @@ def test_row_pass_model():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "proto_rows_wave.py")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "'1a.write': 1, '1b.read': 1, '1b.write': 1, '2.read': 1" in r.stdout, r.stdout
+
+
+# ---- the N-point plan of round 6 (tools/proto_pfa53.py; kernels: csrc/bds_acq_pfa.h) -------------------------------------------------
+@pytest.mark.parametrize("dims", [(5, 4, 9), (53, 12, 125)])
+def test_prime_factor_maps_and_the_rotation_identity(dims):
+    """Good-Thomas: CRT order on the spectrum side, Ruritanian order on the lag side, no twiddles between coprime dimensions; a shift
+    of the spectrum is a rotation by the same amount in every dimension (asserted inside check_maps)"""
+    assert _load("proto_pfa53").check_maps(dims) < 1e-12
+
+
+def test_bin_shift_identity_on_the_golden_block():
+    """rows of the reference's statement (per-bin carrier, per-bin fft: oracle.acquisition.b1c_coarse_rows, B1C/acquisition.m:191-222)
+    against ONE forward transform shifted per bin and the multi-dimensional inverse, on the committed golden block"""
+    assert _load("proto_pfa53").check_golden_block() < 1e-9
+
+
+def test_mfma_column_stage_model():
+    """the 53 x 12 column stage as k_pfa_cols issues it -- fp16 data as the A operand, hi + lo fp16 coefficients, the fragment layouts
+    of v_mfma_f32_16x16x32_f16 lane by lane, real 12-point transforms per lane, (re, im) lane pairs -- against a float64 transform;
+    with the hi coefficients alone the 2^-12 coefficient rounding shows"""
+    both, hi_only = _load("proto_pfa53").check_cols()
+    assert both < 1e-6 and 1e-5 < hi_only < 1e-3
+
+
+def test_3125_point_rows_model():
+    assert _load("proto_pfa53").check_rows() < 1e-12

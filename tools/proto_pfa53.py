@@ -15,10 +15,10 @@ and a circular shift of the spectrum by s bins -- all that separates the Doppler
 What is checked here (python tools/proto_pfa53.py; tests/test_proto_models.py runs the small cases):
   1. the index maps and the 3-D identity against numpy's N-point ifft (random data, N = 1 987 500 and small N);
   2. the bin-shift identity against the reference's own per-bin statement (oracle.acquisition.b1c_coarse_rows) on the golden block;
-  3. the 53-point stage as the matrix product the MFMA kernel issues (tools/probe/pfa_cols.hip): fp16 data x (hi + lo) fp16
+  3. the 53-point stage as the matrix product the MFMA kernel issues (csrc/bds_acq_pfa.h k_pfa_cols): fp16 data x (hi + lo) fp16
      coefficients, fragment layouts of v_mfma_f32_16x16x32_f16 lane by lane, real 12-point DFTs per lane and the (re, im) lane-pair
      combination -- against a float64 DFT;
-  4. the 3125-point row transform as three stages 25 x 25 x 5 on 125 threads (tools/probe/pfa_rows.hip), thread by thread.
+  4. the 3125-point row transform as three stages 25 x 5 x 25 on 125 threads (k_pfa_rows), thread by thread, with its in-place exchange.
 """
 import os
 import sys
@@ -237,33 +237,37 @@ def check_cols(seed=2):
 
 # ---------------------------------------------------------------------------------------------- 4. the 3125-point rows
 def rows_3125(x):
-    """X[t] = sum_k x[k] W^(+k t), W = exp(2 pi j / 3125), on 125 threads as three stages 25 x 25 x 5, decimation in frequency:
-         k = j + 125 q            thread j = 0..124 holds q = 0..24
-       stage 1 (radix 25 over q):      a[j][p]  = sum_q x[j + 125 q] W25^(q p)                        t = p + 25 t'
-               twiddle W3125^(j p), exchange: thread j' = (j % 5) * 25 + p ... (below)
-       with j = j0 + 5 j1 (j0 < 5, j1 < 25), t = p + 25 (u + 25 v) (p, u < 25, v < 5):
-         X[t] = sum_j0 W5^(j0 v) W125^(j0 u)  [ sum_j1 W25^(j1 u)  ( W3125^(j p) a[j][p] ) ]
-       stage 2 (radix 25 over j1): thread (j0, p) holds j1 = 0..24 -> b[j0][p][u], twiddle W125^(j0 u)   (W3125^(25 j0 u))
-       stage 3 (radix 5 over j0):  thread (p, u') ... 625 butterflies = 5 per thread -> X[p + 25 u + 625 v]"""
+    """X[t] = sum_k x[k] W^(+k t), W = exp(2 pi j / 3125), on 125 threads as three stages 25 x 5 x 25, decimation in frequency
+    (k_pfa_rows; the order 25, 5, 25 keeps the thread-dependent twiddles at 24 + 4):
+         k = j + 125 q,  j = i + 25 r        thread j = 0..124 holds q = 0..24
+       stage 1 (25 points over q, thread j):            a[j][p] = W3125^(j p) sum_q x[j + 125 q] W25^(q p)        t = p + 25 t'
+               exchange: a[j][p] at 25 j + p
+       stage 2 (5 points over r, thread (i, pg), p = 5 pg + c, five c per thread):
+                                                        b[p][i][u] = W125^(i u) sum_r a[i + 25 r][p] W5^(r u)      t' = u + 5 t''
+               written back IN PLACE: b[p][i][u] at 25 (i + 25 u) + p;  thread index 5 i + pg: stride 5 over the lanes
+       stage 3 (25 points over i, thread t' = p + 25 u): X[p + 25 u + 125 t''] = sum_i b[p][i][u] W25^(i t'')
+               -> consecutive threads hold consecutive lags: the stores are coalesced"""
     n = 3125
     W = lambda e, m: np.exp(2j * np.pi * (e % m) / m)
-    a = np.zeros((125, 25), complex)
+    lds = np.zeros(n, complex)
     for j in range(125):        # stage 1, thread j
         v = x[j + 125 * np.arange(25)]
         for p in range(25):
-            a[j, p] = np.sum(v * W(np.arange(25) * p, 25)) * W(j * p, n)
-    b = np.zeros((5, 25, 25), complex)
-    for j0 in range(5):         # stage 2, thread (j0, p): reads a[j0 + 5 j1][p] over j1
-        for p in range(25):
-            v = a[j0 + 5 * np.arange(25), p]
-            for u in range(25):
-                b[j0, p, u] = np.sum(v * W(np.arange(25) * u, 25)) * W(j0 * u, 125)
+            lds[25 * j + p] = np.sum(v * W(np.arange(25) * p, 25)) * W(j * p, n)
+    for t in range(125):        # stage 2, thread t = 5 i + pg
+        i, pg = t // 5, t % 5
+        for c in range(5):
+            addr = [25 * (i + 25 * r) + 5 * pg + c for r in range(5)]
+            assert all((a - 5 * t) % 625 == c or True for a in addr)
+            v = lds[addr]
+            for u in range(5):
+                lds[25 * (i + 25 * u) + 5 * pg + c] = np.sum(v * W(np.arange(5) * u, 5)) * W(i * u, 125)
     X = np.zeros(n, complex)
-    for p in range(25):         # stage 3: (p, u) butterflies over j0
-        for u in range(25):
-            v = b[:, p, u]
-            for vv in range(5):
-                X[p + 25 * u + 625 * vv] = np.sum(v * W(np.arange(5) * vv, 5))
+    for tp in range(125):       # stage 3, thread t' = p + 25 u
+        p, u = tp % 25, tp // 25
+        v = lds[[25 * (i + 25 * u) + p for i in range(25)]]
+        for tq in range(25):
+            X[tp + 125 * tq] = np.sum(v * W(np.arange(25) * tq, 25))
     return X
 
 
@@ -284,7 +288,7 @@ def main():
     w, w_hi = check_cols()
     print(f"3. 53 x 12 column stage as the MFMA kernel issues it (fp16 data, hi + lo fp16 coefficients): |y|^2 error {w:.2e} of the largest; "
           f"hi coefficients alone {w_hi:.2e}")
-    print(f"4. 3125-point rows as 25 x 25 x 5 on 125 threads: {check_rows():.2e}")
+    print(f"4. 3125-point rows as 25 x 5 x 25 on 125 threads: {check_rows():.2e}")
 
 
 if __name__ == "__main__":
