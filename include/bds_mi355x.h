@@ -216,13 +216,14 @@ BDS_API int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *prn_
                         int max_prn, double *carrFreq, double *codePhase, double *peakMetric,
                         int32_t *detected);
 /* Budget of the search's inter-pass buffer: a launch pair (row pass + column pass) carries as many PRNs' Doppler rows as fit
- * `gib` GiB, and the more it carries the less a call costs -- the row workgroups of the PRNs share the signal-spectrum rows in L2
- * and a call is a few long launches.  cfg3 (63 PRNs x 201 bins, 5 GB per PRN) on one box:
- *     0        one PRN per pair,  5 GB     196.7 ms per call      (the minimal footprint)
- *    40        8 PRNs per pair,  40 GB     191.6 - 192.1          (the DEFAULT)
- *    80       16 PRNs per pair,  80 GB     189.3 - 189.8
- *   < 0       60 % of the device memory that is free: 32 + 31 PRNs, 150 GiB   186.8 - 187.1   (the SERVING mode of a process
- *             that keeps the device to itself; bench.py times it beside its headline, which is the default: key `serving`)
+ * `gib` GiB; a call is then a few long launches.  cfg3 (63 PRNs x 201 bins) on one box, round 6 (the N-point pair of
+ * csrc/bds_acq_pfa.h: 3.3 GB per PRN; profiles/r06_pfa53_knobs.txt):
+ *     0        one PRN per pair,  3.3 GB    174.3 ms per call     (the minimal footprint)
+ *    40        12 - 13 PRNs per pair        170.4                 (the DEFAULT)
+ *    80        21 PRNs per pair             172.9
+ *   < 0       60 % of the device memory that is free: 32 + 31 PRNs, 100 GiB    173.9   (the SERVING mode; bench.py key `serving`)
+ * With the L-point pair of rounds 3-5 (5 GB per PRN; every configuration the N-point pair does not cover) more PRNs per pair also
+ * shared the 2.5 GB of signal-spectrum rows in L2: 196.7 / 191.6 - 192.1 (8 PRNs) / 189.3 - 189.8 / 186.8 - 187.1 ms.
  * The price is the footprint, and time when it changes hands: a fresh allocation is free (a first call costs the same in every
  * mode), but the driver clears freed device memory at ~33 GB/s and whoever allocates next waits -- up to ~4.8 s after a 150-GiB
  * context is destroyed.  Results are the same bits in every mode.  Same switch as the environment knob BDS_ACQ_PAIR_GB (number

@@ -30,15 +30,16 @@ for name, env in (("fp16 storage (default)", {}), ("fp32 storage", {"BDS_ACQ_FP1
     tm = c.timing()
     rm, ra = c.acq_grid(63, 201)
     pk, dn, fb = c.acq_peaks(63)
-    grids[name] = (rm.astype(np.float64), ra, pk, int(tm["half_storage"]), tm["cell_pair_ms"])
+    grids[name] = (rm.astype(np.float64), ra, pk, int(tm["half_storage"]), tm["cell_pair_ms"], int(tm["fft_len"]))
     c.close()
-(h, ha, hp, hm, ht), (f, fa, fp, fm, ft) = grids["fp16 storage (default)"], grids["fp32 storage"]
+(h, ha, hp, hm, ht, _), (f, fa, fp, fm, ft, _) = grids["fp16 storage (default)"], grids["fp32 storage"]
 assert hm == 1 and fm == 0
 glob = np.abs(h - f) / f.max(axis=1, keepdims=True)
 rel = np.abs(h / f - 1)
 present = sorted(sat.prn for sat in sats)
-print(f"# {label}: plan 768 x 4096, search grid of mode 1 (fp16 storage, {ht:.2f} ms per 201 cells) vs mode 0 (fp32 storage, {ft:.2f} ms)")
-print(f"row maxima, all 63 x 201 rows: |diff| / PRN maximum  max {glob.max():.3e}  mean {glob.mean():.3e}   (kDelta / 2 = 1.0e-03: margin {1e-3 / glob.max():.1f}x)")
+hk = "N-point pair, plan 53 x 12 x 3125" if grids["fp16 storage (default)"][5] == 1987500 else "L-point pair, plan 768 x 4096"
+print(f"# {label}: search grid of the default ({hk}; fp16 storage, {ht:.2f} ms per launch pair) vs fp32 storage (L-point pair 768 x 4096, {ft:.2f} ms per pair)")
+print(f"row maxima, all 63 x 201 rows: |diff| / PRN maximum  max {glob.max():.3e}  mean {glob.mean():.3e}   (kDelta / 2 = 2.0e-03: margin {2e-3 / glob.max():.1f}x)")
 print(f"row maxima, relative to the row's own maximum: max {rel.max():.3e}  rms {np.sqrt((rel ** 2).mean()):.3e}")
 print(f"row argmax agrees on {np.mean(ha == fa):.3f} of the rows; f64 peak of every PRN identical in both modes: {bool(np.array_equal(hp, fp))}")
 worst = np.argsort(glob.max(axis=1))[::-1][:5]
