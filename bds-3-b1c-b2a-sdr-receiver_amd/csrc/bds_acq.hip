@@ -153,6 +153,9 @@ struct AcqState {
     std::map<int, std::vector<std::pair<int, long>>> last_cands;  // PRN -> (bin, lag) cells the last run refined in f64
     bool no_fast_search = false;     // this configuration fell back to the run-time-plan search kernels
     bool no_small = false;           // this configuration's 80 x 4096 plan fell back to fp32 storage: re-planned without it
+    bool fell_back = false;          // a run of this configuration was redone with fp32 storage / on the run-time-plan kernels: the NEXT
+                                     // block (bds_acq_load) starts on the default path again (round 6; until then the fallback stayed for
+                                     // as long as the configuration did -- one pathological block made every later one ten times slower)
     CorrJob *d_jobs = nullptr;
     double2 *d_jobout = nullptr;
     size_t jobs_cap = 0;
@@ -708,6 +711,11 @@ extern "C" int bds_acq_load(bds_ctx *ctx, const bds_settings *s_in, const int8_t
     const bds_settings *s = effective(s_in, &eff);
     // n_samples counts complex samples when is_complex: `samples` then holds 2*n_samples int8 (I,Q pairs)
     const bool cplx = is_complex != 0;
+    if (ctx->acq && ctx->acq->fell_back) {  // a new block: back to the default storage and kernels (acq_configure re-derives them)
+        ctx->acq->fell_back = false;
+        ctx->acq->no_small = false;
+        ctx->acq->plan.L = 0;
+    }
     int rc = acq_configure(ctx, *s);
     if (rc) return rc;
     AcqState &a = *ctx->acq;
@@ -1540,6 +1548,7 @@ extern "C" int bds_acq_run(bds_ctx *ctx, const bds_settings *s_in, const int32_t
         if (rc != kRedoFp32 && rc != kRedoPlain) return rc;
         if (attempt >= 2) return fail(ctx, BDS_ERR_UNSUPPORTED, "bds_acq_run: the search could not be completed (%s)", why.c_str());
         AcqState &a = *ctx->acq;
+        a.fell_back = true;
         const bool plain_kernels = rc == kRedoPlain;
         if (ctx->tune.verbose) fprintf(stderr, "[bds] search re-run (%s): %s\n", plain_kernels ? "run-time-plan kernels" : "fp32 storage", why.c_str());
         if (a.plan.small) {
