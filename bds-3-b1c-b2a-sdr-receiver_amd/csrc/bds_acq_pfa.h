@@ -383,14 +383,17 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
             for (int ins = 0; ins < 4; ++ins)
 #pragma unroll
                 for (int part = 0; part < 2; ++part) fb[ins][part] = s_coef[((nb * 4 + ins) * 2 + part) * 64 + lane];
+            // the MFMAs of BOTH components first (six independent accumulator chains), then the two epilogues: component 1's matrix
+            // work runs under component 0's vector work (columns 1.28 -> 1.25 ms per 201 cells; the epilogue itself on packed
+            // (component 0, component 1) pairs measured no faster -- this kernel waits on latency, not on issue slots: HISTORY.md 8)
+            f4 acc2[NC][3];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                f4 acc[3];
 #pragma unroll
-                for (int quad = 0; quad < 3; ++quad) acc[quad] = (f4){0.f, 0.f, 0.f, 0.f};
+                for (int quad = 0; quad < 3; ++quad) acc2[c][quad] = (f4){0.f, 0.f, 0.f, 0.f};
 #ifdef PFA_EXP_C_NOMFMA  // (timing experiments, tools/exp/r6_pfa_parts.sh: results INVALID)
 #pragma unroll
-                for (int quad = 0; quad < 3; ++quad) acc[quad] = (f4){__uint_as_float(fa[c][quad][0].x), __uint_as_float(fb[1][0].y), __uint_as_float(fa[c][quad][2].z), __uint_as_float(fb[3][1].w)};
+                for (int quad = 0; quad < 3; ++quad) acc2[c][quad] = (f4){__uint_as_float(fa[c][quad][0].x), __uint_as_float(fb[1][0].y), __uint_as_float(fa[c][quad][2].z), __uint_as_float(fb[3][1].w)};
 #else
 #pragma unroll
                 for (int ins = 0; ins < 4; ++ins)
@@ -398,9 +401,13 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                     for (int part = 0; part < 2; ++part)
 #pragma unroll
                         for (int quad = 0; quad < 3; ++quad)
-                            acc[quad] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, fa[c][quad][ins]), __builtin_bit_cast(h8, fb[ins][part]),
-                                                                               acc[quad], 0, 0, 0);
+                            acc2[c][quad] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, fa[c][quad][ins]), __builtin_bit_cast(h8, fb[ins][part]),
+                                                                                   acc2[c][quad], 0, 0, 0);
 #endif
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f4(&acc)[3] = acc2[c];
 #ifdef PFA_EXP_C_NOEPI
 #pragma unroll
                 for (int t = 0; t < 12; ++t) m2[c][t] = acc[t >> 2][t & 3];
