@@ -180,30 +180,57 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
 #pragma unroll
     for (int u = 1; u < 5; ++u) tw2[u] = unit((si * u) % 125, 125);
 
+    const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)A.Xs, 0, K1 * K2 * 2 * K3 * 4, 0x00020000);
     for (int cell = c0; cell < c1; ++cell) {
         const int s = A.bin[cell] * A.shift;
         const int k1s = ((k1c - s) % K1 + K1) % K1, k2s = ((k2 - s) % K2 + K2) % K2, o3 = (K3 - s % K3) % K3;
-        const uint32_t *xrow = A.Xs + ((size_t)k1s * K2 + k2s) * (2 * K3) + o3 + jj;
+        // (buffer loads / stores: one descriptor, one lane offset, the 25 strides as immediates -- per-access 64-bit address arithmetic was
+        //  five vector instructions per load: 8 % of the cell loop)
+        const int xoff = ((k1s * K2 + k2s) * (2 * K3) + o3 + jj) * 4;  // < 2^25 bytes
         uint32_t xn[25];
 #ifdef PFA_EXP_R_NOLOAD
 #pragma unroll
-        for (int q = 0; q < 25; ++q) xn[q] = 0x3c003800u + q + cell + (uint32_t)(size_t)xrow;
+        for (int q = 0; q < 25; ++q) xn[q] = 0x3c003800u + q + cell + (uint32_t)xoff;
 #else
 #pragma unroll
-        for (int q = 0; q < 25; ++q) xn[q] = xrow[125 * q];
+        for (int q = 0; q < 25; ++q) xn[q] = __builtin_amdgcn_raw_buffer_load_b32(xs_rsrc, xoff, 500 * q, 0);
 #endif
         uint32_t outp[NC][25];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             v2f x[25];
+            // X conj(C): (xr, -xi).(cr', ci') and (xi, xr).(cr', ci') with C' = conj(C) stored.  The three-operand v_dot2_f32_f16 with an inline
+            // zero addend, five products per asm block with the dot -> VALU hazard closed by hand (s_nop 2), as bds_acq_wrows.h: the
+            // builtin compiles to the accumulating v_dot2c behind a v_mov 0 per result (50 moves per cell).  -DPFA_ROWS_DOT2_BUILTIN: the builtin.
+#ifndef PFA_ROWS_DOT2_BUILTIN
 #pragma unroll
-            for (int q = 0; q < 25; ++q) {  // X conj(C): (xr, -xi).(cr', ci') and (xi, xr).(cr', ci') with C' = conj(C) stored
+            for (int q = 0; q < 25; q += 5) {
+                uint32_t xs[5], xc[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) xs[i] = __builtin_amdgcn_alignbit(xn[q + i], xn[q + i], 16), xc[i] = xn[q + i] ^ 0x80000000u;
+                float re[5], im[5];
+                asm volatile(
+                    "v_dot2_f32_f16 %0, %10, %20, 0\n v_dot2_f32_f16 %5, %15, %20, 0\n"
+                    "v_dot2_f32_f16 %1, %11, %21, 0\n v_dot2_f32_f16 %6, %16, %21, 0\n"
+                    "v_dot2_f32_f16 %2, %12, %22, 0\n v_dot2_f32_f16 %7, %17, %22, 0\n"
+                    "v_dot2_f32_f16 %3, %13, %23, 0\n v_dot2_f32_f16 %8, %18, %23, 0\n"
+                    "v_dot2_f32_f16 %4, %14, %24, 0\n v_dot2_f32_f16 %9, %19, %24, 0\n s_nop 2"
+                    : "=&v"(re[0]), "=&v"(re[1]), "=&v"(re[2]), "=&v"(re[3]), "=&v"(re[4]), "=&v"(im[0]), "=&v"(im[1]), "=&v"(im[2]), "=&v"(im[3]), "=&v"(im[4])
+                    : "v"(xc[0]), "v"(xc[1]), "v"(xc[2]), "v"(xc[3]), "v"(xc[4]), "v"(xs[0]), "v"(xs[1]), "v"(xs[2]), "v"(xs[3]), "v"(xs[4]),
+                      "v"(cv[c][q]), "v"(cv[c][q + 1]), "v"(cv[c][q + 2]), "v"(cv[c][q + 3]), "v"(cv[c][q + 4]));
+#pragma unroll
+                for (int i = 0; i < 5; ++i) x[q + i] = (v2f){re[i], im[i]};
+            }
+#else
+#pragma unroll
+            for (int q = 0; q < 25; ++q) {
                 const uint32_t xs = __builtin_amdgcn_alignbit(xn[q], xn[q], 16), xc = xn[q] ^ 0x80000000u;
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 const h2 hc = __builtin_bit_cast(h2, cv[c][q]);
                 x[q] = (v2f){__builtin_amdgcn_fdot2(__builtin_bit_cast(h2, xc), hc, 0.f, false),
                              __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, xs), hc, 0.f, false)};
             }
+#endif
             // stage 1: 25 points over q (k3 = j + 125 q) -> p, twiddle W3125^(j p), a[j][p] at 25 j + p
             pk_radix25(x);
             if (c > 0) PFA_RSYNC();  // the previous component's stage-3 reads of the region are done
@@ -245,7 +272,8 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
             }
         }
         // the two rows of the pair meet: after the swap half 0 holds (row 0, row 1) of t'' = e, half 1 of t'' = e + 1
-        uint32_t *dst = A.Bw + (size_t)cell * kCellElems + ((size_t)mp * K2 + k2) * K3 * 4;
+        const __amdgpu_buffer_rsrc_t dst_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(A.Bw + (size_t)cell * kCellElems + ((size_t)mp * K2 + k2) * K3 * 4), 0, K3 * 16, 0x00020000);
 #pragma unroll
         for (int e = 0; e < 25; e += 2) {
             uint32_t P[2], Q[2];
@@ -257,9 +285,9 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
                 P[c] = r[0], Q[c] = r[1];
             }
             const int tq = e + half;
-            if (live && tq < 25) {
-                const int t3 = j + 125 * tq;
-                *reinterpret_cast<uint4 *>(dst + (size_t)t3 * 4) = make_uint4(P[0], Q[0], P[1], Q[1]);
+            if (live && tq < 25) {  // lag t3 = j + 125 tq
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128((u4){P[0], Q[0], P[1], Q[1]}, dst_rsrc, (j + 125 * half) * 16, 125 * 16 * e, 0);
             }
         }
         PFA_RSYNC();  // region free for the next cell
