@@ -63,6 +63,18 @@ for key, prefix in ((("rows", "k_pfa_rows"), ("cols", "k_pfa_cols")) if PFA else
     tot["unit"] += unit
     tot["add"] += add
     tot["insts"] += c["SQ_INSTS_VALU"]
+power = {"measured_W": 1325, "cap_W": 1400, "sclk_MHz": 1996,
+         "note": "rocm-smi sample while the cfg3 search ran (tools/exp/archive/r4_power.sh): the chip sits at its power cap, so the "
+                 "clock (and with it wall time per instruction) follows the switching activity -- tools/probe/coissue.hip: a pure "
+                 "v_fma_f32 stream reaches 0.96 wave-instructions per ns and SIMD (81 % of the 2.4 GHz peak) at ANY occupancy >= 2"}
+if PFA:  # the round-6 pair: sustained 20-s loops, tools/power_sustained.py -> profiles/r06_power_sustained.txt (first line)
+    try:
+        pj = json.loads(open("profiles/r06_power_sustained.txt").readline())
+        power = {"measured_W": pj["power_W"]["median"], "cap_W": 1400, "sclk_MHz": pj["sclk_MHz"]["median"], "ms_per_call": pj["ms_per_call"],
+                 "note": "tools/power_sustained.py: 20-s loop of bds_acq_run, sysfs power / clock at ~20 Hz (profiles/r06_power_sustained.txt: the N-point pair "
+                         "1320 W at 1.92 GHz, 216 J per call; the L-point pair on the same box 1354 W at 1.96 GHz, 260 J per call)"}
+    except Exception:
+        pass
 out = {"workload": workload, "cells_per_pair": cells, "round": rnd, "insts_per_pair": tot["insts"],
        "valu_pipe_cycles_per_simd": tot["valu"], "lds_marginal_issue_cycles_per_simd": tot["marg"], "lds_unit_cycles_per_cu": tot["unit"],
        "clock_GHz": CLOCK,
@@ -70,10 +82,7 @@ out = {"workload": workload, "cells_per_pair": cells, "round": rnd, "insts_per_p
        "additive_r3_bound_ms": sum(k["additive_r3_bound_ms"] for k in kern.values()),
        "model": "per kernel max(vector pipe cycles + marginal LDS issue cost, LDS-unit time, matrix-pipe cycles) / 2.4 GHz (tools/probe/coissue.hip); "
                 "additive_r3_bound_ms = the round-3 sum with 8 / 24 SIMD-cycles per LDS read / write",
-       "power": {"measured_W": 1325, "cap_W": 1400, "sclk_MHz": 1996,
-                 "note": "rocm-smi sample while the cfg3 search ran (tools/exp/r4_power.sh): the chip sits at its power cap, so the "
-                         "clock (and with it wall time per instruction) follows the switching activity -- tools/probe/coissue.hip: a pure "
-                         "v_fma_f32 stream reaches 0.96 wave-instructions per ns and SIMD (81 % of the 2.4 GHz peak) at ANY occupancy >= 2"},
+       "power": power,
        "kernels": kern,
        "source": f"{src} (rocprofv3 --pmc, tools/pmc_run.sh) + {mixp} (tools/isa_mix.py)"}
 json.dump(out, open(f"profiles/valu_{workload}.json", "w"), indent=1)
