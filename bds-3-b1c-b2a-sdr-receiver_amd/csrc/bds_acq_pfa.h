@@ -27,6 +27,8 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "bds_acq_wcols.h"  // Extra, wc_pack, wave_max_f32; bds_fft_pk.h, bds_lds.h
 
 #ifdef PFA_EXP_R_NOBAR
@@ -320,6 +322,11 @@ inline void make_coef_frags(uint16_t *out /* kCoefBytes / 2 halves */) {
                 }
 }
 
+#ifndef PFA_COLS_BOUND_PARTS
+#define PFA_COLS_BOUND_PARTS 1
+#endif
+constexpr int kBoundParts = PFA_COLS_BOUND_PARTS;  // coefficient parts of the column pass's bound pass (1: hi only; 2: as the values' pass)
+
 struct ColsArgs {
     const uint32_t *Bw;           // inter-pass buffer of the launch's cells
     const uint4 *coef;            // make_coef_frags
@@ -405,12 +412,13 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
         const float lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
         // |y|^2 of output block nb: m2[c][t2] for the lane's (t1, t3); both lanes of a pair hold all twelve
-        auto block = [&](int nb, float (&m2)[2][12]) {
+        auto block = [&](int nb, float (&m2)[2][12], auto parts_tag) {
+            constexpr int PARTS = decltype(parts_tag)::value;  // 2: coefficients hi + lo (the values), 1: hi only (the bound pass)
             uint4 fb[4][2];
 #pragma unroll
             for (int ins = 0; ins < 4; ++ins)
 #pragma unroll
-                for (int part = 0; part < 2; ++part) fb[ins][part] = s_coef[((nb * 4 + ins) * 2 + part) * 64 + lane];
+                for (int part = 0; part < PARTS; ++part) fb[ins][part] = s_coef[((nb * 4 + ins) * 2 + part) * 64 + lane];
             // the MFMAs of BOTH components first (six independent accumulator chains), then the two epilogues: component 1's matrix
             // work runs under component 0's vector work (columns 1.28 -> 1.25 ms per 201 cells; the epilogue itself on packed
             // (component 0, component 1) pairs measured no faster -- this kernel waits on latency, not on issue slots: HISTORY.md 8)
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
 #pragma unroll
                 for (int ins = 0; ins < 4; ++ins)
 #pragma unroll
-                    for (int part = 0; part < 2; ++part)
+                    for (int part = 0; part < PARTS; ++part)
 #pragma unroll
                         for (int quad = 0; quad < 3; ++quad)
                             acc2[c][quad] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, fa[c][quad][ins]), __builtin_bit_cast(h8, fb[ins][part]),
@@ -464,14 +472,18 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
             }
         };
         const int t3o = t0 + (lane >> 4);  // the lag t3 of this lane's outputs
-        float best = 0.f;
+        constexpr int kParts1 = DBG ? 2 : kBoundParts;  // (the debug instantiation reports this pass's values: both parts)
+        float best = 0.f, ssum = 0.f;
         for (int nb = 0; nb < NB; ++nb) {
             float m2[2][12];
-            block(nb, m2);
+            block(nb, m2, std::integral_constant<int, kParts1>{});
             const int t1 = (16 * nb + (lane & 15)) >> 1;
             if (t1 < K1 && t3o < K3) {
 #pragma unroll
-                for (int t = 0; t < 12; ++t) best = fmaxf(best, NC == 2 ? m2[0][t] + m2[1][t] : m2[0][t]);
+                for (int t = 0; t < 12; ++t) {
+                    const float e = NC == 2 ? m2[0][t] + m2[1][t] : m2[0][t];
+                    best = fmaxf(best, e), ssum += e;
+                }
             }
             if (DBG && cell == A.dbg_cell && t0 / 4 == A.dbg_group && t1 < K1 && !(lane & 1)) {
 #pragma unroll
@@ -485,7 +497,20 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
         // outputs, stays below both the cell's maximum so far and the sieve threshold of the PRN's running bound, the wave has nothing
         // to report (bds_acq_wcols.h).  Otherwise the exact values: the outputs are recomputed (they were never all in registers) --
         const float wsum2 = NC > 1 ? A.w0 * A.w0 + A.w1 * A.w1 : A.w0 * A.w0;
-        const float bw = wave_max_f32(best) * wsum2 * 1.00001f;
+        float ub = sqrtf(best);
+        if (kParts1 == 1) {
+            // the bound pass multiplies by fp16(coefficient) only (half the matrix work).  What the values' pass adds, per component:
+            // |sum x lo| <= 2^-11 ||x||_1 (|lo| <= 2^-12 per real entry of the rotation), through the exact 12-point stage
+            // <= 2^-11 sqrt(636) ||x||_2 over the 636 inputs of a lag t3, and ||x||_2 <= ||y_hi||_2 / (sqrt(636) - ||T_lo||) with
+            // ||T_lo|| <= sqrt(12) * 53 * 2^-11.5 = 0.063: delta_c <= 4.9e-4 sqrt(sum over the lag's 636 outputs of |y_hi,c|^2), and by
+            // Minkowski sqrt(|y_d|^2 + |y_p|^2) grows by at most sqrt(delta_d^2 + delta_p^2) = 4.9e-4 sqrt(sum of what `best` is the max of).
+            float s16 = ssum;  // the 16 lanes of a lag; the two lanes of a pair hold the same twelve values: half the sum
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) s16 += __shfl_xor(s16, o);
+            ub += 5.0e-4f * sqrtf(0.5f * s16);
+        }
+        ub = wave_max_f32(ub);
+        const float bw = ub * ub * wsum2 * 1.00001f;
         const float curv = __uint_as_float(cur), lim = fminf(curv, lbv * A.keep);
         if (!(bw < lim * lim)) {  // (wave-uniform; also taken while the bounds are unset or not finite)
             if (A.stats && lane == 0) atomicAdd(A.stats + 1, 1ull);
@@ -497,7 +522,7 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
             int lag1 = 0x7fffffff, lag2 = 0x7fffffff;
             for (int nb = 0; nb < NB; ++nb) {
                 float m2[2][12];
-                block(nb, m2);
+                block(nb, m2, std::integral_constant<int, 2>{});
                 const int t1 = (16 * nb + (lane & 15)) >> 1;
                 if (t1 < K1 && t3o < K3) {
 #pragma unroll
@@ -539,7 +564,7 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                         if (A.stats && lane == 0) atomicAdd(A.stats + 2, 1ull);
                         for (int nb = 0; nb < NB; ++nb) {
                             float m2[2][12];
-                            block(nb, m2);
+                            block(nb, m2, std::integral_constant<int, 2>{});
                             const int t1 = (16 * nb + (lane & 15)) >> 1;
                             const bool mine = t1 < K1 && t3o < K3;
 #pragma unroll

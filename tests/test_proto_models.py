@@ -51,5 +51,11 @@ def test_mfma_column_stage_model():
     assert both < 1e-6 and 1e-5 < hi_only < 1e-3
 
 
+def test_hi_only_bound_pass_margin():
+    """k_pfa_cols' first pass uses fp16(coefficient) alone and widens its Cauchy-Schwarz bound by 5e-4 sqrt(sum of the lag's outputs):
+    the values' pass (hi + lo) never exceeds that, on random inputs and on inputs built against one output's lo column"""
+    assert _load("proto_pfa53").check_bound() < 1.0
+
+
 def test_3125_point_rows_model():
     assert _load("proto_pfa53").check_rows() < 1e-12

@@ -235,6 +235,41 @@ def check_cols(seed=2):
     return worst, float(np.max(np.abs(got_hi - ref[:, :, :4])) / np.max(ref))
 
 
+def check_bound(seed=5, trials=40):
+    """The column pass's first pass multiplies by the hi coefficients only; a wave is skipped when
+    sqrt(|y_d,hi|^2 + |y_p,hi|^2) + 5e-4 sqrt(sum over the lag's 636 outputs of (|y_d,hi|^2 + |y_p,hi|^2)) stays below the limit.
+    Returns the worst (sqrt(|y_d|^2 + |y_p|^2) with hi + lo  -  the same with hi) / (that margin) over random inputs and over inputs built
+    against single outputs (signs of the lo column: the l1 worst case).  Must stay below 1."""
+    rng = np.random.default_rng(seed)
+    _, hi, lo = coef_tables()
+    H = hi.astype(np.float64)[:2 * K1, :2 * K1]
+    F = H + lo.astype(np.float64)[:2 * K1, :2 * K1]
+    w12 = np.exp(2j * np.pi * np.outer(np.arange(K2), np.arange(K2)) / K2)
+
+    def transform(x, tab):  # x: real [12][106] (k2; 2 k1 + ri) -> complex [53][12]
+        z = x @ tab                          # [k2][2 t1 + ri]
+        zc = z[:, 0::2] + 1j * z[:, 1::2]    # [k2][t1]
+        return (w12 @ zc).T                  # [t1][t2]
+
+    worst = 0.0
+    for trial in range(trials):
+        xs = []
+        for c in range(2):
+            if trial % 2 == 0:
+                x = rng.standard_normal((K2, 2 * K1)) * rng.choice([1.0, 30.0, 2000.0])
+            else:  # against output (t1, ri): every k2 row carries the sign pattern of that lo column (the 12-point stage adds them at t2 = 0)
+                o = int(rng.integers(0, 2 * K1))
+                x = np.tile(np.sign(lo.astype(np.float64)[:2 * K1, o]), (K2, 1)) * 100.0
+            xs.append(x.astype(np.float16).astype(np.float64))
+        yh = [transform(x, H) for x in xs]
+        yf = [transform(x, F) for x in xs]
+        eh = np.abs(yh[0]) ** 2 + np.abs(yh[1]) ** 2
+        ef = np.abs(yf[0]) ** 2 + np.abs(yf[1]) ** 2
+        margin = 5.0e-4 * np.sqrt(eh.sum())
+        worst = max(worst, float(np.max(np.sqrt(ef) - np.sqrt(eh)) / margin))
+    return worst
+
+
 # ---------------------------------------------------------------------------------------------- 4. the 3125-point rows
 def rows_3125(x):
     """X[t] = sum_k x[k] W^(+k t), W = exp(2 pi j / 3125), on 125 threads as three stages 25 x 5 x 25, decimation in frequency
