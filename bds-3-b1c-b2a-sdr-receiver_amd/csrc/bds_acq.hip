@@ -1288,9 +1288,9 @@ void AcqRun::launch_list(int ncells, Rec *recs, const CellList &cl, int cell0, h
         pfa::RowsArgs ra{(const uint32_t *)a.d_Xs, (const uint32_t *)a.d_Cs, (uint32_t *)a.d_Bw, cl.bin, cl.cs, ncells, gc, pfa};
         hipLaunchKernelGGL(pfa::k_pfa_rows<2>, dim3((unsigned)(pfa::MP * pfa::K2 * chunks)), dim3(pfa::kRowsThreads), rows_lds, s_main, ra);
         if (mid) (void)hipEventRecord(mid, s_main);
-        const int qch = ctx->tune.pfa_qchunk > 0 ? ctx->tune.pfa_qchunk : 4;
-        const long items = (long)((196 + qch - 1) / qch) * qch * ncells;
-        const unsigned cgrid = (unsigned)std::min<long>(items, ctx->tune.pfa_cgrid > 0 ? ctx->tune.pfa_cgrid : 4096);
+        const int qch = ctx->tune.pfa_qchunk > 0 ? ctx->tune.pfa_qchunk : 1;  // (one tile of a cell, then the same tile of the next cell)
+        const long items = (long)((pfa::kTiles + qch - 1) / qch) * qch * ncells;
+        const unsigned cgrid = (unsigned)std::min<long>(items, ctx->tune.pfa_cgrid > 0 ? ctx->tune.pfa_cgrid : 8192);
         pfa::ColsArgs ca{(const uint32_t *)a.d_Bw, a.d_pfa_coef, ncells, w0, w1, so1.cellmax, so1.lb, so1.lb_div, so1.extra, so1.extra_count,
                          so1.extra_cap, cell0, so1.keep, qch, nullptr, nullptr, -1, -1};
         hipLaunchKernelGGL((pfa::k_pfa_cols<2, false>), dim3(cgrid), dim3(pfa::kColsThreads), pfa::kCoefBytes, s_main, ca);

@@ -44,7 +44,15 @@ constexpr int K1 = 53, K2 = 12, K3 = 3125;
 constexpr long NP = (long)K1 * K2 * K3;  // 1 987 500
 constexpr int MP = 27;                   // row pairs (54 rows: one zero row)
 constexpr int NB = 7;                    // output blocks of 16 (106 real outputs -> 112)
-constexpr size_t kCellElems = (size_t)MP * K2 * K3 * 4;  // 4-byte (fp16 complex) elements of a cell in the inter-pass buffer
+// inter-pass buffer of a cell: [tile of 16 lags t3 (196)][row pair mp (27)][k2 (12)][lag in the tile (16)][component 2][row of the pair 2],
+// fp16 complex: a column workgroup's item (16 lags, all 324 (mp, k2)) is ONE contiguous 83 KB block, a (mp, k2, lag) piece 16 bytes.
+// (Round 6 first had [mp][k2][t3 3125]: 50 KB contiguous per row workgroup, but 324 pieces of 64 bytes 50 KB apart per column wave --
+//  columns 1.15 ms per 201 cells against 1.04 with the tiles; the row pass does not notice its 256-byte runs.)
+constexpr int kTileLags = 16, kTiles = (K3 + kTileLags - 1) / kTileLags;
+constexpr size_t kCellElems = (size_t)kTiles * MP * K2 * kTileLags * 4;  // 4-byte (fp16 complex) elements of a cell
+__host__ __device__ constexpr size_t bw_piece(int mp, int k2, int t3) {  // element index of the 4-element piece of (mp, k2, t3) in its cell
+    return (((size_t)(t3 / kTileLags) * MP + mp) * K2 + k2) * (kTileLags * 4) + (size_t)(t3 % kTileLags) * 4;
+}  // 4-byte (fp16 complex) elements of a cell in the inter-pass buffer
 constexpr int kRowsThreads = 256, kColsThreads = 256;
 constexpr int kCoefFrags = NB * 4 * 2;  // B fragments (16 bytes per lane): [nb][ins][hi / lo]
 constexpr size_t kCoefBytes = (size_t)kCoefFrags * 64 * 16;
@@ -274,8 +282,9 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
             }
         }
         // the two rows of the pair meet: after the swap half 0 holds (row 0, row 1) of t'' = e, half 1 of t'' = e + 1
-        const __amdgpu_buffer_rsrc_t dst_rsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(A.Bw + (size_t)cell * kCellElems + ((size_t)mp * K2 + k2) * K3 * 4), 0, K3 * 16, 0x00020000);
+        // (descriptor at the piece of lag 0: a lag's offset is tile * 82 944 + (lag in the tile) * 16 bytes)
+        const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(A.Bw + (size_t)cell * kCellElems + bw_piece(mp, k2, 0)), 0,
+                                                                                   (unsigned)((kCellElems - bw_piece(mp, k2, 0)) * 4), 0x00020000);
 #pragma unroll
         for (int e = 0; e < 25; e += 2) {
             uint32_t P[2], Q[2];
@@ -289,7 +298,8 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
             const int tq = e + half;
             if (live && tq < 25) {  // lag t3 = j + 125 tq
                 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-                __builtin_amdgcn_raw_buffer_store_b128((u4){P[0], Q[0], P[1], Q[1]}, dst_rsrc, (j + 125 * half) * 16, 125 * 16 * e, 0);
+                const int t3s = j + 125 * tq;
+                __builtin_amdgcn_raw_buffer_store_b128((u4){P[0], Q[0], P[1], Q[1]}, dst_rsrc, (int)(bw_piece(0, 0, t3s) * 4), 0, 0);
             }
         }
         PFA_RSYNC();  // region free for the next cell
@@ -380,11 +390,12 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
     __syncthreads();
     const int ai = lane & 15, g = ai >> 2, r = ai & 3, ks = lane >> 4;
     const float sgn = (lane & 1) ? 1.f : -1.f;
-    constexpr int kBlocks = (K3 + 15) / 16;  // 196 blocks of 16 lags t3 per cell
-    const int qch = A.qchunk > 0 ? A.qchunk : 4, nq = (kBlocks + qch - 1) / qch;
+    constexpr int kBlocks = kTiles;  // 196 blocks of 16 lags t3 per cell = the tiles of the inter-pass buffer
+    const int qch = A.qchunk > 0 ? A.qchunk : 1, nq = (kBlocks + qch - 1) / qch;
     const long n_items = (long)nq * A.ncells * qch;
-    // work list: qch adjacent blocks of one cell (1 KB of every buffer row), then the same blocks of the NEXT cell: the workgroups
-    // that run together work on different cells, so a cell's running maximum is settled by its first few waves
+    // work list: qch adjacent tiles of one cell (83 KB each, contiguous), then the same tiles of the NEXT cell: the workgroups that run
+    // together work on different cells, so a cell's running maximum is settled by its first few waves (qch = 1: 2.4 % of the wave items go
+    // through the values' pass, 4: 3.0 %, 8: 3.8 %)
     for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int b = (int)(item % qch), cl = (int)((item / qch) % A.ncells), q = (int)(item / ((long)qch * A.ncells));
         const int blk = q * qch + b;
@@ -402,9 +413,9 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
             for (int ins = 0; ins < 4; ++ins) {
                 const int mg = 4 * ins + ks;
                 uint4 l0 = make_uint4(0, 0, 0, 0), l1 = l0;
-                const size_t off = ((size_t)(4 * quad + r) * K3 + t3) * 4;
-                if (2 * mg < MP) l0 = *reinterpret_cast<const uint4 *>(base + (size_t)(2 * mg) * K2 * K3 * 4 + off);
-                if (2 * mg + 1 < MP) l1 = *reinterpret_cast<const uint4 *>(base + (size_t)(2 * mg + 1) * K2 * K3 * 4 + off);
+                const size_t off = bw_piece(0, 4 * quad + r, t3);
+                if (2 * mg < MP) l0 = *reinterpret_cast<const uint4 *>(base + (size_t)(2 * mg) * K2 * (kTileLags * 4) + off);
+                if (2 * mg + 1 < MP) l1 = *reinterpret_cast<const uint4 *>(base + (size_t)(2 * mg + 1) * K2 * (kTileLags * 4) + off);
                 fa[0][quad][ins] = make_uint4(l0.x, l0.y, l1.x, l1.y);
                 fa[1][quad][ins] = make_uint4(l0.z, l0.w, l1.z, l1.w);
             }

@@ -166,7 +166,7 @@ int main(int argc, char **argv) {
                 cd ref = 0;
                 if (k1 < K1)
                     for (int k3 = 0; k3 < K3; ++k3) ref += Ycrt(cell, comp, k1, k2, k3) * std::polar(1.0, 2 * M_PI * (double)(((long)k3 * t3) % K3) / K3);
-                const cd got = unpack(Bw[(size_t)cell * kCellElems + ((((size_t)(k1 / 2) * K2 + k2) * K3 + t3) * 2 + comp) * 2 + (k1 & 1)]);
+                const cd got = unpack(Bw[(size_t)cell * kCellElems + bw_piece(k1 / 2, k2, t3) + comp * 2 + (k1 & 1)]);
                 worst_rows = std::max(worst_rows, std::abs(got - ref));
                 rms_rows += std::norm(ref);
                 ++nchk;
@@ -176,8 +176,12 @@ int main(int argc, char **argv) {
     printf("row pass: %ld sampled outputs of %d cells: worst |error| %.3g against an rms output of %.3g (%.2e; fp16 rounding is 4.9e-4 of a value)\n", nchk, ncell_t,
            worst_rows, rms_rows, worst_rows / rms_rows);
     size_t nan_left = 0;
-    for (size_t i = 0; i < Bw.size(); ++i) nan_left += Bw[i] == 0xffffffffu;
-    printf("          elements of the inter-pass buffer never written: %zu of %zu\n", nan_left, Bw.size());
+    for (int cell = 0; cell < ncell_t; ++cell)
+        for (int mp = 0; mp < MP; ++mp)
+            for (int k2 = 0; k2 < K2; ++k2)
+                for (int t3 = 0; t3 < K3; ++t3)
+                    for (int e = 0; e < 4; ++e) nan_left += Bw[(size_t)cell * kCellElems + bw_piece(mp, k2, t3) + e] == 0xffffffffu;
+    printf("          elements of the inter-pass buffer never written: %zu of %zu\n", nan_left, (size_t)ncell_t * MP * K2 * K3 * 4);
 
     // column pass on the GPU's own buffer, one (cell, t3 group) at a time in debug mode
     double worst_cols = 0, worst_e2e = 0, big = 0;
@@ -201,7 +205,7 @@ int main(int argc, char **argv) {
                             cd y = 0;
                             for (int k1 = 0; k1 < K1; ++k1)
                                 for (int k2 = 0; k2 < K2; ++k2)
-                                    y += unpack(Bw[(size_t)cell * kCellElems + ((((size_t)(k1 / 2) * K2 + k2) * K3 + t3) * 2 + comp) * 2 + (k1 & 1)]) *
+                                    y += unpack(Bw[(size_t)cell * kCellElems + bw_piece(k1 / 2, k2, t3) + comp * 2 + (k1 & 1)]) *
                                          std::polar(1.0, 2 * M_PI * ((double)((k1 * t1) % K1) / K1 + (double)((k2 * t2) % K2) / K2));
                             const double got = dbg[((comp * K1 + t1) * 12 + t2) * 4 + g];
                             worst_cols = std::max(worst_cols, std::abs(got - std::norm(y)));
@@ -246,7 +250,7 @@ int main(int argc, char **argv) {
                 for (int comp = 0; comp < 2; ++comp)
                     for (int k1 = 0; k1 < K1; ++k1)
                         for (int k2 = 0; k2 < K2; ++k2)
-                            z[((size_t)comp * K1 + k1) * K2 + k2] = unpack(Bw[(size_t)cell * kCellElems + ((((size_t)(k1 / 2) * K2 + k2) * K3 + t3) * 2 + comp) * 2 + (k1 & 1)]);
+                            z[((size_t)comp * K1 + k1) * K2 + k2] = unpack(Bw[(size_t)cell * kCellElems + bw_piece(k1 / 2, k2, t3) + comp * 2 + (k1 & 1)]);
                 for (int comp = 0; comp < 2; ++comp)  // 53 points over k1
                     for (int t1 = 0; t1 < K1; ++t1)
                         for (int k2 = 0; k2 < K2; ++k2) {
@@ -293,11 +297,11 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     CK(hipEventCreate(&e2));
-    for (int gc : {201, 67}) {
+    for (int gc : {67}) {
         RowsArgs rt{d_Xs, d_Cs, d_Bw, d_bin, d_cs, ncells, gc, 1};
         const int chunks = (ncells + gc - 1) / gc;
-        for (int cgrid : {2048, 4096})
-        for (int qch : {4, 196}) {
+        for (int cgrid : {2048, 4096, 8192})
+        for (int qch : {1, 2, 4, 8}) {
             float best_r = 1e9f, best_c = 1e9f;
             for (int rep = 0; rep <= reps; ++rep) {  // the last repetition counts the passes (one atomic per wave item: not timed)
                 const bool counting = rep == reps;
