@@ -299,7 +299,11 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
             if (live && tq < 25) {  // lag t3 = j + 125 tq
                 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
                 const int t3s = j + 125 * tq;
+#ifdef PFA_EXP_R_NOSTORE
+                asm volatile("" ::"v"(P[0]), "v"(Q[0]), "v"(P[1]), "v"(Q[1]), "v"(t3s));
+#else
                 __builtin_amdgcn_raw_buffer_store_b128((u4){P[0], Q[0], P[1], Q[1]}, dst_rsrc, (int)(bw_piece(0, 0, t3s) * 4), 0, 0);
+#endif
             }
         }
         PFA_RSYNC();  // region free for the next cell
@@ -389,7 +393,8 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
     for (int i = tid; i < kCoefFrags * 64; i += kColsThreads) s_coef[i] = A.coef[i];
     __syncthreads();
     const int ai = lane & 15, g = ai >> 2, r = ai & 3, ks = lane >> 4;
-    const float sgn = (lane & 1) ? 1.f : -1.f;
+    const bool odd = lane & 1;
+    auto t2_of = [&](int i) { return odd ? (i == 0 ? 6 : 12 - i) : i; };  // the output t2 behind slot i of this lane
     constexpr int kBlocks = kTiles;  // 196 blocks of 16 lags t3 per cell = the tiles of the inter-pass buffer
     const int qch = A.qchunk > 0 ? A.qchunk : 1, nq = (kBlocks + qch - 1) / qch;
     const long n_items = (long)nq * A.ncells * qch;
@@ -414,6 +419,10 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                 const int mg = 4 * ins + ks;
                 uint4 l0 = make_uint4(0, 0, 0, 0), l1 = l0;
                 const size_t off = bw_piece(0, 4 * quad + r, t3);
+#ifdef PFA_EXP_C_NOLOAD
+                l0 = make_uint4(0x3c003800u + lane, 0x38003c00u + (unsigned)item, 0x3c003400u + quad, 0x34003c00u + ins), l1 = l0;
+                if (false)
+#endif
                 if (2 * mg < MP) l0 = *reinterpret_cast<const uint4 *>(base + (size_t)(2 * mg) * K2 * (kTileLags * 4) + off);
                 if (2 * mg + 1 < MP) l1 = *reinterpret_cast<const uint4 *>(base + (size_t)(2 * mg + 1) * K2 * (kTileLags * 4) + off);
                 fa[0][quad][ins] = make_uint4(l0.x, l0.y, l1.x, l1.y);
@@ -422,8 +431,9 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
         // the cell's maximum so far and the PRN's running bound; stale values are lower values: a redundant visit of the exact pass
         const float lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
-        // |y|^2 of output block nb: m2[c][t2] for the lane's (t1, t3); both lanes of a pair hold all twelve
-        auto block = [&](int nb, float (&m2)[2][12], auto parts_tag) {
+        // |y|^2 of output block nb: m2[c][i] for the lane's (t1, t3) -- each output in ONE lane of its (re, im) pair: the even lane holds
+        // t2 = 0, 1, .., 5 (i = t2), the odd lane t2 = 6, 11, 10, .., 7 (i = 0, 1, .., 5: t2 = 12 - i)
+        auto block = [&](int nb, float (&m2)[2][6], auto parts_tag) {
             constexpr int PARTS = decltype(parts_tag)::value;  // 2: coefficients hi + lo (the values), 1: hi only (the bound pass)
             uint4 fb[4][2];
 #pragma unroll
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                 const f4(&acc)[3] = acc2[c];
 #ifdef PFA_EXP_C_NOEPI
 #pragma unroll
-                for (int t = 0; t < 12; ++t) m2[c][t] = acc[t >> 2][t & 3];
+                for (int t = 0; t < 6; ++t) m2[c][t] = acc[t >> 1][t & 1] + acc[t >> 1][2 + (t & 1)];
                 continue;
 #endif
                 // lane (G = lane >> 4, o = lane & 15): acc[quad][rr] = row 4 G + rr <-> (t3 = t0 + G, k2 = 4 quad + rr) of output 16 nb + o
@@ -465,20 +475,26 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
 #pragma unroll
                 for (int k = 0; k < 12; ++k) v[k] = acc[k >> 2][k & 3];
                 real_dft12(v, P, Q);
-                // the lane pair (o even: re part of z, o odd: im part): y[t] = A[t] + j B[t] -> even lane: re y = P - Q', odd lane: im y = P + Q'
-                float rr[12];
-                rr[0] = P[0], rr[6] = P[6];
-#pragma unroll
-                for (int t = 1; t < 6; ++t) {
-                    const float qp = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, Q[t]), 0xB1, 0xf, 0xf, true));
-                    rr[t] = fmaf(sgn, qp, P[t]);
-                    rr[12 - t] = fmaf(-sgn, qp, P[t]);
+                // the lane pair (o even: the real part of z, o odd: the imaginary part) holds A = DFT12(re z) = P_e + j Q_e and B = DFT12(im z) =
+                // P_o + j Q_o, and y[t] = A[t] + j B[t], y[12 - t] = conj(A[t]) + j conj(B[t]):
+                //   |y[t]|^2 = S + X, |y[12 - t]|^2 = S - X with S = P_e^2 + Q_e^2 + P_o^2 + Q_o^2, X = 2 (Q_e P_o - P_e Q_o).
+                // With x = Q P' - P Q' (' = the partner lane's) the even lane's S + 2 x is |y[t]|^2 and the odd lane's is |y[12 - t]|^2: six
+                // instructions per t and pair of outputs, each output formed once (the first form squared re y and im y in both lanes).
+                // (the compiler keeps a v_mov_b32_dpp in front of each of these; the 17 DPP-operand adds / products of a component issued by
+                //  hand -- 34 instructions fewer per output block -- measured the same 0.96 ms: the kernel waits on latency, HISTORY.md 8)
+                auto partner = [](float a) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xf, 0xf, true)); };
+                {
+                    const float p0 = P[0] * P[0], p6 = P[6] * P[6];  // Q[0] = Q[6] = 0
+                    const float S0 = p0 + partner(p0), S6 = p6 + partner(p6);
+                    m2[c][0] = odd ? S6 : S0;
                 }
 #pragma unroll
-                for (int t = 0; t < 12; ++t) {
-                    const float sq = rr[t] * rr[t];
-                    const float sp = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sq), 0xB1, 0xf, 0xf, true));
-                    m2[c][t] = sq + sp;
+                for (int t = 1; t < 6; ++t) {
+                    const float sl = fmaf(Q[t], Q[t], P[t] * P[t]);
+                    const float S = sl + partner(sl);
+                    float x = partner(P[t]) * Q[t];
+                    x = fmaf(-partner(Q[t]), P[t], x);
+                    m2[c][t] = fmaf(2.f, x, S);
                 }
             }
         };
@@ -486,21 +502,21 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
         constexpr int kParts1 = DBG ? 2 : kBoundParts;  // (the debug instantiation reports this pass's values: both parts)
         float best = 0.f, ssum = 0.f;
         for (int nb = 0; nb < NB; ++nb) {
-            float m2[2][12];
+            float m2[2][6];
             block(nb, m2, std::integral_constant<int, kParts1>{});
             const int t1 = (16 * nb + (lane & 15)) >> 1;
             if (t1 < K1 && t3o < K3) {
 #pragma unroll
-                for (int t = 0; t < 12; ++t) {
-                    const float e = NC == 2 ? m2[0][t] + m2[1][t] : m2[0][t];
+                for (int i = 0; i < 6; ++i) {
+                    const float e = NC == 2 ? m2[0][i] + m2[1][i] : m2[0][i];
                     best = fmaxf(best, e), ssum += e;
                 }
             }
-            if (DBG && cell == A.dbg_cell && t0 / 4 == A.dbg_group && t1 < K1 && !(lane & 1)) {
+            if (DBG && cell == A.dbg_cell && t0 / 4 == A.dbg_group && t1 < K1) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
 #pragma unroll
-                    for (int t = 0; t < 12; ++t) A.dbg[((c * K1 + t1) * 12 + t) * 4 + (lane >> 4)] = m2[c][t];
+                    for (int i = 0; i < 6; ++i) A.dbg[((c * K1 + t1) * 12 + t2_of(i)) * 4 + (lane >> 4)] = m2[c][i];
             }
         }
         if (A.stats && lane == 0) atomicAdd(A.stats, 1ull);
@@ -515,33 +531,36 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
             // <= 2^-11 sqrt(636) ||x||_2 over the 636 inputs of a lag t3, and ||x||_2 <= ||y_hi||_2 / (sqrt(636) - ||T_lo||) with
             // ||T_lo|| <= sqrt(12) * 53 * 2^-11.5 = 0.063: delta_c <= 4.9e-4 sqrt(sum over the lag's 636 outputs of |y_hi,c|^2), and by
             // Minkowski sqrt(|y_d|^2 + |y_p|^2) grows by at most sqrt(delta_d^2 + delta_p^2) = 4.9e-4 sqrt(sum of what `best` is the max of).
-            float s16 = ssum;  // the 16 lanes of a lag; the two lanes of a pair hold the same twelve values: half the sum
+            float s16 = ssum;  // the 16 lanes of a lag
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) s16 += __shfl_xor(s16, o);
-            ub += 5.0e-4f * sqrtf(0.5f * s16);
+            ub += 5.0e-4f * sqrtf(s16);
         }
         ub = wave_max_f32(ub);
         const float bw = ub * ub * wsum2 * 1.00001f;
         const float curv = __uint_as_float(cur), lim = fminf(curv, lbv * A.keep);
-        if (!(bw < lim * lim)) {  // (wave-uniform; also taken while the bounds are unset or not finite)
+#if defined(PFA_EXP_C_NOEXACT) || defined(PFA_EXP_C_NOMFMA) || defined(PFA_EXP_C_NOEPI) || defined(PFA_EXP_C_NOLOAD) || defined(PFA_EXP_R_NOLOAD) || defined(PFA_EXP_R_NOSTORE)
+        if (bw < 0.f)  // (timing experiments on invalid data: the bound pass alone)
+#else
+        if (!(bw < lim * lim))  // (wave-uniform; also taken while the bounds are unset or not finite)
+#endif
+        {
             if (A.stats && lane == 0) atomicAdd(A.stats + 1, 1ull);
-            // -- each output owned by ONE lane of its pair (even lane: t2 = 0..5, odd lane: t2 = 6..11); a lane keeps its two largest
-            // values with their lags (first lag on ties, like max()).  Two qualifying values in one lane's 42 outputs are the rare case of
-            // the rare case: then a third pass lists exhaustively.
-            const int th = (lane & 1) * 6;
+            // -- a lane keeps the two largest of its values with their lags (first lag on ties, like max()).  Two qualifying values in one
+            // lane's 42 outputs are the rare case of the rare case: then a third pass lists exhaustively.
             float top1 = -1.f, top2 = -1.f;
             int lag1 = 0x7fffffff, lag2 = 0x7fffffff;
             for (int nb = 0; nb < NB; ++nb) {
-                float m2[2][12];
+                float m2[2][6];
                 block(nb, m2, std::integral_constant<int, 2>{});
                 const int t1 = (16 * nb + (lane & 15)) >> 1;
                 if (t1 < K1 && t3o < K3) {
 #pragma unroll
-                    for (int t = 0; t < 12; ++t) {
-                        if ((t >= 6) != (th == 6)) continue;
-                        float a = A.w0 * __builtin_amdgcn_sqrtf(m2[0][t]);  // raw v_sqrt_f32 (1 ulp): the value only feeds the sieve
-                        if (NC > 1) a += A.w1 * __builtin_amdgcn_sqrtf(m2[NC - 1][t]);
-                        const int lag = (int)lag_of(t1, t, t3o);
+                    for (int i = 0; i < 6; ++i) {
+                        // raw v_sqrt_f32 (1 ulp): the value only feeds the sieve; S + 2 x of a vanishing output may come out below zero
+                        float a = A.w0 * __builtin_amdgcn_sqrtf(fmaxf(m2[0][i], 0.f));
+                        if (NC > 1) a += A.w1 * __builtin_amdgcn_sqrtf(fmaxf(m2[NC - 1][i], 0.f));
+                        const int lag = (int)lag_of(t1, t2_of(i), t3o);
                         if (a > top1 || (a == top1 && lag < lag1)) {
                             top2 = top1, lag2 = lag1, top1 = a, lag1 = lag;
                         } else if (a > top2 || (a == top2 && lag < lag2)) {
@@ -574,16 +593,16 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                     } else {
                         if (A.stats && lane == 0) atomicAdd(A.stats + 2, 1ull);
                         for (int nb = 0; nb < NB; ++nb) {
-                            float m2[2][12];
+                            float m2[2][6];
                             block(nb, m2, std::integral_constant<int, 2>{});
                             const int t1 = (16 * nb + (lane & 15)) >> 1;
                             const bool mine = t1 < K1 && t3o < K3;
 #pragma unroll
-                            for (int t = 0; t < 12; ++t) {
+                            for (int i = 0; i < 6; ++i) {
                                 float a = -1.f;
-                                if (mine && ((t >= 6) == (th == 6))) {
-                                    a = A.w0 * __builtin_amdgcn_sqrtf(m2[0][t]);
-                                    if (NC > 1) a += A.w1 * __builtin_amdgcn_sqrtf(m2[NC - 1][t]);
+                                if (mine) {
+                                    a = A.w0 * __builtin_amdgcn_sqrtf(fmaxf(m2[0][i], 0.f));
+                                    if (NC > 1) a += A.w1 * __builtin_amdgcn_sqrtf(fmaxf(m2[NC - 1][i], 0.f));
                                 }
                                 const unsigned long long mask = __builtin_amdgcn_ballot_w64(a >= thr);
                                 if (mask) {  // (wave-uniform)
@@ -594,7 +613,7 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                                         const int idx = base_i + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                                         if ((unsigned)idx < (unsigned)A.extra_cap) {  // (unsigned: a counter run over 2^31 must not index backwards)
                                             Extra ex;
-                                            ex.v = a, ex.lag = (int)lag_of(t1, t, t3o), ex.cell = cell;
+                                            ex.v = a, ex.lag = (int)lag_of(t1, t2_of(i), t3o), ex.cell = cell;
                                             A.extra[idx] = ex;
                                         }
                                     }

@@ -3,7 +3,7 @@
 # (csrc/bds_acq_pfa.h, PFA_EXP_*: results INVALID, timing only).  Build here (no GPU needed), run on the GPU box:
 #   tools/exp/r6_pfa_parts.sh build ; gpurun -- tools/exp/r6_pfa_parts.sh run > profiles/r06_pfa53_parts.txt
 cd "$(dirname "$0")/../.."
-VARS="base C_NOMFMA C_NOEPI R_NOLOAD R_NOBAR"
+VARS="base C_NOEXACT C_NOMFMA C_NOEPI C_NOLOAD R_NOLOAD R_NOSTORE R_NOBAR"
 if [ "$1" = build ]; then
     for v in $VARS; do
         d=""; [ $v != base ] && d="-DPFA_EXP_$v"

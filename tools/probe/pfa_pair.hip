@@ -300,8 +300,8 @@ int main(int argc, char **argv) {
     for (int gc : {67}) {
         RowsArgs rt{d_Xs, d_Cs, d_Bw, d_bin, d_cs, ncells, gc, 1};
         const int chunks = (ncells + gc - 1) / gc;
-        for (int cgrid : {2048, 4096, 8192})
-        for (int qch : {1, 2, 4, 8}) {
+        for (int cgrid : {4096, 8192})
+        for (int qch : {4, 1}) {
             float best_r = 1e9f, best_c = 1e9f;
             for (int rep = 0; rep <= reps; ++rep) {  // the last repetition counts the passes (one atomic per wave item: not timed)
                 const bool counting = rep == reps;
