@@ -1284,7 +1284,7 @@ void AcqRun::launch_list(int ncells, Rec *recs, const CellList &cl, int cell0, h
     if (pfa) {  // the N-point pair (bds_acq_pfa.h): every lag of the N is searched, the cells come as a list
         const int gc = std::max(1, cl.gc), chunks = (ncells + gc - 1) / gc;
         const size_t rows_lds = 2 * 3136 * sizeof(float2);
-        want_lds(ctx, pfa::k_pfa_cols<2, false>, pfa::kCoefBytes);
+        want_lds(ctx, pfa::k_pfa_cols<2, false>, pfa::kColsLds);
         pfa::RowsArgs ra{(const uint32_t *)a.d_Xs, (const uint32_t *)a.d_Cs, (uint32_t *)a.d_Bw, cl.bin, cl.cs, ncells, gc, pfa};
         hipLaunchKernelGGL(pfa::k_pfa_rows<2>, dim3((unsigned)(pfa::MP * pfa::K2 * chunks)), dim3(pfa::kRowsThreads), rows_lds, s_main, ra);
         if (mid) (void)hipEventRecord(mid, s_main);
@@ -1293,7 +1293,7 @@ void AcqRun::launch_list(int ncells, Rec *recs, const CellList &cl, int cell0, h
         const unsigned cgrid = (unsigned)std::min<long>(items, ctx->tune.pfa_cgrid > 0 ? ctx->tune.pfa_cgrid : 8192);
         pfa::ColsArgs ca{(const uint32_t *)a.d_Bw, a.d_pfa_coef, ncells, w0, w1, so1.cellmax, so1.lb, so1.lb_div, so1.extra, so1.extra_count,
                          so1.extra_cap, cell0, so1.keep, qch, nullptr, nullptr, -1, -1};
-        hipLaunchKernelGGL((pfa::k_pfa_cols<2, false>), dim3(cgrid), dim3(pfa::kColsThreads), pfa::kCoefBytes, s_main, ca);
+        hipLaunchKernelGGL((pfa::k_pfa_cols<2, false>), dim3(cgrid), dim3(pfa::kColsThreads), pfa::kColsLds, s_main, ca);
         return;
     }
     if (a.half) {

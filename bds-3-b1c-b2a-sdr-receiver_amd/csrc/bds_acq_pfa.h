@@ -56,6 +56,7 @@ __host__ __device__ constexpr size_t bw_piece(int mp, int k2, int t3) {  // elem
 constexpr int kRowsThreads = 256, kColsThreads = 256;
 constexpr int kCoefFrags = NB * 4 * 2;  // B fragments (16 bytes per lane): [nb][ins][hi / lo]
 constexpr size_t kCoefBytes = (size_t)kCoefFrags * 64 * 16;
+constexpr size_t kColsLds = kCoefBytes + (size_t)NB * kColsThreads * 4;  // + the lanes' maxima per output block (the values' pass visits flagged blocks only)
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -355,7 +356,7 @@ struct ColsArgs {
     int cell0;                    // run-wide index of cell 0 of this launch
     float keep;                   // 1 - tolerance of the sieve
     int qchunk;                   // blocks of 16 lags of a cell that follow each other in the work list
-    unsigned long long *stats;    // optional (probe): [0] wave items, [1] of them through the exact pass, [2] through the exhaustive pass
+    unsigned long long *stats;    // optional (probe): [0] wave items, [1] of them through the values' pass, [2] through the exhaustive pass, [3] output blocks the values' pass visited
     float *dbg;                   // optional: |y_d|^2, |y_p|^2 of one (cell, t3 group): [2][53][12][4]
     int dbg_cell, dbg_group;
 };
@@ -389,6 +390,7 @@ template <int NC, bool DBG>
 __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
     extern __shared__ __align__(16) unsigned char pfa_lds[];
     uint4 *s_coef = reinterpret_cast<uint4 *>(pfa_lds);
+    float *s_bm = reinterpret_cast<float *>(pfa_lds + kCoefBytes);  // [output block][thread]: the lane's largest |y_d|^2 + |y_p|^2 of the block
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < kCoefFrags * 64; i += kColsThreads) s_coef[i] = A.coef[i];
     __syncthreads();
@@ -505,13 +507,16 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
             float m2[2][6];
             block(nb, m2, std::integral_constant<int, kParts1>{});
             const int t1 = (16 * nb + (lane & 15)) >> 1;
+            float bmax = 0.f;
             if (t1 < K1 && t3o < K3) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     const float e = NC == 2 ? m2[0][i] + m2[1][i] : m2[0][i];
-                    best = fmaxf(best, e), ssum += e;
+                    bmax = fmaxf(bmax, e), ssum += e;
                 }
             }
+            best = fmaxf(best, bmax);
+            s_bm[nb * kColsThreads + tid] = bmax;  // (read back by this lane only, in the rare values' pass)
             if (DBG && cell == A.dbg_cell && t0 / 4 == A.dbg_group && t1 < K1) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
         // outputs, stays below both the cell's maximum so far and the sieve threshold of the PRN's running bound, the wave has nothing
         // to report (bds_acq_wcols.h).  Otherwise the exact values: the outputs are recomputed (they were never all in registers) --
         const float wsum2 = NC > 1 ? A.w0 * A.w0 + A.w1 * A.w1 : A.w0 * A.w0;
-        float ub = sqrtf(best);
+        float dlt = 0.f;  // what the values' pass may add to sqrt(|y_d|^2 + |y_p|^2) of this lane's outputs
         if (kParts1 == 1) {
             // the bound pass multiplies by fp16(coefficient) only (half the matrix work).  What the values' pass adds, per component:
             // |sum x lo| <= 2^-11 ||x||_1 (|lo| <= 2^-12 per real entry of the rotation), through the exact 12-point stage
@@ -534,9 +539,9 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
             float s16 = ssum;  // the 16 lanes of a lag
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) s16 += __shfl_xor(s16, o);
-            ub += 5.0e-4f * sqrtf(s16);
+            dlt = 5.0e-4f * sqrtf(s16);
         }
-        ub = wave_max_f32(ub);
+        const float ub = wave_max_f32(sqrtf(best) + dlt);
         const float bw = ub * ub * wsum2 * 1.00001f;
         const float curv = __uint_as_float(cur), lim = fminf(curv, lbv * A.keep);
 #if defined(PFA_EXP_C_NOEXACT) || defined(PFA_EXP_C_NOMFMA) || defined(PFA_EXP_C_NOEPI) || defined(PFA_EXP_C_NOLOAD) || defined(PFA_EXP_R_NOLOAD) || defined(PFA_EXP_R_NOSTORE)
@@ -546,11 +551,21 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
 #endif
         {
             if (A.stats && lane == 0) atomicAdd(A.stats + 1, 1ull);
+            // -- only the output blocks in which some lane's bound reaches the limit (the same expression per lane and block as the wave's test
+            // above: the block that failed it is among them); every output of the other blocks is below the cell's maximum so far and
+            // below the list's threshold.  Typically one block of the seven.
+            unsigned fmask = 0;
+            for (int nb = 0; nb < NB; ++nb) {
+                const float u = sqrtf(s_bm[nb * kColsThreads + tid]) + dlt;
+                if (__builtin_amdgcn_ballot_w64(!(u * u * wsum2 * 1.00001f < lim * lim))) fmask |= 1u << nb;
+            }
+            if (A.stats && lane == 0) atomicAdd(A.stats + 3, (unsigned long long)__builtin_popcount(fmask));
             // -- a lane keeps the two largest of its values with their lags (first lag on ties, like max()).  Two qualifying values in one
             // lane's 42 outputs are the rare case of the rare case: then a third pass lists exhaustively.
             float top1 = -1.f, top2 = -1.f;
             int lag1 = 0x7fffffff, lag2 = 0x7fffffff;
             for (int nb = 0; nb < NB; ++nb) {
+                if (!((fmask >> nb) & 1)) continue;
                 float m2[2][6];
                 block(nb, m2, std::integral_constant<int, 2>{});
                 const int t1 = (16 * nb + (lane & 15)) >> 1;
@@ -593,6 +608,7 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                     } else {
                         if (A.stats && lane == 0) atomicAdd(A.stats + 2, 1ull);
                         for (int nb = 0; nb < NB; ++nb) {
+                            if (!((fmask >> nb) & 1)) continue;
                             float m2[2][6];
                             block(nb, m2, std::integral_constant<int, 2>{});
                             const int t1 = (16 * nb + (lane & 15)) >> 1;

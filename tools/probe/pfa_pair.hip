@@ -138,8 +138,8 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(d_coef, cf.data(), kCoefBytes, hipMemcpyHostToDevice));
     }
     const size_t rows_lds = 2 * 3136 * sizeof(float2);
-    CK(hipFuncSetAttribute((const void *)k_pfa_cols<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoefBytes));
-    CK(hipFuncSetAttribute((const void *)k_pfa_cols<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoefBytes));
+    CK(hipFuncSetAttribute((const void *)k_pfa_cols<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColsLds));
+    CK(hipFuncSetAttribute((const void *)k_pfa_cols<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kColsLds));
 
     // ---------------- correctness: each test cell is its own one-cell chunk (gc = 1: the PRN slot changes from cell to cell)
     for (int i = 0; i < ncell_t; ++i) h_bin[i] = tb[i], h_cs[i] = (long)tslot[i] * 2 * NP;
@@ -192,7 +192,7 @@ int main(int argc, char **argv) {
             CK(hipMemset(d_extra_count, 0, sizeof(int)));
             CK(hipMemset(d_dbg, 0, sizeof(float) * 2 * K1 * 12 * 4));
             ColsArgs ca{d_Bw, d_coef, ncell_t, 0.52440442f, 0.85146932f, d_cellmax, d_lb, 1, d_extra, d_extra_count, extra_cap, 0, 0.996f, 4, nullptr, d_dbg, cell, grp};
-            hipLaunchKernelGGL((k_pfa_cols<2, true>), dim3(512), dim3(kColsThreads), kCoefBytes, 0, ca);
+            hipLaunchKernelGGL((k_pfa_cols<2, true>), dim3(512), dim3(kColsThreads), kColsLds, 0, ca);
             CK(hipDeviceSynchronize());
             std::vector<float> dbg(2 * K1 * 12 * 4);
             CK(hipMemcpy(dbg.data(), d_dbg, dbg.size() * 4, hipMemcpyDeviceToHost));
@@ -313,7 +313,7 @@ int main(int argc, char **argv) {
                 CK(hipEventRecord(e0));
                 hipLaunchKernelGGL(k_pfa_rows<2>, dim3(MP * K2 * chunks), dim3(kRowsThreads), rows_lds, 0, rt);
                 CK(hipEventRecord(e1));
-                hipLaunchKernelGGL((k_pfa_cols<2, false>), dim3(cgrid), dim3(kColsThreads), kCoefBytes, 0, ct);
+                hipLaunchKernelGGL((k_pfa_cols<2, false>), dim3(cgrid), dim3(kColsThreads), kColsLds, 0, ct);
                 CK(hipEventRecord(e2));
                 CK(hipDeviceSynchronize());
                 float mr, mc;
@@ -325,9 +325,10 @@ int main(int argc, char **argv) {
             int n_ex = 0;
             CK(hipMemcpy(st, d_stats, sizeof(st), hipMemcpyDeviceToHost));
             CK(hipMemcpy(&n_ex, d_extra_count, sizeof(int), hipMemcpyDeviceToHost));
-            printf("timing: %d PRNs x %d bins, %d-cell row workgroups, column grid %d, %d-block chunks: rows %.3f ms + columns %.3f ms per 201 cells = %.3f ms  (L-point pair of round 5: 3.0 - 3.1 ms); "
-                   "%llu wave items, %llu through the exact pass (%.2f %%), %llu exhaustive, %d list entries\n",
-                   prns, D, gc, cgrid, qch, best_r / prns, best_c / prns, (best_r + best_c) / prns, st[0], st[1], 100.0 * st[1] / std::max(1ull, st[0]), st[2], n_ex);
+            printf("timing: %d PRNs x %d bins, %d-cell row workgroups, column grid %d, %d-block chunks: rows %.3f ms + columns %.3f ms per 201 cells = %.3f ms  "
+                   "%llu wave items, %llu through the values' pass (%.2f %%; %.2f of 7 output blocks each), %llu exhaustive, %d list entries\n",
+                   prns, D, gc, cgrid, qch, best_r / prns, best_c / prns, (best_r + best_c) / prns, st[0], st[1], 100.0 * st[1] / std::max(1ull, st[0]),
+                   (double)st[3] / std::max(1ull, st[1]), st[2], n_ex);
         }
     }
     return 0;
