@@ -218,14 +218,16 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
             for (int q = 0; q < 25; q += 5) {
                 uint32_t xs[5], xc[5];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) xs[i] = __builtin_amdgcn_alignbit(xn[q + i], xn[q + i], 16), xc[i] = xn[q + i] ^ 0x80000000u;
+                for (int i = 0; i < 5; ++i) xs[i] = __builtin_amdgcn_alignbit(xn[q + i], xn[q + i], 16), xc[i] = xn[q + i];
                 float re[5], im[5];
+                // (neg_hi on the signal word: (xr, -xi) without an xor per point -- the dot instructions take neg_lo / neg_hi, not op_sel,
+                //  so the swapped word of the imaginary part is still prepared: tools/probe/dot2_mods.hip)
                 asm volatile(
-                    "v_dot2_f32_f16 %0, %10, %20, 0\n v_dot2_f32_f16 %5, %15, %20, 0\n"
-                    "v_dot2_f32_f16 %1, %11, %21, 0\n v_dot2_f32_f16 %6, %16, %21, 0\n"
-                    "v_dot2_f32_f16 %2, %12, %22, 0\n v_dot2_f32_f16 %7, %17, %22, 0\n"
-                    "v_dot2_f32_f16 %3, %13, %23, 0\n v_dot2_f32_f16 %8, %18, %23, 0\n"
-                    "v_dot2_f32_f16 %4, %14, %24, 0\n v_dot2_f32_f16 %9, %19, %24, 0\n s_nop 2"
+                    "v_dot2_f32_f16 %0, %10, %20, 0 neg_hi:[1,0,0]\n v_dot2_f32_f16 %5, %15, %20, 0\n"
+                    "v_dot2_f32_f16 %1, %11, %21, 0 neg_hi:[1,0,0]\n v_dot2_f32_f16 %6, %16, %21, 0\n"
+                    "v_dot2_f32_f16 %2, %12, %22, 0 neg_hi:[1,0,0]\n v_dot2_f32_f16 %7, %17, %22, 0\n"
+                    "v_dot2_f32_f16 %3, %13, %23, 0 neg_hi:[1,0,0]\n v_dot2_f32_f16 %8, %18, %23, 0\n"
+                    "v_dot2_f32_f16 %4, %14, %24, 0 neg_hi:[1,0,0]\n v_dot2_f32_f16 %9, %19, %24, 0\n s_nop 2"
                     : "=&v"(re[0]), "=&v"(re[1]), "=&v"(re[2]), "=&v"(re[3]), "=&v"(re[4]), "=&v"(im[0]), "=&v"(im[1]), "=&v"(im[2]), "=&v"(im[3]), "=&v"(im[4])
                     : "v"(xc[0]), "v"(xc[1]), "v"(xc[2]), "v"(xc[3]), "v"(xc[4]), "v"(xs[0]), "v"(xs[1]), "v"(xs[2]), "v"(xs[3]), "v"(xs[4]),
                       "v"(cv[c][q]), "v"(cv[c][q + 1]), "v"(cv[c][q + 2]), "v"(cv[c][q + 3]), "v"(cv[c][q + 4]));
