@@ -1290,7 +1290,8 @@ void AcqRun::launch_list(int ncells, Rec *recs, const CellList &cl, int cell0, h
         if (mid) (void)hipEventRecord(mid, s_main);
         const int qch = ctx->tune.pfa_qchunk > 0 ? ctx->tune.pfa_qchunk : 1;  // (one tile of a cell, then the same tile of the next cell)
         const long items = (long)((pfa::kTiles + qch - 1) / qch) * qch * ncells;
-        const unsigned cgrid = (unsigned)std::min<long>(items, ctx->tune.pfa_cgrid > 0 ? ctx->tune.pfa_cgrid : 8192);
+        // (a workgroup loads the 57 KB coefficient table once: at least ~24 items each when the launch is small -- one PRN's row per pair)
+        const unsigned cgrid = (unsigned)std::min<long>(items, ctx->tune.pfa_cgrid > 0 ? ctx->tune.pfa_cgrid : std::max<long>(512, std::min<long>(8192, items / 24)));
         pfa::ColsArgs ca{(const uint32_t *)a.d_Bw, a.d_pfa_coef, ncells, w0, w1, so1.cellmax, so1.lb, so1.lb_div, so1.extra, so1.extra_count,
                          so1.extra_cap, cell0, so1.keep, qch, nullptr, nullptr, -1, -1};
         hipLaunchKernelGGL((pfa::k_pfa_cols<2, false>), dim3(cgrid), dim3(pfa::kColsThreads), pfa::kColsLds, s_main, ca);

@@ -11,8 +11,8 @@ import bds_amd  # noqa: E402
 import bench  # noqa: E402
 
 s, x, sats, _ = bench.build_workload("b1c")
-VARIANTS = [{}, {"BDS_ACQ_PFA_QCHUNK": "2"}, {"BDS_ACQ_PFA_QCHUNK": "8"}, {"BDS_ACQ_PFA_QCHUNK": "14"}, {"BDS_ACQ_PFA_CGRID": "2048"}, {"BDS_ACQ_PFA_CGRID": "8192"},
-            {"BDS_ACQ_PFA_CGRID": "1024"}, {"BDS_ACQ_LIST_GC": "201"}, {"BDS_ACQ_LIST_GC": "-1"}, {"BDS_ACQ_PAIR_GB": "0"}, {"BDS_ACQ_PAIR_GB": "80"},
+VARIANTS = [{}, {"BDS_ACQ_PFA_QCHUNK": "2"}, {"BDS_ACQ_PFA_QCHUNK": "4"}, {"BDS_ACQ_PFA_QCHUNK": "8"}, {"BDS_ACQ_PFA_CGRID": "2048"}, {"BDS_ACQ_PFA_CGRID": "4096"},
+            {"BDS_ACQ_PFA_CGRID": "16384"}, {"BDS_ACQ_PFA_CGRID": "32768"}, {"BDS_ACQ_LIST_GC": "201"}, {"BDS_ACQ_PAIR_GB": "0"}, {"BDS_ACQ_PAIR_GB": "20"}, {"BDS_ACQ_PAIR_GB": "80"},
             {"BDS_ACQ_PAIR_GB": "auto"}, {"BDS_ACQ_PFA": "0"}, {}]
 for env in VARIANTS:
     for k, v in env.items():

@@ -331,5 +331,57 @@ int main(int argc, char **argv) {
                    (double)st[3] / std::max(1ull, st[1]), st[2], n_ex);
         }
     }
+    // ---------------- the row pass of one half of the cells beside the column pass of the other half (two streams), against the same four launches in a row
+    if (prns >= 2) {
+        hipStream_t s1, s2;
+        CK(hipStreamCreate(&s1));
+        CK(hipStreamCreate(&s2));
+        hipEvent_t evA, evB, t0, t1;
+        CK(hipEventCreate(&evA));
+        CK(hipEventCreate(&evB));
+        CK(hipEventCreate(&t0));
+        CK(hipEventCreate(&t1));
+        const int nA = (prns / 2) * D, nB = ncells - nA, gc = 67;
+        auto rows = [&](hipStream_t st, int off, int n) {
+            RowsArgs r{d_Xs, d_Cs, d_Bw + (size_t)off * kCellElems, d_bin + off, d_cs + off, n, gc, 1};
+            hipLaunchKernelGGL(k_pfa_rows<2>, dim3(MP * K2 * ((n + gc - 1) / gc)), dim3(kRowsThreads), rows_lds, st, r);
+        };
+        auto cols = [&](hipStream_t st, int off, int n) {
+            ColsArgs c{d_Bw + (size_t)off * kCellElems, d_coef, n, 0.52440442f, 0.85146932f, d_cellmax, d_lb, D, d_extra, d_extra_count, extra_cap, off, 0.996f, 1, nullptr, nullptr, -1, -1};
+            hipLaunchKernelGGL((k_pfa_cols<2, false>), dim3(8192), dim3(kColsThreads), kColsLds, st, c);
+        };
+        float best_seq = 1e9f, best_ovl = 1e9f;
+        for (int rep = 0; rep < 2 * reps; ++rep) {
+            const bool ovl = rep & 1;
+            CK(hipMemset(d_cellmax, 0, ncells * sizeof(unsigned long long)));
+            CK(hipMemset(d_lb, 0, ncells * sizeof(float)));
+            CK(hipMemset(d_extra_count, 0, sizeof(int)));
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(t0, s1));
+            rows(s1, 0, nA);
+            CK(hipEventRecord(evA, s1));
+            hipStream_t sc = ovl ? s2 : s1;
+            if (ovl) { CK(hipStreamWaitEvent(s2, evA, 0)); }
+            if (ovl) {
+                rows(s1, nA, nB);  // (enqueued first: both queues have work when the first row pass ends)
+                CK(hipEventRecord(evB, s1));
+                cols(sc, 0, nA);
+                CK(hipStreamWaitEvent(s2, evB, 0));
+                cols(sc, nA, nB);
+                CK(hipEventRecord(t1, s2));
+            } else {
+                cols(s1, 0, nA);
+                rows(s1, nA, nB);
+                cols(s1, nA, nB);
+                CK(hipEventRecord(t1, s1));
+            }
+            CK(hipDeviceSynchronize());
+            float ms;
+            CK(hipEventElapsedTime(&ms, t0, t1));
+            (ovl ? best_ovl : best_seq) = std::min(ovl ? best_ovl : best_seq, ms);
+        }
+        printf("two halves of %d + %d cells: rows, columns, rows, columns in a row %.3f ms per 201 cells; the second row pass beside the first column pass (two streams) %.3f ms\n",
+               nA, nB, best_seq / prns, best_ovl / prns);
+    }
     return 0;
 }
