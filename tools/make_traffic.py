@@ -27,10 +27,11 @@ def counters(prefix):
 rn, r = counters("k_rows_")
 cn, c = counters(sys.argv[5] if len(sys.argv) > 5 else "k_cols_wave_f")
 # FETCH_SIZE correction per kernel (MI355X_MICROARCH.md, HBM: "x 2 for wide coalesced streaming reads ... other access widths are
-# uncalibrated: calibrate on a known byte count in your own access pattern").  argv[7] = factor of the column pass: the N-point
-# pair's column pass (k_pfa_cols) requests 64-byte pieces and reads every byte of the inter-pass buffer exactly once -- 16.2 MB per
-# cell by construction --: its raw FETCH_SIZE is 1.10 x that (= TCC_MISS x 64 B), doubled it would be 8.3 TB/s with the matrix
-# instructions compiled out (profiles/r06_pfa53_parts.txt): more than the chip's peak.  Factor 1 there.
+# uncalibrated: calibrate on a known byte count in your own access pattern").  argv[7] = factor of the column pass.  The N-point
+# pair's column pass (k_pfa_cols) reads every byte of the inter-pass buffer exactly once -- 16.26 MB per cell by construction: that is
+# the calibration.  With the buffer in tiles (a workgroup's item one contiguous 83 KB block) its raw FETCH_SIZE is 0.53 x that: the
+# guide's factor 2 (1.06 x the known bytes).  With the first layout of round 6 (64-byte pieces 50 KB apart) the raw counter was
+# 1.10 x the known bytes and the factor 1 (doubled it would have been 8.3 TB/s with the matrix instructions compiled out).
 cf = float(sys.argv[7]) if len(sys.argv) > 7 else 2.0
 total = 1024.0 * (2 * r["FETCH_SIZE"] + r["WRITE_SIZE"] + cf * c["FETCH_SIZE"] + c["WRITE_SIZE"])
 out = {"workload": workload, "cells_per_pair": cells, "round": (sys.argv[6] if len(sys.argv) > 6 else "round 4"), "bytes_per_pair": total,

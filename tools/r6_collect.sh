@@ -9,7 +9,7 @@ cp gpurun_out/kernel_stats_trk_WB.txt profiles/r06_trk_wb_kernel_stats.txt
 tail -1 gpurun_out/bench_b1c.json > profiles/r06_bench_b1c.json
 tail -1 gpurun_out/bench_b2a.json > profiles/r06_bench_b2a.json
 cp gpurun_out/bench_under_rocprof_b1c.json profiles/r06_bench_b1c_under_rocprof.json 2>/dev/null
-python tools/make_traffic.py gpurun_out/pmc_summary_default.txt b1c ${PMC_CELLS:-1608} profiles/r06_b1c_pmc.txt k_pfa_cols "round 6" 1 > /dev/null
+python tools/make_traffic.py gpurun_out/pmc_summary_default.txt b1c ${PMC_CELLS:-1608} profiles/r06_b1c_pmc.txt k_pfa_cols "round 6" 2 > /dev/null
 python tools/make_valu.py gpurun_out/pmc_summary_default.txt profiles/r06_isa_mix.json b1c ${PMC_CELLS:-1608} "round 6" pfa > /dev/null
 python - <<'PY'
 import json
