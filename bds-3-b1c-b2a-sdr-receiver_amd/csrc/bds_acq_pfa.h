@@ -437,17 +437,14 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
         const unsigned cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
         // |y|^2 of output block nb: m2[c][i] for the lane's (t1, t3) -- each output in ONE lane of its (re, im) pair: the even lane holds
         // t2 = 0, 1, .., 5 (i = t2), the odd lane t2 = 6, 11, 10, .., 7 (i = 0, 1, .., 5: t2 = 12 - i)
-        auto block = [&](int nb, float (&m2)[2][6], auto parts_tag) {
+        auto matrix = [&](int nb, f4 (&acc2)[NC][3], auto parts_tag) {
             constexpr int PARTS = decltype(parts_tag)::value;  // 2: coefficients hi + lo (the values), 1: hi only (the bound pass)
             uint4 fb[4][2];
 #pragma unroll
             for (int ins = 0; ins < 4; ++ins)
 #pragma unroll
                 for (int part = 0; part < PARTS; ++part) fb[ins][part] = s_coef[((nb * 4 + ins) * 2 + part) * 64 + lane];
-            // the MFMAs of BOTH components first (six independent accumulator chains), then the two epilogues: component 1's matrix
-            // work runs under component 0's vector work (columns 1.28 -> 1.25 ms per 201 cells; the epilogue itself on packed
-            // (component 0, component 1) pairs measured no faster -- this kernel waits on latency, not on issue slots: HISTORY.md 8)
-            f4 acc2[NC][3];
+            // (six independent accumulator chains: both components)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -466,6 +463,8 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                                                                                    acc2[c][quad], 0, 0, 0);
 #endif
             }
+        };
+        auto epilogue = [&](const f4 (&acc2)[NC][3], float (&m2)[2][6]) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const f4(&acc)[3] = acc2[c];
@@ -502,12 +501,25 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                 }
             }
         };
+        auto block = [&](int nb, float (&m2)[2][6], auto parts_tag) {
+            f4 acc2[NC][3];
+            matrix(nb, acc2, parts_tag);
+            epilogue(acc2, m2);
+        };
         const int t3o = t0 + (lane >> 4);  // the lag t3 of this lane's outputs
         constexpr int kParts1 = DBG ? 2 : kBoundParts;  // (the debug instantiation reports this pass's values: both parts)
         float best = 0.f, ssum = 0.f;
+        // The bound pass, software-pipelined: the matrix instructions of output block nb + 1 are in flight while the vector pipe works on
+        // block nb's accumulators (two waves per SIMD that started together stay in step -- both in their matrix phase, then both in
+        // their epilogue -- so the overlap has to come from inside the wave).  Fully unrolled: one scheduling region (0.93 -> 0.905 ms per
+        // 201 cells; a forced 1 : 6 or 1 : 9 matrix : vector interleave by sched_group_barrier measured the same).
+        f4 accp[2][NC][3];
+        matrix(0, accp[0], std::integral_constant<int, kParts1>{});
+#pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             float m2[2][6];
-            block(nb, m2, std::integral_constant<int, kParts1>{});
+            if (nb + 1 < NB) matrix(nb + 1, accp[(nb + 1) & 1], std::integral_constant<int, kParts1>{});
+            epilogue(accp[nb & 1], m2);
             const int t1 = (16 * nb + (lane & 15)) >> 1;
             float bmax = 0.f;
             if (t1 < K1 && t3o < K3) {
