@@ -58,6 +58,31 @@ def test_doppler_steps_of_two_bins_and_a_narrow_band(block, monkeypatch):
     assert inside and all(a[0][0][p - 1] != 0 for p in inside) and a[0][0][4] == 0
 
 
+def test_peaks_on_the_edges_of_the_three_dimensions(monkeypatch):
+    """six satellites whose correlation peaks sit at the first / last index of the 53-, 12- and 3125-point dimensions and on both sides of
+    the inter-pass buffer's tile boundaries (lag in the tile 0 / 15, the last tile's 5 lags): lag = t1 N/53 + t2 N/12 + t3 N/3125 mod N"""
+    from helpers import spc_of
+
+    s = bds_amd.init_settings_b1c(samplingFreq=99.375e6, IF=14.58e6, acqSatelliteList=list(range(1, 64)), acqCohT=10, pilotACQflag=1,
+                                  acqSearchBand=2100.0)
+    spc = spc_of(s)
+    edges = [(0, 0, 0), (52, 11, 3124), (26, 5, 3120), (1, 1, 15), (51, 10, 16), (13, 7, 3119)]
+    lags = [(t1 * (N // 53) + t2 * (N // 12) + t3 * (N // 3125)) % N for t1, t2, t3 in edges]
+    prns = [3, 11, 17, 29, 41, 53]
+    sats = [synth.Sat(p, 50.0 * (7 * i - 17), float(t % spc), 0.3 + i, 50.0) for i, (p, t) in enumerate(zip(prns, lags))]
+    x = synth.make_if(s, sats, 4 * spc, seed=41, code_doppler=False)
+    a = _run(monkeypatch, s, x, prns + [5])
+    b = _run(monkeypatch, s, x, prns + [5], {"BDS_ACQ_PFA": "0"})
+    assert (a[1]["rows_kernel"], a[1]["cols_kernel"], a[1]["fft_len"]) == (3, 4, N) and b[1]["fft_len"] == 3145728
+    _same_decisions(a, b)
+    for i, (p, t) in enumerate(zip(prns, lags)):
+        assert a[0][0][p - 1] != 0, p
+        bin_ = int(np.argmax(a[2][i]))
+        assert int(a[3][i][bin_]) % spc == t % spc == int(b[3][i][bin_]) % spc, (p, edges[i], int(a[3][i][bin_]), t)
+        assert abs(a[0][1][p - 1] - (t % spc)) <= 1.0, (p, a[0][1][p - 1], t % spc)  # codePhase (0-based sample of the code start)
+    assert a[0][0][4] == 0
+
+
 @pytest.mark.parametrize("change,why", [(dict(acqStep=25.0, acqSearchBand=500.0), "half a spectrum bin per Doppler step"),
                                         (dict(pilotACQflag=0), "one component"),
                                         (dict(acqCohT=5), "N = 15 ms of samples")])

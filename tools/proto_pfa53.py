@@ -159,8 +159,9 @@ def mfma_16x16x32(a_frag, b_frag, acc):
 
 
 def buffer_layout(cells_rows):
-    """inter-pass buffer of one cell and component as the row pass leaves it: [mg][k2][t3][mi][re, im] fp16 -- a lane's A fragment
-    (4 consecutive k1 of one (k2, t3)) is 16 contiguous bytes, a row workgroup (mg, k2) writes 50 KB contiguous.
+    """inter-pass buffer of one cell and component, as a plain [mg][k2][t3][mi][re, im] fp16 container: a lane's A fragment = 4 consecutive
+    k1 of one (k2, t3).  (The kernels' buffer holds both components and is tiled over t3 -- [tile of 16 lags][mp][k2][lag][component][mi],
+    csrc/bds_acq_pfa.h bw_piece -- so that a column workgroup's item is one contiguous block; the fragment is the same 4 values.)
     cells_rows: complex [53][12][3125] (k1, k2, t3) -> fp16 array [14][12][3125][4][2]"""
     buf = np.zeros((MG, K2, K3, 4, 2), dtype=np.float16)
     for k1 in range(K1):
@@ -203,14 +204,20 @@ def cols_wave(buf, t0, hi, lo):
             v = np.array([acc[k2 // 4, lane, k2 % 4] for k2 in range(12)], dtype=np.float64)
             F = np.array([np.sum(v * w12[(np.arange(12) * t2) % 12]) for t2 in range(12)])
             P[lane], Q[lane] = F.real, F.imag
+        # |y[t]|^2 = S + X, |y[12 - t]|^2 = S - X with S = P_e^2 + Q_e^2 + P_o^2 + Q_o^2 and X = 2 (Q_e P_o - P_e Q_o) (e / o = the even / odd lane
+        # of the pair): each lane forms x = Q P' - P Q' from its own and its partner's (') values; S + 2 x is |y[t]|^2 in the even lane and
+        # |y[12 - t]|^2 in the odd lane.  Slot 0: the even lane holds t2 = 0, the odd lane t2 = 6 (Q = 0 there).
         for lane in range(64):
             G, o = lane >> 4, 16 * nb + (lane & 15)
-            if o >= 2 * K1 or (lane & 1):
+            if o >= 2 * K1:
                 continue
-            t1 = o // 2
-            y_re = P[lane] - Q[lane ^ 1]       # partner = the imaginary-part lane (DPP quad_perm [1,0,3,2])
-            y_im = Q[lane] + P[lane ^ 1]
-            res[t1, :, G] = y_re ** 2 + y_im ** 2
+            t1, odd, pr = o // 2, lane & 1, lane ^ 1
+            t2_0 = 6 if odd else 0
+            res[t1, t2_0, G] = P[lane][t2_0] ** 2 + P[pr][t2_0] ** 2
+            for t in range(1, 6):
+                S = P[lane][t] ** 2 + Q[lane][t] ** 2 + P[pr][t] ** 2 + Q[pr][t] ** 2
+                x = Q[lane][t] * P[pr][t] - P[lane][t] * Q[pr][t]
+                res[t1, 12 - t if odd else t, G] = S + 2 * x
     return res
 
 
