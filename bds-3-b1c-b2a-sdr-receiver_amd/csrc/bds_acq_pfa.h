@@ -192,8 +192,11 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
     for (int u = 1; u < 5; ++u) tw2[u] = unit((si * u) % 125, 125);
 
     const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)A.Xs, 0, K1 * K2 * 2 * K3 * 4, 0x00020000);
+    // The next cell's Doppler bin is requested right behind this cell's signal loads and taken into a scalar in front of this cell's
+    // stores: a vector load at the head of the loop would be waited for with vmcnt(0), i.e. together with the stores just issued.
+    int bin_cur = A.bin[c0];
     for (int cell = c0; cell < c1; ++cell) {
-        const int s = A.bin[cell] * A.shift;
+        const int s = bin_cur * A.shift;
         const int k1s = ((k1c - s) % K1 + K1) % K1, k2s = ((k2 - s) % K2 + K2) % K2, o3 = (K3 - s % K3) % K3;
         // (buffer loads / stores: one descriptor, one lane offset, the 25 strides as immediates -- per-access 64-bit address arithmetic was
         //  five vector instructions per load: 8 % of the cell loop)
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
 #pragma unroll
         for (int q = 0; q < 25; ++q) xn[q] = __builtin_amdgcn_raw_buffer_load_b32(xs_rsrc, xoff, 500 * q, 0);
 #endif
+        int bin_next = A.bin[min(cell + 1, c1 - 1)];
         uint32_t outp[NC][25];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -288,6 +292,16 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
         // (descriptor at the piece of lag 0: a lag's offset is tile * 82 944 + (lag in the tile) * 16 bytes)
         const __amdgpu_buffer_rsrc_t dst_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(A.Bw + (size_t)cell * kCellElems + bw_piece(mp, k2, 0)), 0,
                                                                                    (unsigned)((kCellElems - bw_piece(mp, k2, 0)) * 4), 0x00020000);
+        asm volatile("" : "+v"(bin_next));  // (the bin's wait stands here: every load long back, no store in flight yet)
+        bin_cur = __builtin_amdgcn_readfirstlane(bin_next);
+        typedef int v4i __attribute__((ext_vector_type(4)));
+#ifdef PFA_EXP_R_SAMECELL  // (timing experiment: every cell's stores into the first cell's 16 MB -- the Infinity Cache takes them)
+        const unsigned long long dst_base = (unsigned long long)(A.Bw + bw_piece(mp, k2, 0));
+#else
+        const unsigned long long dst_base = (unsigned long long)(A.Bw + (size_t)cell * kCellElems + bw_piece(mp, k2, 0));
+#endif
+        const v4i dst_words = {(int)(unsigned)dst_base, (int)((unsigned)(dst_base >> 32) & 0xffffu), (int)(unsigned)((kCellElems - bw_piece(mp, k2, 0)) * 4), 0x00020000};
+        (void)dst_rsrc;
 #pragma unroll
         for (int e = 0; e < 25; e += 2) {
             uint32_t P[2], Q[2];
@@ -305,7 +319,17 @@ __global__ __launch_bounds__(kRowsThreads, 2) void k_pfa_rows(RowsArgs A) {
 #ifdef PFA_EXP_R_NOSTORE
                 asm volatile("" ::"v"(P[0]), "v"(Q[0]), "v"(P[1]), "v"(Q[1]), "v"(t3s));
 #else
+#ifdef PFA_ROWS_STORE_BUILTIN
                 __builtin_amdgcn_raw_buffer_store_b128((u4){P[0], Q[0], P[1], Q[1]}, dst_rsrc, (int)(bw_piece(0, 0, t3s) * 4), 0, 0);
+#else
+                // Issued by hand: loads and stores share the vmcnt counter and return out of order relative to each other, so with stores
+                // the compiler knows of in flight its first wait for a load of the NEXT cell becomes vmcnt(0) -- the whole latency of this
+                // cell's 13 stores in front of every cell (the row pass with its stores compiled out ran 17 % faster).  Stores it does not
+                // know of only make its counted waits longer, never shorter: of the k + S operations a wait lets return, at most S are stores.
+                // Nothing in this kernel reads the buffer; the end of the kernel makes the stores visible.
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n s_nop 0" ::"v"((u4){P[0], Q[0], P[1], Q[1]}), "v"((int)(bw_piece(0, 0, t3s) * 4)), "s"(dst_words)
+                             : "memory");
+#endif
 #endif
             }
         }
@@ -425,16 +449,18 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                 const size_t off = bw_piece(0, 4 * quad + r, t3);
 #ifdef PFA_EXP_C_NOLOAD
                 l0 = make_uint4(0x3c003800u + lane, 0x38003c00u + (unsigned)item, 0x3c003400u + quad, 0x34003c00u + ins), l1 = l0;
-                if (false)
+                if (false) {
+#else
+                {
 #endif
-                if (2 * mg < MP) l0 = *reinterpret_cast<const uint4 *>(base + (size_t)(2 * mg) * K2 * (kTileLags * 4) + off);
-                if (2 * mg + 1 < MP) l1 = *reinterpret_cast<const uint4 *>(base + (size_t)(2 * mg + 1) * K2 * (kTileLags * 4) + off);
+                // (rows past the 54th -- k1 >= 54: the K padding of the last matrix instruction -- read row pair 26 again: their coefficients are
+                //  zeros and the buffer holds finite values, and a load under a lane condition costs a branch and a full vmcnt(0) wait per quad)
+                l0 = *reinterpret_cast<const uint4 *>(base + (size_t)min(2 * mg, MP - 1) * K2 * (kTileLags * 4) + off);
+                l1 = *reinterpret_cast<const uint4 *>(base + (size_t)min(2 * mg + 1, MP - 1) * K2 * (kTileLags * 4) + off);
+                }
                 fa[0][quad][ins] = make_uint4(l0.x, l0.y, l1.x, l1.y);
                 fa[1][quad][ins] = make_uint4(l0.z, l0.w, l1.z, l1.w);
             }
-        // the cell's maximum so far and the PRN's running bound; stale values are lower values: a redundant visit of the exact pass
-        const float lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned cur = (unsigned)(__hip_atomic_load(A.cellmax + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
         // |y|^2 of output block nb: m2[c][i] for the lane's (t1, t3) -- each output in ONE lane of its (re, im) pair: the even lane holds
         // t2 = 0, 1, .., 5 (i = t2), the odd lane t2 = 6, 11, 10, .., 7 (i = 0, 1, .., 5: t2 = 12 - i)
         auto matrix = [&](int nb, f4 (&acc2)[NC][3], auto parts_tag) {
@@ -515,21 +541,26 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
         // 201 cells; a forced 1 : 6 or 1 : 9 matrix : vector interleave by sched_group_barrier measured the same).
         f4 accp[2][NC][3];
         matrix(0, accp[0], std::integral_constant<int, kParts1>{});
+        // the cell's maximum so far and the PRN's running bound; stale values are lower values: a redundant visit of the values' pass.
+        // (Requested here, behind block 0's matrix instructions and their wait for the fragments: two device-scope loads in front of
+        //  that wait would hold up the whole item, here they have six output blocks to arrive in.)
+        const float lbv = __hip_atomic_load(lbp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the value half of the packed word alone: with the 64-bit load the compiler reuses the dead low register at once and waits for it)
+        const unsigned cur = __hip_atomic_load(reinterpret_cast<const unsigned *>(A.cellmax + cell) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             float m2[2][6];
             if (nb + 1 < NB) matrix(nb + 1, accp[(nb + 1) & 1], std::integral_constant<int, kParts1>{});
             epilogue(accp[nb & 1], m2);
             const int t1 = (16 * nb + (lane & 15)) >> 1;
-            float bmax = 0.f;
-            if (t1 < K1 && t3o < K3) {
+            float bmax = 0.f, bsum = 0.f;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const float e = NC == 2 ? m2[0][i] + m2[1][i] : m2[0][i];
-                    bmax = fmaxf(bmax, e), ssum += e;
-                }
+            for (int i = 0; i < 6; ++i) {
+                const float e = NC == 2 ? m2[0][i] + m2[1][i] : m2[0][i];
+                bmax = fmaxf(bmax, e), bsum += e;
             }
-            best = fmaxf(best, bmax);
+            if (!(t1 < K1 && t3o < K3)) bmax = 0.f, bsum = 0.f;  // (selects, no branch: the seven blocks stay one scheduling region)
+            best = fmaxf(best, bmax), ssum += bsum;
             s_bm[nb * kColsThreads + tid] = bmax;  // (read back by this lane only, in the rare values' pass)
             if (DBG && cell == A.dbg_cell && t0 / 4 == A.dbg_group && t1 < K1) {
 #pragma unroll
@@ -550,9 +581,11 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
             // <= 2^-11 sqrt(636) ||x||_2 over the 636 inputs of a lag t3, and ||x||_2 <= ||y_hi||_2 / (sqrt(636) - ||T_lo||) with
             // ||T_lo|| <= sqrt(12) * 53 * 2^-11.5 = 0.063: delta_c <= 4.9e-4 sqrt(sum over the lag's 636 outputs of |y_hi,c|^2), and by
             // Minkowski sqrt(|y_d|^2 + |y_p|^2) grows by at most sqrt(delta_d^2 + delta_p^2) = 4.9e-4 sqrt(sum of what `best` is the max of).
-            float s16 = ssum;  // the 16 lanes of a lag
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) s16 += __shfl_xor(s16, o);
+            float s16 = ssum;  // the 16 lanes of a lag: rotations within the DPP row (row_ror 8, 4, 2, 1), no LDS round trips
+            s16 += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s16), 0x128, 0xf, 0xf, true));
+            s16 += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s16), 0x124, 0xf, 0xf, true));
+            s16 += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s16), 0x122, 0xf, 0xf, true));
+            s16 += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s16), 0x121, 0xf, 0xf, true));
             dlt = 5.0e-4f * sqrtf(s16);
         }
         const float ub = wave_max_f32(sqrtf(best) + dlt);
