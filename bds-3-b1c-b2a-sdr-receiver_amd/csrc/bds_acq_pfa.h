@@ -425,13 +425,16 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
     auto t2_of = [&](int i) { return odd ? (i == 0 ? 6 : 12 - i) : i; };  // the output t2 behind slot i of this lane
     constexpr int kBlocks = kTiles;  // 196 blocks of 16 lags t3 per cell = the tiles of the inter-pass buffer
     const int qch = A.qchunk > 0 ? A.qchunk : 1, nq = (kBlocks + qch - 1) / qch;
-    const long n_items = (long)nq * A.ncells * qch;
     // work list: qch adjacent tiles of one cell (83 KB each, contiguous), then the same tiles of the NEXT cell: the workgroups that run
     // together work on different cells, so a cell's running maximum is settled by its first few waves (qch = 1: 2.4 % of the wave items go
     // through the values' pass, 4: 3.0 %, 8: 3.8 %)
-    for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int b = (int)(item % qch), cl = (int)((item / qch) % A.ncells), q = (int)(item / ((long)qch * A.ncells));
-        const int blk = q * qch + b;
+    // (item = (q ncells + cl) qch + b walked in its three digits: the divisions of a 64-bit item number by run-time values were ~400 scalar
+    //  instructions per item)
+    const unsigned ncl = (unsigned)A.ncells, uq = (unsigned)qch;
+    unsigned b = blockIdx.x % uq, cl = (blockIdx.x / uq) % ncl, q = blockIdx.x / (uq * ncl);
+    const unsigned gb = gridDim.x % uq, gcl = (gridDim.x / uq) % ncl, gq = gridDim.x / (uq * ncl);
+    for (; q < (unsigned)nq; b += gb, cl += gcl + (b >= uq ? (b -= uq, 1u) : 0u), q += gq + (cl >= ncl ? (cl -= ncl, 1u) : 0u)) {
+        const int blk = (int)(q * uq + b);
         const int t0 = 16 * blk + 4 * wave;
         if (blk >= kBlocks || t0 >= K3) continue;
         const int cell = A.cell0 + cl;
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(kColsThreads, 2) void k_pfa_cols(ColsArgs A) {
                 uint4 l0 = make_uint4(0, 0, 0, 0), l1 = l0;
                 const size_t off = bw_piece(0, 4 * quad + r, t3);
 #ifdef PFA_EXP_C_NOLOAD
-                l0 = make_uint4(0x3c003800u + lane, 0x38003c00u + (unsigned)item, 0x3c003400u + quad, 0x34003c00u + ins), l1 = l0;
+                l0 = make_uint4(0x3c003800u + lane, 0x38003c00u + cl + blk, 0x3c003400u + quad, 0x34003c00u + ins), l1 = l0;
                 if (false) {
 #else
                 {
