@@ -218,11 +218,11 @@ BDS_API int bds_acq_run(bds_ctx *ctx, const bds_settings *s, const int32_t *prn_
 /* Budget of the search's inter-pass buffer: a launch pair (row pass + column pass) carries as many PRNs' Doppler rows as fit
  * `gib` GiB; a call is then a few long launches.  cfg3 (63 PRNs x 201 bins) on one box, round 6 (the N-point pair of
  * csrc/bds_acq_pfa.h: 3.3 GB per PRN; profiles/r06_pfa53_knobs_tiled.txt):
- *     0        one PRN per pair,  3.3 GB    148.4 ms per call     (the minimal footprint)
- *    20        5 - 6 PRNs per pair          139.5
- *    40        12 - 13 PRNs per pair        136.0 - 137.3         (the DEFAULT)
- *    80        21 PRNs per pair             135.8
- *   < 0       60 % of the device memory that is free: 32 + 31 PRNs, 100 GiB    134.4   (the SERVING mode; bench.py key `serving`)
+ *     0        one PRN per pair,  3.3 GB    144.6 ms per call     (the minimal footprint)
+ *    20        5 - 6 PRNs per pair          132.8
+ *    40        12 - 13 PRNs per pair        132.1 - 133.0         (the DEFAULT)
+ *    80        21 PRNs per pair             132.8
+ *   < 0       60 % of the device memory that is free: 32 + 31 PRNs, 100 GiB    132.2   (the SERVING mode; bench.py key `serving`)
  * With the L-point pair of rounds 3-5 (5 GB per PRN; every configuration the N-point pair does not cover) more PRNs per pair also
  * shared the 2.5 GB of signal-spectrum rows in L2: 196.7 / 191.6 - 192.1 (8 PRNs) / 189.3 - 189.8 / 186.8 - 187.1 ms.
  * The price is the footprint, and time when it changes hands: a fresh allocation is free (a first call costs the same in every

@@ -69,10 +69,12 @@ power = {"measured_W": 1325, "cap_W": 1400, "sclk_MHz": 1996,
                  "v_fma_f32 stream reaches 0.96 wave-instructions per ns and SIMD (81 % of the 2.4 GHz peak) at ANY occupancy >= 2"}
 if PFA:  # the round-6 pair: sustained 20-s loops, tools/power_sustained.py -> profiles/r06_power_sustained.txt (first line)
     try:
-        pj = json.loads(open("profiles/r06_power_sustained.txt").readline())
+        pjs = [json.loads(l) for l in open("profiles/r06_power_sustained.txt") if l.startswith("{")]
+        pj = pjs[0]
+        desc = "; ".join("%s %.1f ms per call at %.0f W / %.2f GHz = %.0f J" % (q["label"], q["ms_per_call"], q["power_W"]["median"], q["sclk_MHz"]["median"] / 1e3,
+                                                                                q["ms_per_call"] * q["power_W"]["median"] / 1e3) for q in pjs)
         power = {"measured_W": pj["power_W"]["median"], "cap_W": 1400, "sclk_MHz": pj["sclk_MHz"]["median"], "ms_per_call": pj["ms_per_call"],
-                 "note": "tools/power_sustained.py: 20-s loop of bds_acq_run, sysfs power / clock at ~20 Hz (profiles/r06_power_sustained.txt: the N-point pair "
-                         "1320 W at 1.92 GHz, 216 J per call; the L-point pair on the same box 1354 W at 1.96 GHz, 260 J per call)"}
+                 "note": "tools/power_sustained.py: 20-s loops of bds_acq_run, sysfs power / clock at ~20 Hz (profiles/r06_power_sustained.txt: " + desc + ")"}
     except Exception:
         pass
 out = {"workload": workload, "cells_per_pair": cells, "round": rnd, "insts_per_pair": tot["insts"],
